@@ -1,0 +1,143 @@
+"""ctypes binding of libdgsct.so (include/dgsct.h).  No CPU fallback: if the HIP library is missing
+or does not load, importing the product path raises -- build it with ``python -m dgsct_amd.build``
+(or ``__graft_entry__.build()``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdgsct.so")
+
+F32, BF16 = 0, 1
+REMAP_CONV, REMAP_FIXED = 0, 1
+
+# parameter table order == enum in include/dgsct.h; values are the reference state_dict names
+PARAM_NAMES: List[str] = [
+    "gate", "my_tokens", "gate_av", "conv_adapter.weight", "conv_adapter.bias", "fc.weight", "fc.bias",
+    "fc_affine_audio_1.weight", "fc_affine_audio_1.bias", "fc_affine_video_1.weight", "fc_affine_video_1.bias",
+    "fc_affine_bottleneck.weight", "fc_affine_bottleneck.bias", "fc_affine_video_2.weight", "fc_affine_video_2.bias",
+    "fc_affine_audio_2.weight", "fc_affine_audio_2.bias", "fc_affine_v_s_att.weight", "fc_affine_v_s_att.bias",
+    "fc_affine_v_c_att.weight", "fc_affine_v_c_att.bias", "down_sampler.weight", "up_sampler.weight",
+    "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var",
+    "bn2.weight", "bn2.bias", "bn2.running_mean", "bn2.running_var",
+    "ln_before.weight", "ln_before.bias", "ln_post.weight", "ln_post.bias",
+    "temporal_gated.0.weight", "temporal_gated.0.bias",
+]
+P_COUNT = len(PARAM_NAMES)
+P_INDEX = {n: i for i, n in enumerate(PARAM_NAMES)}
+P_WN = P_INDEX["conv_adapter.weight"]
+
+
+class AdapterDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("BT", "T", "N", "C", "No", "Co", "tk", "r", "g", "dtype", "remap", "use_bn", "use_gate",
+                                         "ln_before", "ln_post", "gate_before_ln_post", "temporal", "training")] + \
+               [(n, C.c_float) for n in ("alpha", "beta", "gamma", "eps", "bn_momentum")]
+
+
+class Sizes(C.Structure):
+    _fields_ = [("prep_bytes", C.c_int64), ("saved_bytes", C.c_int64), ("ws_fwd_bytes", C.c_int64),
+                ("ws_bwd_bytes", C.c_int64), ("grad_floats", C.c_int64),
+                ("grad_offset", C.c_int64 * P_COUNT), ("grad_numel", C.c_int64 * P_COUNT)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("KB", C.c_int32),
+                ("batch", C.c_int32), ("splitk", C.c_int32), ("atomic", C.c_int32),
+                ("A", C.c_void_p), ("lda", C.c_int64), ("a_kmajor", C.c_int32), ("a_bs", C.c_int64), ("a_kbs", C.c_int64),
+                ("B", C.c_void_p), ("ldb", C.c_int64), ("b_kmajor", C.c_int32), ("b_bs", C.c_int64), ("b_kbs", C.c_int64),
+                ("D", C.c_void_p), ("ddt", C.c_int32), ("ldd", C.c_int64), ("dbs", C.c_int64),
+                ("alpha", C.c_float), ("alpha_ptr", C.c_void_p),
+                ("bias_m", C.c_void_p), ("bias_n", C.c_void_p), ("bias_n_bs", C.c_int64), ("m_mod", C.c_int32),
+                ("r1_m", C.c_void_p), ("r1_n", C.c_void_p), ("act", C.c_int32),
+                ("R", C.c_void_p), ("rdt", C.c_int32), ("ldr", C.c_int64), ("rbs", C.c_int64), ("beta", C.c_float),
+                ("mask", C.c_void_p), ("ldmask", C.c_int64), ("maskbs", C.c_int64)]
+
+
+EXPORTS = ["dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
+           "dgsct_adapter_backward", "dgsct_saved_region", "dgsct_test_gemm"]
+
+_PP = C.POINTER(C.c_void_p)
+
+
+class Lib:
+    """One loaded instance of the C ABI."""
+
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(f"dg-sct_amd: HIP library not found at {path}; there is no CPU fallback. "
+                               f"Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        self.path = path
+        self.c = C.CDLL(path)
+        for name in EXPORTS:
+            if not hasattr(self.c, name):
+                raise RuntimeError(f"dg-sct_amd: {path} does not export {name}")
+        c = self.c
+        c.dgsct_version.restype = C.c_int
+        c.dgsct_arch.restype = C.c_char_p
+        c.dgsct_last_error.restype = C.c_char_p
+        c.dgsct_query.argtypes = [C.POINTER(AdapterDesc), C.POINTER(Sizes)]
+        c.dgsct_prepare.argtypes = [C.POINTER(AdapterDesc), _PP, C.c_void_p, C.c_void_p]
+        c.dgsct_adapter_forward.argtypes = [C.POINTER(AdapterDesc), _PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        c.dgsct_adapter_backward.argtypes = [C.POINTER(AdapterDesc), _PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+        c.dgsct_saved_region.argtypes = [C.POINTER(AdapterDesc), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64)]
+        c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        if c.dgsct_version() != 100:
+            raise RuntimeError("dg-sct_amd: libdgsct version mismatch")
+
+    # ------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.c.dgsct_last_error().decode()}")
+
+    def query(self, desc: AdapterDesc) -> Sizes:
+        s = Sizes()
+        self._check(self.c.dgsct_query(C.byref(desc), C.byref(s)), "dgsct_query")
+        return s
+
+    @staticmethod
+    def ptr_table(ptrs: Sequence[Optional[int]]):
+        arr = (C.c_void_p * P_COUNT)()
+        for i, p in enumerate(ptrs):
+            arr[i] = p if p else None
+        return arr
+
+    def prepare(self, desc, ptrs, prep: int, stream: int):
+        self._check(self.c.dgsct_prepare(C.byref(desc), C.cast(ptrs, _PP), prep, stream), "dgsct_prepare")
+
+    def forward(self, desc, ptrs, prep, X, Y, out, amap, tmap, saved, ws, stream):
+        self._check(self.c.dgsct_adapter_forward(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, out, amap, tmap, saved, ws,
+                                                 stream), "dgsct_adapter_forward")
+
+    def backward(self, desc, ptrs, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream):
+        self._check(self.c.dgsct_adapter_backward(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, saved, dOut, dMap, dTmap,
+                                                  dX, dY, grads, ws, stream), "dgsct_adapter_backward")
+
+    def saved_regions(self, desc):
+        out = {}
+        i = 0
+        name = C.create_string_buffer(64)
+        off, nb = C.c_int64(), C.c_int64()
+        while self.c.dgsct_saved_region(C.byref(desc), i, name, 64, C.byref(off), C.byref(nb)) == 0:
+            out[name.value.decode()] = (off.value, nb.value)
+            i += 1
+        return out
+
+    def test_gemm(self, args: GemmArgs, stream: int):
+        self._check(self.c.dgsct_test_gemm(C.byref(args), stream), "dgsct_test_gemm")
+
+
+_DEFAULT: Optional[Lib] = None
+
+
+def default_lib() -> Lib:
+    """The product library (hand-written gfx950 kernels).  Raises if it has not been built."""
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = Lib(LIB_PATH)
+    return _DEFAULT

@@ -1,0 +1,181 @@
+"""Drop-in ``VisualAdapter(nn.Module)`` -- the reference's plugin interface for the hot path.
+
+Mirrors reference ``DG-SCT/AVE/nets/net_trans.py:433-674`` (ctor :437, forward :552, returns :674):
+same constructor arguments, same parameter/buffer names and shapes (so ``best_82.18.pt`` and any
+reference ``state_dict`` load by name, ``main_trans.py:306``; freeze-by-name ``'adapter_blocks' in
+name`` keeps working, ``main_trans.py:242``), same init distributions, same call convention
+(``x``/``vis_token`` are the ``[BT,C,N,1]`` permuted views of token-major maps, ``:891-892``) and the
+same error behaviour (``NotImplementedError`` for unknown ``adapter_kind``, ``:549-550``).
+
+The other five copies of the class are flavours (``flavour=``): AVVP ``mgn.py:162-414``, AVS-S4/MS3
+``PVT_AVSModel.py:90-316 / 90-300``, AVQA ``net_avst.py:27-218``, pretrain/few/zero-shot
+``pretrain/nets/net_trans.py:343-600``.
+
+The arithmetic runs in libdgsct.so (hand-written gfx950 kernels); there is no PyTorch or CPU
+fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import PARAM_NAMES
+
+FLAVOUR_DEFAULTS = {
+    #            remap      alpha beta  gamma temporal ln_before_ok gate_first T   tokens_init has(num_tk arg)
+    "ave":      dict(remap="conv", alpha=0.3, beta=0.05, gamma=0.0, temporal=False, ln_before_ok=True, gate_first=False, T=10, tokens="rand"),
+    "avvp":     dict(remap="conv", alpha=0.3, beta=0.05, gamma=0.0, temporal=False, ln_before_ok=True, gate_first=False, T=10, tokens="rand"),
+    "avs_s4":   dict(remap="bicubic", alpha=0.3, beta=0.05, gamma=0.0, temporal=False, ln_before_ok=False, gate_first=True, T=5, tokens="zeros"),
+    "avs_ms3":  dict(remap="conv", alpha=0.2, beta=0.1, gamma=0.0, temporal=False, ln_before_ok=False, gate_first=True, T=5, tokens="zeros"),
+    "avqa":     dict(remap="conv", alpha=0.3, beta=0.05, gamma=0.0, temporal=False, ln_before_ok=True, gate_first=False, T=10, tokens="zeros"),
+    "pretrain": dict(remap="conv", alpha=0.3, beta=0.01, gamma=0.05, temporal=True, ln_before_ok=True, gate_first=False, T=10, tokens="rand"),
+}
+
+
+def bicubic_matrix(No: int, N: int) -> torch.Tensor:
+    """Dense [N, No] operator of F.interpolate(mode='bicubic') between square token grids
+    (AVS-S4 remap, PVT_AVSModel.py:190-197): the resize is linear in the tokens, so it takes the
+    place of conv_adapter.weight in the same MFMA GEMM."""
+    hi, ho = int(math.isqrt(No)), int(math.isqrt(N))
+    if hi * hi != No or ho * ho != N:
+        raise ValueError("bicubic remap needs square token grids")
+    eye = torch.eye(No, dtype=torch.float64).view(No, 1, hi, hi)
+    out = F.interpolate(eye, size=[ho, ho], mode="bicubic")
+    return out.view(No, N).t().contiguous().float()
+
+
+class VisualAdapter(nn.Module):
+    """Conventional bottleneck adapter with DG-SCT cross-modal gating (see module docstring)."""
+
+    def __init__(self, input_dim, output_dim, adapter_kind, dim_list=None, layer_idx=0, reduction_factor=16, opt=None,
+                 use_bn=True, use_gate=True, num_tk=None, conv_dim_in=0, conv_dim_out=0, linear_in=0, linear_out=0,
+                 flavour: str = "ave", compute_dtype: Optional[torch.dtype] = None, lib: Optional[_lib.Lib] = None):
+        super().__init__()
+        if flavour not in FLAVOUR_DEFAULTS:
+            raise ValueError(f"unknown flavour {flavour!r}")
+        fl = FLAVOUR_DEFAULTS[flavour]
+        self.adapter_kind = adapter_kind
+        self.use_bn = bool(use_bn)
+        self.is_multimodal = bool(opt.is_multimodal)
+        self.opt = opt
+        self.flavour = flavour
+        self.compute_dtype = compute_dtype
+        self._lib = lib
+        # AVS/AVQA copies have no num_tk argument and read opt.num_tokens (PVT_AVSModel.py:130, net_avst.py:60)
+        self.num_tk = int(num_tk if num_tk is not None else opt.num_tokens)
+        if not (adapter_kind == "bottleneck" and self.is_multimodal):
+            # "bottleneck" without is_multimodal and "basic" are never built by any reference launcher
+            # (SURVEY 8a-1); anything else raises exactly like the reference (:549-550).
+            raise NotImplementedError(f"adapter_kind={adapter_kind!r} with is_multimodal={self.is_multimodal} is not on the "
+                                      f"DG-SCT hot path")
+        if input_dim != output_dim or linear_out != input_dim:
+            raise ValueError("DG-SCT adapters have input_dim == output_dim == linear_out")
+        C, d_model = linear_out, linear_out // 2
+        # --- parameter holders: stock modules give the reference names, shapes and init distributions
+        self.conv_adapter = nn.Conv2d(conv_dim_in, conv_dim_out, kernel_size=1)
+        self.fc = nn.Linear(linear_in, linear_out)
+        self.conv_dim_out = conv_dim_out
+        if flavour in ("avvp", "pretrain"):
+            self.fc_caption = nn.Linear(512, 192)          # present in checkpoints, never on the used path
+        self.fc_affine_audio_1 = nn.Linear(C, C)
+        self.fc_affine_video_1 = nn.Linear(C, C)
+        self.fc_affine_bottleneck = nn.Linear(C, d_model)
+        self.fc_affine_video_2 = nn.Linear(C, d_model)
+        self.fc_affine_audio_2 = nn.Linear(C, d_model)
+        self.fc_affine_v_s_att = nn.Linear(d_model, 1)
+        self.fc_affine_v_c_att = nn.Linear(d_model, C)
+        if flavour in ("avvp", "avs_s4", "avs_ms3", "pretrain"):
+            self.temporal_gated = nn.Sequential(nn.Linear(C, 1), nn.Sigmoid())
+        self.gate = nn.Parameter(torch.zeros(1)) if use_gate else None
+        self.down_sample_size = input_dim // reduction_factor
+        if fl["tokens"] == "rand":
+            self.my_tokens = nn.Parameter(torch.rand((self.num_tk, input_dim)))
+        else:
+            self.my_tokens = nn.Parameter(torch.zeros((self.num_tk, input_dim)))
+        if flavour in ("ave", "avvp", "pretrain"):
+            self.gate_tk = nn.Parameter(torch.ones(1))      # unused by the reference forward too (never gets a grad)
+        self.gate_av = nn.Parameter(torch.zeros(1))
+        g = int(opt.num_conv_group)
+        self.down_sampler = nn.Conv2d(input_dim, self.down_sample_size, 1, groups=g, bias=False)
+        self.up_sampler = nn.Conv2d(self.down_sample_size, output_dim, 1, groups=g, bias=False)
+        if use_bn:
+            self.bn1 = nn.BatchNorm2d(self.down_sample_size)
+            self.bn2 = nn.BatchNorm2d(output_dim)
+        if opt.is_before_layernorm:
+            self.ln_before = nn.LayerNorm(output_dim)
+        if opt.is_post_layernorm:
+            self.ln_post = nn.LayerNorm(output_dim)
+
+        alpha = float(getattr(opt, "alpha", fl["alpha"])) if flavour == "pretrain" else fl["alpha"]
+        beta = float(getattr(opt, "beta", fl["beta"])) if flavour == "pretrain" else fl["beta"]
+        gamma = float(getattr(opt, "gamma", fl["gamma"])) if flavour == "pretrain" else fl["gamma"]
+        self.spec = ops.AdapterSpec(
+            N=int(conv_dim_out), C=int(C), No=int(conv_dim_in), Co=int(linear_in), tk=self.num_tk, r=int(reduction_factor), g=g,
+            use_bn=bool(use_bn), use_gate=bool(use_gate), ln_before=bool(opt.is_before_layernorm) and fl["ln_before_ok"],
+            ln_post=bool(opt.is_post_layernorm), gate_before_ln_post=fl["gate_first"], remap=fl["remap"],
+            alpha=alpha, beta=beta, gamma=gamma, temporal=fl["temporal"], T=fl["T"])
+        if fl["remap"] == "bicubic":
+            self.register_buffer("_remap_op", bicubic_matrix(int(conv_dim_in), int(conv_dim_out)), persistent=False)
+        self._prep_cache = None
+
+    # ------------------------------------------------------------------
+    def _param_list(self) -> List[Optional[torch.Tensor]]:
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        out: List[Optional[torch.Tensor]] = []
+        for name in PARAM_NAMES:
+            t = sd.get(name)
+            if name == "conv_adapter.weight":
+                t = self._remap_op if self.spec.remap == "bicubic" else t.view(self.spec.N, self.spec.No)
+            elif name == "conv_adapter.bias" and self.spec.remap == "bicubic":
+                t = None
+            elif name in ("down_sampler.weight", "up_sampler.weight"):
+                t = t.view(t.shape[0], t.shape[1])
+            elif name.startswith("temporal_gated") and not self.spec.temporal:
+                t = None
+            elif name.startswith("ln_before") and not self.spec.ln_before:
+                t = None
+            out.append(t)
+        return out
+
+    def _prepared(self, lib, params, dtype, device):
+        key = (dtype, device, tuple((p.data_ptr(), p._version) for p in params if p is not None))
+        if self._prep_cache is None or self._prep_cache[0] != key:
+            self._prep_cache = (key, ops.prepare(lib, self.spec, params, dtype, device))
+        return self._prep_cache[1]
+
+    def forward(self, x, vis_token=None, caption=None, is_temporal=False):
+        """x [BT,C,N,1], vis_token [BT,Co,No,1] (views of token-major maps) ->
+        (output [BT,C,N,1], spatial_att_maps [BT,1,N][, temporal_att_maps [BT/T,T,1,1]])."""
+        if caption is not None:
+            raise NotImplementedError("caption prompts (AVVP mgn.py:306-308) are never passed by any reference launcher")
+        if not x.is_cuda:
+            raise RuntimeError("dg-sct_amd.VisualAdapter runs on MI355X through libdgsct.so; there is no CPU path "
+                               "(move the module and its inputs to a ROCm device)")
+        lib = self._lib or _lib.default_lib()
+        X = x.squeeze(-1).permute(0, 2, 1)           # [BT,N,C]: contiguous when x is the reference's permuted view
+        Y = vis_token.squeeze(-1).permute(0, 2, 1)
+        in_dtype = x.dtype
+        cd = self.compute_dtype or (torch.bfloat16 if in_dtype == torch.bfloat16 else torch.float32)
+        X = X.to(cd).contiguous()
+        Y = Y.to(cd).contiguous()
+        params = [ops.check_param(n, p, X.device) for n, p in zip(PARAM_NAMES, self._param_list())]
+        prep = self._prepared(lib, params, cd, X.device)
+        training = self.training
+        out, amap, tmap = ops.adapter_apply(lib, self.spec, training, prep, X, Y, params)
+        if training and self.use_bn:
+            self.bn1.num_batches_tracked += 1
+            self.bn2.num_batches_tracked += 1
+        if out.dtype != in_dtype:
+            out = out.to(in_dtype)
+        output = out.permute(0, 2, 1).unsqueeze(-1)
+        spatial = amap.unsqueeze(1)
+        if self.flavour == "pretrain":
+            T = self.spec.T
+            return output, spatial, tmap.view(-1, T, 1, 1)
+        return output, spatial

@@ -1,0 +1,98 @@
+// extern "C" surface of libdgsct.so (include/dgsct.h).  No exceptions, no torch types, no device
+// allocations: descriptors in, raw device pointers in, status code out.
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/dgsct.h"
+#include "err.h"
+#include "plan.h"
+#include "prims.h"
+
+using namespace dgsct;
+
+extern "C" {
+
+int dgsct_version(void) { return DGSCT_VERSION; }
+const char* dgsct_arch(void) { return "gfx950"; }
+const char* dgsct_last_error(void) { return last_error(); }
+
+int dgsct_query(const dgsct_adapter_desc* desc, dgsct_sizes* out) {
+  clear_error();
+  if (!desc || !out) { set_error("dgsct_query: NULL argument"); return 2; }
+  Plan p(*desc);
+  if (!p.ok) return 2;
+  out->prep_bytes = p.prep_bytes;
+  out->saved_bytes = p.saved_bytes;
+  out->ws_fwd_bytes = p.ws_fwd_bytes;
+  out->ws_bwd_bytes = p.ws_bwd_bytes;
+  out->grad_floats = p.grad_floats;
+  for (int i = 0; i < DGSCT_P_COUNT; ++i) { out->grad_offset[i] = p.grad_off[i]; out->grad_numel[i] = p.grad_numel[i]; }
+  return 0;
+}
+
+int dgsct_prepare(const dgsct_adapter_desc* desc, float* const* params, void* prep, void* stream) {
+  clear_error();
+  if (!desc || !params || !prep) { set_error("dgsct_prepare: NULL argument"); return 2; }
+  Plan p(*desc);
+  if (!p.ok) return 2;
+  return p.prepare(params, prep, stream);
+}
+
+int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
+                          const void* Y, void* out, float* map, float* tmap, void* saved, void* ws, void* stream) {
+  clear_error();
+  if (!desc || !params || !prep || !X || !Y || !out || !map || !saved || !ws) {
+    set_error("dgsct_adapter_forward: NULL argument");
+    return 2;
+  }
+  Plan p(*desc);
+  if (!p.ok) return 2;
+  return p.forward(params, prep, X, Y, out, map, tmap, saved, ws, stream);
+}
+
+int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
+                           const void* Y, const void* saved, const void* dOut, const float* dMap, const float* dTmap,
+                           void* dX, void* dY, float* grads, void* ws, void* stream) {
+  clear_error();
+  if (!desc || !params || !prep || !X || !Y || !saved || !dOut || !dX || !dY || !grads || !ws) {
+    set_error("dgsct_adapter_backward: NULL argument");
+    return 2;
+  }
+  Plan p(*desc);
+  if (!p.ok) return 2;
+  return p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream);
+}
+
+int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes) {
+  clear_error();
+  if (!desc) return 2;
+  Plan p(*desc);
+  if (!p.ok) return 2;
+  if (i < 0 || i >= (int)p.saved_regions.size()) return 1;
+  const Region& r = p.saved_regions[i];
+  if (name && name_cap > 0) { std::strncpy(name, r.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (offset) *offset = r.offset;
+  if (bytes) *bytes = r.bytes;
+  return 0;
+}
+
+int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
+  clear_error();
+  if (!a) return 2;
+  Ctx ctx{stream, a->mode};
+  Gemm g;
+  g.M = a->M; g.N = a->N; g.K = a->K; g.KB = a->KB; g.batch = a->batch; g.splitk = a->splitk; g.atomic = a->atomic;
+  g.A.p = a->A; g.A.ld = a->lda; g.A.kmajor = a->a_kmajor; g.A.bs = a->a_bs; g.A.kbs = a->a_kbs;
+  g.B.p = a->B; g.B.ld = a->ldb; g.B.kmajor = a->b_kmajor; g.B.bs = a->b_bs; g.B.kbs = a->b_kbs;
+  g.D = a->D; g.ddt = a->ddt; g.ldd = a->ldd; g.dbs = a->dbs;
+  g.alpha = a->alpha; g.alpha_ptr = a->alpha_ptr;
+  g.bias_m = a->bias_m; g.bias_n = a->bias_n; g.bias_n_bs = a->bias_n_bs; g.m_mod = a->m_mod;
+  g.r1_m = a->r1_m; g.r1_n = a->r1_n; g.act = a->act;
+  g.R = a->R; g.rdt = a->rdt; g.ldr = a->ldr; g.rbs = a->rbs; g.beta = a->beta;
+  g.mask = a->mask; g.ldmask = a->ldmask; g.maskbs = a->maskbs;
+  gemm(ctx, g);
+  return has_error() ? 1 : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// Device-side helpers shared by the gfx950 kernels: bf16 <-> fp32, 16-byte vector element access,
+// sub-wavefront (power-of-two lane group) reductions.  Wavefront = 64 lanes on CDNA4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "prims.h"
+
+namespace dgsct {
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// round-to-nearest-even, NaN preserved (same rounding as torch.Tensor.to(torch.bfloat16))
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <int DT> struct El;
+template <> struct El<DT_F32>  { static constexpr int ES = 4; static constexpr int VMAX = 4; };
+template <> struct El<DT_BF16> { static constexpr int ES = 2; static constexpr int VMAX = 8; };
+
+template <int DT>
+__device__ __forceinline__ float lde(const void* p, long i) {
+  if (DT == DT_F32) return reinterpret_cast<const float*>(p)[i];
+  return bf2f(reinterpret_cast<const unsigned short*>(p)[i]);
+}
+template <int DT>
+__device__ __forceinline__ void ste(void* p, long i, float v) {
+  if (DT == DT_F32) reinterpret_cast<float*>(p)[i] = v;
+  else reinterpret_cast<unsigned short*>(p)[i] = f2bf(v);
+}
+__device__ __forceinline__ float lde_rt(const void* p, int dt, long i) {
+  return dt == DT_F32 ? reinterpret_cast<const float*>(p)[i] : bf2f(reinterpret_cast<const unsigned short*>(p)[i]);
+}
+__device__ __forceinline__ void ste_rt(void* p, int dt, long i, float v) {
+  if (dt == DT_F32) reinterpret_cast<float*>(p)[i] = v;
+  else reinterpret_cast<unsigned short*>(p)[i] = f2bf(v);
+}
+
+// VE consecutive elements starting at element index i (i*ES must be VE*ES-aligned for VE > 1).
+template <int DT, int VE>
+__device__ __forceinline__ void ldv(const void* p, long i, float (&v)[VE]) {
+  if (DT == DT_F32) {
+    const float* q = reinterpret_cast<const float*>(p) + i;
+    if (VE == 4) { float4 t = *reinterpret_cast<const float4*>(q); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = q[e];
+    }
+  } else {
+    const unsigned short* q = reinterpret_cast<const unsigned short*>(p) + i;
+    if (VE == 8) {
+      uint4 t = *reinterpret_cast<const uint4*>(q);
+      unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    } else if (VE == 4) {
+      uint2 t = *reinterpret_cast<const uint2*>(q);
+      unsigned w[2] = {t.x, t.y};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = bf2f(q[e]);
+    }
+  }
+}
+template <int DT, int VE>
+__device__ __forceinline__ void stv(void* p, long i, const float (&v)[VE]) {
+  if (DT == DT_F32) {
+    float* q = reinterpret_cast<float*>(p) + i;
+    if (VE == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) q[e] = v[e];
+    }
+  } else {
+    unsigned short* q = reinterpret_cast<unsigned short*>(p) + i;
+    if (VE == 8) {
+      unsigned w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+      *reinterpret_cast<uint4*>(q) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else if (VE == 4) {
+      unsigned w[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) w[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+      *reinterpret_cast<uint2*>(q) = make_uint2(w[0], w[1]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) q[e] = f2bf(v[e]);
+    }
+  }
+}
+// VE consecutive fp32 values
+template <int VE>
+__device__ __forceinline__ void ldf(const float* p, long i, float (&v)[VE]) {
+  const float* q = p + i;
+  if (VE % 4 == 0) {
+#pragma unroll
+    for (int e = 0; e < VE; e += 4) { float4 t = *reinterpret_cast<const float4*>(q + e); v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = q[e];
+  }
+}
+
+// sum over a power-of-two group of GS lanes (GS <= 64) that is aligned inside the wavefront
+__device__ __forceinline__ float group_sum(float x, int gs) {
+  for (int o = gs >> 1; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ float group_max(float x, int gs) {
+  for (int o = gs >> 1; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+  return x;
+}
+// sum over the 256-thread workgroup; result valid in every thread.  red: >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum(float x, float* red) {
+  x = group_sum(x, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float x, float* red) {
+  x = group_max(x, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ int imin_d(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ long lmin_d(long a, long b) { return a < b ? a : b; }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+}  // namespace dgsct

@@ -1,0 +1,380 @@
+// Batched / grouped / split-K MFMA GEMM engine for gfx950 (MI355X, CDNA4), hand-written.
+//
+//   D[b][m][n] = epilogue( sum_k A[b][m][k] * B[b][n][k] )          (see prims.h: struct Gemm)
+//
+// * BF16 mode: v_mfma_f32_32x32x16_bf16, fp32 accumulate.  K-major operands are staged to LDS as
+//   [rows][32+8] (80-byte rows: conflict-free ds_read_b128 fragment reads); MN-major operands
+//   (token-contraction GEMMs: Wn.Y, every weight gradient) are staged as [32 k-rows][rows+pad]
+//   and read with ds_read_b64_tr_b16, the CDNA4 LDS transpose read, so no transposed copy of an
+//   activation is ever written to HBM.  Row pitch = 64 (mod 128) bytes keeps the four k-rows of a
+//   tr-read lane group on disjoint banks.
+// * F32 mode (the parity path): v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain); LDS holds
+//   [16 k-rows][rows+4] so either operand layout is one ds_read_b32 per fragment.
+// * 256 threads = 4 wavefronts (64 lanes) per workgroup, wave grid WGM x WGN, each wave owns
+//   TM x TN 32x32 accumulator tiles.  Global->register prefetch of tile t+1 overlaps the MFMAs of
+//   tile t (register staging: the operand roles here need transposes / zero-fill guards that the
+//   lane-linear LDS-DMA path cannot express).
+// * blockIdx.x is remapped so that the 8 XCDs each walk a contiguous range of tiles (private L2s).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "prims.h"
+#include "device_util.h"
+
+namespace dgsct {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct GemmK {
+  int M, N, K, KB;
+  int tiles_m, tiles_n, kt_per_kb, kt_total, kt_per_split;
+  const char* A; long lda, a_bs, a_kbs; int a_vec;
+  const char* B; long ldb, b_bs, b_kbs; int b_vec;
+  char* D; int ddt; long ldd, dbs;
+  float alpha; const float* alpha_ptr;
+  const float* bias_m; const float* bias_n; long bias_n_bs; int m_mod;
+  const float* r1_m; const float* r1_n;
+  int act;
+  const char* R; int rdt; long ldr, rbs; float beta;
+  const char* mask; long ldmask, maskbs;
+  int atomic;
+};
+
+// pitch (bytes) of one k-row of an MN-major bf16 LDS tile holding `rows` elements: >= rows*2, == 64 (mod 128)
+__host__ __device__ constexpr int mn_pitch_bf16(int rows) {
+  int b = rows * 2;
+  int v = (b / 128) * 128 + 64;
+  return v >= b ? v : v + 128;
+}
+
+template <int MODE, bool KM, int ROWS>
+struct TileGeom {
+  static constexpr int ES = MODE == DT_BF16 ? 2 : 4;
+  static constexpr int BKT = MODE == DT_BF16 ? 32 : 16;
+  static constexpr int VE = 16 / ES;                       // elements per 16-byte chunk
+  static constexpr int NCHUNK = ROWS * BKT / VE;           // chunks per tile
+  static constexpr int NLD = (NCHUNK + 255) / 256;         // chunks per thread
+  // LDS pitch (bytes)
+  static constexpr int PITCH = MODE == DT_BF16 ? (KM ? (BKT + 8) * 2 : mn_pitch_bf16(ROWS)) : (ROWS + 4) * 4;
+  static constexpr int LDS_BYTES = MODE == DT_BF16 ? (KM ? ROWS * PITCH : BKT * PITCH) : BKT * PITCH;
+};
+
+// ---- global -> register staging of one operand tile --------------------------------------------
+template <int MODE, bool KM, int ROWS, int NLD_>
+__device__ __forceinline__ void stage_load(uint4 (&reg)[NLD_], const char* base, long ld,
+                                           int r0, int rows_total, int k0, int K, int vec, int tid) {
+  using G = TileGeom<MODE, KM, ROWS>;
+  constexpr int ES = G::ES, VE = G::VE;
+#pragma unroll
+  for (int i = 0; i < G::NLD; ++i) {
+    int c = tid + i * 256;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c < G::NCHUNK) {
+      int r, k;
+      if (KM) { r = c / (G::BKT / VE); k = (c % (G::BKT / VE)) * VE; }
+      else    { k = c / (ROWS / VE);   r = (c % (ROWS / VE)) * VE; }
+      int rg = r0 + r, kg = k0 + k;
+      if (KM) {
+        if (rg < rows_total && kg < K) {
+          const char* p = base + ((long)rg * ld + kg) * ES;
+          if (vec && kg + VE <= K) v = *reinterpret_cast<const uint4*>(p);
+          else {
+            unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+              if (kg + e < K) {
+                if (ES == 4) w[e] = reinterpret_cast<const unsigned*>(p)[e];
+                else w[e >> 1] |= (unsigned)reinterpret_cast<const unsigned short*>(p)[e] << ((e & 1) * 16);
+              }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
+      } else {
+        if (kg < K && rg < rows_total) {
+          const char* p = base + ((long)kg * ld + rg) * ES;
+          if (vec && rg + VE <= rows_total) v = *reinterpret_cast<const uint4*>(p);
+          else {
+            unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+              if (rg + e < rows_total) {
+                if (ES == 4) w[e] = reinterpret_cast<const unsigned*>(p)[e];
+                else w[e >> 1] |= (unsigned)reinterpret_cast<const unsigned short*>(p)[e] << ((e & 1) * 16);
+              }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
+      }
+    }
+    reg[i] = v;
+  }
+}
+
+// ---- register -> LDS ---------------------------------------------------------------------------
+template <int MODE, bool KM, int ROWS, int NLD_>
+__device__ __forceinline__ void stage_store(const uint4 (&reg)[NLD_], char* lds, int tid) {
+  using G = TileGeom<MODE, KM, ROWS>;
+  constexpr int VE = G::VE;
+#pragma unroll
+  for (int i = 0; i < G::NLD; ++i) {
+    int c = tid + i * 256;
+    if (c < G::NCHUNK) {
+      int r, k;
+      if (KM) { r = c / (G::BKT / VE); k = (c % (G::BKT / VE)) * VE; }
+      else    { k = c / (ROWS / VE);   r = (c % (ROWS / VE)) * VE; }
+      if (MODE == DT_BF16) {
+        if (KM) *reinterpret_cast<uint4*>(lds + r * G::PITCH + k * 2) = reg[i];
+        else    *reinterpret_cast<uint4*>(lds + k * G::PITCH + r * 2) = reg[i];
+      } else {
+        if (KM) {   // transpose on the way in: LDS is [k][row]
+          float* l = reinterpret_cast<float*>(lds);
+          const int pitch = G::PITCH / 4;
+          l[(k + 0) * pitch + r] = __uint_as_float(reg[i].x);
+          l[(k + 1) * pitch + r] = __uint_as_float(reg[i].y);
+          l[(k + 2) * pitch + r] = __uint_as_float(reg[i].z);
+          l[(k + 3) * pitch + r] = __uint_as_float(reg[i].w);
+        } else {
+          *reinterpret_cast<uint4*>(lds + k * G::PITCH + r * 4) = reg[i];
+        }
+      }
+    }
+  }
+}
+
+// ---- LDS -> MFMA fragment (bf16) ---------------------------------------------------------------
+// 32x32x16 operand fragment: lane l holds X[row = l&31][k = 8*(l>>5) .. +7] of the 16-deep k-step kk.
+template <bool KM, int ROWS>
+__device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row0, int kk, int lane) {
+  using G = TileGeom<DT_BF16, KM, ROWS>;
+  if (KM) {
+    const char* p = lds + (row0 + (lane & 31)) * G::PITCH + (kk * 16 + (lane >> 5) * 8) * 2;
+    return *reinterpret_cast<const bf16x8_t*>(p);
+  } else {
+    // two transposed reads of a [4 k][16 rows] block per 16-lane group (ds_read_b64_tr_b16):
+    // the lane supplies the address of 4 consecutive rows of ONE k-row, and receives 4 consecutive
+    // k of ONE row: result[j] = LDS[k = kbase + j][row = rbase + (lane&15)].
+    const int kbase = kk * 16 + (lane >> 5) * 8 + ((lane & 15) >> 2);
+    const int r = row0 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const char* p0 = lds + kbase * G::PITCH + r * 2;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * G::PITCH));
+    s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+template <int MODE, bool AK, bool BK, int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  using GA = TileGeom<MODE, AK, BM>;
+  using GB = TileGeom<MODE, BK, BN>;
+  constexpr int BKT = GA::BKT;
+  constexpr int ES = GA::ES;
+  __shared__ __attribute__((aligned(16))) char smem[GA::LDS_BYTES + GB::LDS_BYTES];
+  char* ldsA = smem;
+  char* ldsB = smem + GA::LDS_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // XCD-aware tile order: hardware round-robins consecutive workgroup ids over the 8 XCDs; give each XCD a
+  // contiguous run of tiles so operand panels shared by neighbouring tiles stay in ONE private L2 (bijective).
+  const int ntile = p.tiles_m * p.tiles_n;
+  int t = blockIdx.x;
+  {
+    const int q = ntile >> 3, r = ntile & 7, x = t & 7, y = t >> 3;
+    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int tm = t % p.tiles_m, tn = t / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int b = blockIdx.y;
+  const int kt_begin = blockIdx.z * p.kt_per_split;
+  int kt_end = kt_begin + p.kt_per_split;
+  if (kt_end > p.kt_total) kt_end = p.kt_total;
+
+  const char* Ab = p.A + (long)b * p.a_bs * ES;
+  const char* Bb = p.B + (long)b * p.b_bs * ES;
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[GA::NLD], rb[GB::NLD];
+  auto prefetch = [&](int kt) {
+    const int kb = kt / p.kt_per_kb;
+    const int k0 = (kt - kb * p.kt_per_kb) * BKT;
+    stage_load<MODE, AK, BM>(ra, Ab + (long)kb * p.a_kbs * ES, p.lda, m0, p.M, k0, p.K, p.a_vec, tid);
+    stage_load<MODE, BK, BN>(rb, Bb + (long)kb * p.b_kbs * ES, p.ldb, n0, p.N, k0, p.K, p.b_vec, tid);
+  };
+
+  if (kt_begin < kt_end) prefetch(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();                       // previous tile's fragment reads are done
+    stage_store<MODE, AK, BM>(ra, ldsA, tid);
+    stage_store<MODE, BK, BN>(rb, ldsB, tid);
+    __syncthreads();
+    if (kt + 1 < kt_end) prefetch(kt + 1);  // global loads fly under the MFMAs below
+    if (MODE == DT_BF16) {
+#pragma unroll
+      for (int kk = 0; kk < BKT / 16; ++kk) {
+        bf16x8_t af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = frag_bf16<AK, BM>(ldsA, (wm * TM + i) * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = frag_bf16<BK, BN>(ldsB, (wn * TN + j) * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const float* la = reinterpret_cast<const float*>(ldsA);
+      const float* lb = reinterpret_cast<const float*>(ldsB);
+      constexpr int PA = GA::PITCH / 4, PB = GB::PITCH / 4;
+#pragma unroll
+      for (int kk = 0; kk < BKT / 2; ++kk) {
+        float af[TM], bf[TN];
+        const int k = kk * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = la[k * PA + (wm * TM + i) * 32 + (lane & 31)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = lb[k * PB + (wn * TN + j) * 32 + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: accumulator element r of tile (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+  const float alpha = p.alpha * (p.alpha_ptr ? *p.alpha_ptr : 1.f);
+  char* Db = p.D + (long)b * p.dbs * (p.ddt == DT_F32 ? 4 : 2);
+  const char* Rb = p.R ? p.R + (long)b * p.rbs * (p.rdt == DT_F32 ? 4 : 2) : nullptr;
+  const char* Mb = p.mask ? p.mask + (long)b * p.maskbs * ES : nullptr;
+  const float* bias_n = p.bias_n ? p.bias_n + (long)b * p.bias_n_bs : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    if (n >= p.N) continue;
+    const float bn = bias_n ? bias_n[n] : 0.f;
+    const float r1n = p.r1_n ? p.r1_n[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = alpha * acc[i][j][r] + bn;
+        if (p.bias_m || p.r1_m) {
+          const int mm = p.m_mod > 0 ? m % p.m_mod : m;
+          if (p.bias_m) v += p.bias_m[mm];
+          if (p.r1_m) v += p.r1_m[mm] * r1n;
+        }
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+        if (Mb) {
+          const long o = (long)m * p.ldmask + n;
+          const float mv = MODE == DT_BF16 ? bf2f(reinterpret_cast<const unsigned short*>(Mb)[o])
+                                           : reinterpret_cast<const float*>(Mb)[o];
+          if (!(mv > 0.f)) v = 0.f;
+        }
+        if (Rb) {
+          const long o = (long)m * p.ldr + n;
+          v += p.beta * (p.rdt == DT_F32 ? reinterpret_cast<const float*>(Rb)[o]
+                                         : bf2f(reinterpret_cast<const unsigned short*>(Rb)[o]));
+        }
+        const long o = (long)m * p.ldd + n;
+        if (p.atomic) unsafeAtomicAdd(reinterpret_cast<float*>(Db) + o, v);
+        else if (p.ddt == DT_F32) reinterpret_cast<float*>(Db)[o] = v;
+        else reinterpret_cast<unsigned short*>(Db)[o] = f2bf(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int WGM, int WGN, int TM, int TN>
+static void launch_cfg(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s) {
+  if (ak && bk)       hipLaunchKernelGGL((gemm_kernel<MODE, true, true, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<MODE, true, false, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<MODE, false, true, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
+  else                hipLaunchKernelGGL((gemm_kernel<MODE, false, false, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int MODE>
+static void gemm_mode(const Ctx& ctx, const Gemm& g) {
+  constexpr int ES = MODE == DT_BF16 ? 2 : 4;
+  constexpr int VE = 16 / ES;
+  constexpr int BKT = MODE == DT_BF16 ? 32 : 16;
+  if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
+  GemmK k;
+  k.M = g.M; k.N = g.N; k.K = g.K; k.KB = g.KB;
+  k.A = (const char*)g.A.p; k.lda = g.A.ld; k.a_bs = g.A.bs; k.a_kbs = g.A.kbs;
+  k.B = (const char*)g.B.p; k.ldb = g.B.ld; k.b_bs = g.B.bs; k.b_kbs = g.B.kbs;
+  k.a_vec = aligned16(g.A.p) && g.A.ld % VE == 0 && g.A.bs % VE == 0 && g.A.kbs % VE == 0;
+  k.b_vec = aligned16(g.B.p) && g.B.ld % VE == 0 && g.B.bs % VE == 0 && g.B.kbs % VE == 0;
+  k.D = (char*)g.D; k.ddt = g.ddt; k.ldd = g.ldd; k.dbs = g.dbs;
+  k.alpha = g.alpha; k.alpha_ptr = g.alpha_ptr;
+  k.bias_m = g.bias_m; k.bias_n = g.bias_n; k.bias_n_bs = g.bias_n_bs; k.m_mod = g.m_mod;
+  k.r1_m = g.r1_m; k.r1_n = g.r1_n; k.act = g.act;
+  k.R = (const char*)g.R; k.rdt = g.rdt; k.ldr = g.ldr; k.rbs = g.rbs; k.beta = g.beta;
+  k.mask = (const char*)g.mask; k.ldmask = g.ldmask; k.maskbs = g.maskbs;
+  k.atomic = g.atomic;
+  k.kt_per_kb = (g.K + BKT - 1) / BKT;
+  k.kt_total = k.kt_per_kb * g.KB;
+
+  // tile configuration
+  int cfg;
+  auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.batch; };
+  if (g.N <= 32) cfg = 2;                                       // 128 x 32
+  else if (g.M <= 32) cfg = 3;                                  // 32 x 128
+  else if (g.N % 128 != 0 && g.N % 96 == 0 && g.M >= 96) cfg = 1;   // 128 x 96 (remap widths are multiples of 96)
+  else if (g.M >= 128 && g.N >= 128 && tiles(128, 128) >= 192) cfg = 0;   // 128 x 128
+  else cfg = 4;                                                 // 64 x 64
+  static const int BMs[5] = {128, 128, 128, 32, 64}, BNs[5] = {128, 96, 32, 128, 64};
+  k.tiles_m = (g.M + BMs[cfg] - 1) / BMs[cfg];
+  k.tiles_n = (g.N + BNs[cfg] - 1) / BNs[cfg];
+  int splitk = g.splitk;
+  if (!g.atomic) splitk = 1;
+  else if (splitk <= 0) {                                       // auto: aim for >= 1024 workgroups, >= 4 k-tiles each
+    long wg = (long)k.tiles_m * k.tiles_n * g.batch;
+    splitk = (int)((1024 + wg - 1) / wg);
+    int maxs = k.kt_total / 4; if (maxs < 1) maxs = 1;
+    if (splitk > maxs) splitk = maxs;
+    if (splitk < 1) splitk = 1;
+  }
+  k.kt_per_split = (k.kt_total + splitk - 1) / splitk;
+  splitk = (k.kt_total + k.kt_per_split - 1) / k.kt_per_split;
+  dim3 grid(k.tiles_m * k.tiles_n, g.batch, splitk);
+  hipStream_t s = (hipStream_t)ctx.stream;
+  const int ak = g.A.kmajor, bk = g.B.kmajor;
+  switch (cfg) {
+    case 0: launch_cfg<MODE, 2, 2, 2, 2>(k, ak, bk, grid, s); break;
+    case 1: launch_cfg<MODE, 4, 1, 1, 3>(k, ak, bk, grid, s); break;
+    case 2: launch_cfg<MODE, 4, 1, 1, 1>(k, ak, bk, grid, s); break;
+    case 3: launch_cfg<MODE, 1, 4, 1, 1>(k, ak, bk, grid, s); break;
+    default: launch_cfg<MODE, 2, 2, 1, 1>(k, ak, bk, grid, s); break;
+  }
+}
+
+void gemm(const Ctx& ctx, const Gemm& g) {
+  if (ctx.mode == DT_BF16) gemm_mode<DT_BF16>(ctx, g);
+  else gemm_mode<DT_F32>(ctx, g);
+}
+
+}  // namespace dgsct

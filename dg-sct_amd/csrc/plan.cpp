@@ -1,0 +1,706 @@
+// Kernel schedule of one DG-SCT adapter forward / backward, written against prims.h only (plain C++,
+// no HIP syntax).  It follows oracle/dgsct_oracle.py step by step (F1..F11 / B11..B1), which in turn
+// restates reference DG-SCT/AVE/nets/net_trans.py:552-674 and its autograd.
+//
+// Data layout in HBM (all token-major, row = one token, channels contiguous):
+//   activations  E = desc.dtype (bf16 or fp32); per-frame gate vectors, statistics, logits: fp32.
+//   `saved`  : what backward needs from forward (Yp, remap intermediate, P1, tok, P2, X1, vq1, Xc,
+//              vq2, X3, Zp, Z, Op + small fp32 vectors) -- one region per adapter call.
+//   `ws`     : scratch that dies with the call (logits, cotangents), shared by all adapters of a stream.
+//   `prep`   : MFMA-operand (E) copies of the weights + three derived bias vectors.
+#include "plan.h"
+
+#include <cstdio>
+#include <cstring>
+
+#include "err.h"
+#include "prims.h"
+
+namespace dgsct {
+
+static inline int64_t rup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct Arena {
+  int64_t off = 0;
+  std::vector<Region>* regs = nullptr;
+  int64_t take(const char* name, int64_t bytes) {
+    int64_t o = off;
+    off += rup(bytes, 256);
+    if (regs) regs->push_back(Region{name, o, bytes});
+    return o;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+Plan::Plan(const dgsct_adapter_desc& d_) : d(d_) {
+  B = d.BT; N = d.N; C = d.C; No = d.No; Co = d.Co; tk = d.tk; g = d.g;
+  dd = C / 2; ds = d.r > 0 ? C / d.r : 0;
+  E = d.dtype; es = (int64_t)dt_size(E);
+  Np = (int)rup(N, 8); Nop = (int)rup(No, 8); tkp = (int)rup(tk, 8);
+  R = (int64_t)B * N;
+  {
+    const int64_t a = (int64_t)N * No * Co + (int64_t)N * Co * C;
+    const int64_t b = (int64_t)No * Co * C + (int64_t)N * No * C;
+    orderA = a <= b;
+  }
+  ok = validate();
+  if (ok) layout();
+}
+
+bool Plan::validate() {
+  auto bad = [&](const char* m) { set_error("dgsct: bad descriptor: %s", m); return false; };
+  if (B <= 0 || N <= 0 || C <= 0 || No <= 0 || Co <= 0 || tk <= 0) return bad("non-positive dimension");
+  if (d.r <= 0 || g <= 0 || C % d.r || ds % g || C % g) return bad("C must be divisible by r and g, C/r by g");
+  if (C % 4 || C > 1536) return bad("C must be a multiple of 4 and <= 1536");
+  if (dd % 4) return bad("C/2 must be a multiple of 4");
+  if (tk > 64) return bad("tk must be <= 64");
+  if (d.T > 0 && B % d.T) return bad("BT must be a multiple of T");
+  if (E != DT_F32 && E != DT_BF16) return bad("dtype");
+  if (d.remap != DGSCT_REMAP_CONV && d.remap != DGSCT_REMAP_FIXED) return bad("remap");
+  return true;
+}
+
+void Plan::layout() {
+  // ---- prep: E copies of the GEMM weights (bf16 mode only) + derived fp32 vectors
+  {
+    Arena a;
+    auto wcopy = [&](int id, int64_t numel) {
+      wnumel[id] = numel;
+      prep_w[id] = (E == DT_BF16) ? a.take("w", numel * es) : -1;
+    };
+    for (int i = 0; i < DGSCT_P_COUNT; ++i) { prep_w[i] = -1; wnumel[i] = 0; }
+    wcopy(DGSCT_P_TOKENS, (int64_t)tk * C);
+    wcopy(DGSCT_P_WN, (int64_t)N * No);
+    wcopy(DGSCT_P_WC, (int64_t)C * Co);
+    wcopy(DGSCT_P_WA1, (int64_t)C * C);
+    wcopy(DGSCT_P_WV1, (int64_t)C * C);
+    wcopy(DGSCT_P_WB, (int64_t)dd * C);
+    wcopy(DGSCT_P_WV2, (int64_t)dd * C);
+    wcopy(DGSCT_P_WA2, (int64_t)dd * C);
+    wcopy(DGSCT_P_WCATT, (int64_t)C * dd);
+    wcopy(DGSCT_P_WD, (int64_t)ds * (C / g));
+    wcopy(DGSCT_P_WU, (int64_t)C * (ds / g));
+    prep_rowb = a.take("rowb", (int64_t)N * 4);
+    prep_colb = a.take("colb", (int64_t)C * 4);
+    prep_colb2 = a.take("colb2", (int64_t)C * 4);
+    prep_bytes = a.off;
+  }
+  // ---- saved
+  {
+    Arena a; a.regs = &saved_regions;
+    // zero block first (atomically accumulated in forward)
+    s.a = a.take("a", (int64_t)B * C * 4);
+    s.mvq1 = a.take("mvq1", (int64_t)B * C * 4);
+    s.bnacc1 = a.take("bnacc1", (int64_t)3 * ds * 4);
+    s.bnacc2 = a.take("bnacc2", (int64_t)3 * C * 4);
+    s.zero_end = a.off;
+    s.Yp = a.take("Yp", R * C * es);
+    s.T = a.take("T", orderA ? R * Co * es : (int64_t)B * C * Nop * es);
+    s.P1 = a.take("P1", (int64_t)B * tk * Np * es);
+    s.tok = a.take("tok", (int64_t)B * tk * C * es);
+    s.aE = a.take("aE", (int64_t)B * C * es);
+    s.P2 = a.take("P2", R * tkp * es);
+    s.X1 = a.take("X1", R * C * es);
+    s.aq1 = a.take("aq1", (int64_t)B * C * es);
+    s.aq2 = a.take("aq2", (int64_t)B * dd * es);
+    s.vq1 = a.take("vq1", R * C * es);
+    s.m1 = a.take("m1", (int64_t)B * C * es);
+    s.q = a.take("q", (int64_t)B * dd * es);
+    s.ch = a.take("ch", (int64_t)B * C * 4);
+    s.Xc = a.take("Xc", R * C * es);
+    s.vq2 = a.take("vq2", R * dd * es);
+    s.sl = a.take("sl", R * 4);
+    s.sg = a.take("sg", R * 4);
+    s.map = a.take("map", R * 4);
+    s.tg = a.take("tg", (int64_t)B * 4);
+    s.X3 = a.take("X3", R * C * es);
+    s.mu_b = a.take("mu_b", R * 4);
+    s.rstd_b = a.take("rstd_b", R * 4);
+    s.Zp = a.take("Zp", R * ds * es);
+    s.Z = a.take("Z", R * ds * es);
+    s.Op = a.take("Op", R * C * es);
+    s.bn1 = a.take("bn1", (int64_t)4 * ds * 4);   // mean | rstd | sc | sh
+    s.bn2 = a.take("bn2", (int64_t)4 * C * 4);
+    s.mu_p = a.take("mu_p", R * 4);
+    s.rstd_p = a.take("rstd_p", R * 4);
+    saved_bytes = a.off;
+  }
+  // ---- forward scratch
+  {
+    Arena a;
+    wf.S1 = a.take("S1", (int64_t)B * tk * Np * 4);
+    wf.S2 = a.take("S2", R * tkp * 4);
+    ws_fwd_bytes = a.off;
+  }
+  // ---- backward scratch
+  {
+    Arena a;
+    wb.bnsums2 = a.take("bnsums2", (int64_t)2 * C * 4);
+    wb.bnsums1 = a.take("bnsums1", (int64_t)2 * ds * 4);
+    wb.dch = a.take("dch", (int64_t)B * C * 4);
+    wb.dtg = a.take("dtg", (int64_t)B * 4);
+    wb.u = a.take("u", (int64_t)B * dd * 4);
+    wb.dwcsum = a.take("dwcsum", (int64_t)C * 4);
+    wb.zero_end = a.off;
+    wb.dO = a.take("dO", R * C * es);
+    wb.dZ = a.take("dZ", R * ds * es);
+    wb.dX3 = a.take("dX3", R * C * es);
+    wb.dX1 = a.take("dX1", R * C * es);
+    wb.dXc = a.take("dXc", R * C * es);
+    wb.dsg = a.take("dsg", R * 4);
+    wb.dsl = a.take("dsl", R * 4);
+    wb.tmpBd = a.take("tmpBd", (int64_t)B * dd * 4);
+    wb.dpre_c = a.take("dpre_c", (int64_t)B * C * es);
+    wb.dq = a.take("dq", (int64_t)B * dd * es);
+    wb.dm1 = a.take("dm1", (int64_t)B * C * 4);
+    wb.dpa1 = a.take("dpa1", (int64_t)B * C * es);
+    wb.dpa2 = a.take("dpa2", (int64_t)B * dd * es);
+    wb.coef = a.take("coef", (int64_t)B * C * 4);
+    wb.da = a.take("da", (int64_t)B * C * 4);
+    wb.daN = a.take("daN", (int64_t)B * C * 4);
+    wb.dpre_t = a.take("dpre_t", (int64_t)B * 4);
+    wb.U = a.take("U", R * tkp * 4);
+    wb.dS2 = a.take("dS2", R * tkp * es);
+    wb.dtokF = a.take("dtokF", (int64_t)B * tk * C * 4);
+    wb.dtokE = a.take("dtokE", (int64_t)B * tk * C * es);
+    wb.dP1 = a.take("dP1", (int64_t)B * tk * Np * 4);
+    wb.dS1 = a.take("dS1", (int64_t)B * tk * Np * es);
+    wb.dYp = a.take("dYp", R * C * es);
+    wb.dT = a.take("dT", orderA ? R * Co * es : (int64_t)B * C * Nop * es);
+    wb.rowtmp = a.take("rowtmp", R * 4);
+    ws_bwd_bytes = a.off;
+  }
+  // ---- gradients (flat fp32)
+  {
+    int64_t off = 0;
+    for (int i = 0; i < DGSCT_P_COUNT; ++i) { grad_off[i] = -1; grad_numel[i] = 0; }
+    auto gr = [&](int id, int64_t n, bool on = true) {
+      if (!on) return;
+      grad_off[id] = off; grad_numel[id] = n; off += rup(n, 4);
+    };
+    gr(DGSCT_P_GATE, 1, d.use_gate);
+    gr(DGSCT_P_TOKENS, (int64_t)tk * C);
+    gr(DGSCT_P_GATE_AV, 1);
+    gr(DGSCT_P_WN, (int64_t)N * No, d.remap == DGSCT_REMAP_CONV);
+    gr(DGSCT_P_BN, N, d.remap == DGSCT_REMAP_CONV);
+    gr(DGSCT_P_WC, (int64_t)C * Co);
+    gr(DGSCT_P_BC, C);
+    gr(DGSCT_P_WA1, (int64_t)C * C); gr(DGSCT_P_BA1, C);
+    gr(DGSCT_P_WV1, (int64_t)C * C); gr(DGSCT_P_BV1, C);
+    gr(DGSCT_P_WB, (int64_t)dd * C); gr(DGSCT_P_BB, dd);
+    gr(DGSCT_P_WV2, (int64_t)dd * C); gr(DGSCT_P_BV2, dd);
+    gr(DGSCT_P_WA2, (int64_t)dd * C); gr(DGSCT_P_BA2, dd);
+    gr(DGSCT_P_WS, dd); gr(DGSCT_P_BS, 1);
+    gr(DGSCT_P_WCATT, (int64_t)C * dd); gr(DGSCT_P_BCATT, C);
+    gr(DGSCT_P_WD, (int64_t)ds * (C / g));
+    gr(DGSCT_P_WU, (int64_t)C * (ds / g));
+    gr(DGSCT_P_BN1_W, ds, d.use_bn); gr(DGSCT_P_BN1_B, ds, d.use_bn);
+    gr(DGSCT_P_BN2_W, C, d.use_bn); gr(DGSCT_P_BN2_B, C, d.use_bn);
+    gr(DGSCT_P_LNB_W, C, d.ln_before); gr(DGSCT_P_LNB_B, C, d.ln_before);
+    gr(DGSCT_P_LNP_W, C, d.ln_post); gr(DGSCT_P_LNP_B, C, d.ln_post);
+    gr(DGSCT_P_WT, C, d.temporal); gr(DGSCT_P_BT, 1, d.temporal);
+    grad_floats = off;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+inline MatOp km(const void* p, long ld, long bs = 0, long kbs = 0) { MatOp m; m.p = p; m.ld = ld; m.kmajor = 1; m.bs = bs; m.kbs = kbs; return m; }
+inline MatOp mn(const void* p, long ld, long bs = 0, long kbs = 0) { MatOp m; m.p = p; m.ld = ld; m.kmajor = 0; m.bs = bs; m.kbs = kbs; return m; }
+inline Gemm mk(int M, int N, int K, int batch = 1) { Gemm g; g.M = M; g.N = N; g.K = K; g.batch = batch; return g; }
+inline void outE(Gemm& g, void* D, int E, long ld, long dbs = 0) { g.D = D; g.ddt = E; g.ldd = ld; g.dbs = dbs; }
+inline void outF(Gemm& g, float* D, long ld, long dbs = 0) { g.D = D; g.ddt = DT_F32; g.ldd = ld; g.dbs = dbs; }
+inline void resid(Gemm& g, const void* R, int rdt, long ld, long rbs = 0, float beta = 1.f) { g.R = R; g.rdt = rdt; g.ldr = ld; g.rbs = rbs; g.beta = beta; }
+inline void atomic_out(Gemm& g) { g.atomic = 1; g.splitk = 0; }
+inline EwArg F32(const void* p) { EwArg a; a.p = p; a.dt = DT_F32; return a; }
+inline EwArg Earg(const void* p, int E) { EwArg a; a.p = p; a.dt = E; return a; }
+const EwArg NOARG{};
+}  // namespace
+
+struct Bound {
+  // resolved pointers of one call
+  const Plan& P;
+  float* const* params;
+  const char* prep;
+  char* saved;
+  char* ws;
+  Ctx ctx;
+  Bound(const Plan& p, float* const* pr, const void* prep_, void* saved_, void* ws_, void* stream)
+      : P(p), params(pr), prep((const char*)prep_), saved((char*)saved_), ws((char*)ws_), ctx{stream, p.E} {}
+  const float* F(int id) const { return params[id]; }
+  float* Fm(int id) const { return params[id]; }
+  const void* W(int id) const { return P.E == DT_BF16 ? (const void*)(prep + P.prep_w[id]) : (const void*)params[id]; }
+  template <typename T = void> T* S(int64_t off) const { return reinterpret_cast<T*>(saved + off); }
+  template <typename T = void> T* Wk(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
+  const float* rowb() const { return reinterpret_cast<const float*>(prep + P.prep_rowb); }
+  const float* colb() const { return reinterpret_cast<const float*>(prep + P.prep_colb); }
+  const float* colb2() const { return reinterpret_cast<const float*>(prep + P.prep_colb2); }
+};
+
+// ------------------------------------------------------------------------------------------------
+int Plan::prepare(float* const* params, void* prep, void* stream) const {
+  Ctx ctx{stream, E};
+  char* p = (char*)prep;
+  if (E == DT_BF16)
+    for (int i = 0; i < DGSCT_P_COUNT; ++i)
+      if (prep_w[i] >= 0) {
+        if (!params[i]) { set_error("dgsct_prepare: parameter %d is NULL", i); return 2; }
+        cvt(ctx, params[i], p + prep_w[i], E, wnumel[i]);
+      }
+  float* rowb = (float*)(p + prep_rowb);
+  float* colb = (float*)(p + prep_colb);
+  float* colb2 = (float*)(p + prep_colb2);
+  if (d.remap == DGSCT_REMAP_CONV) {
+    // Yp = Wn.Y.Wc^T + bn (x) rowsum(Wc) + 1 (x) bc                       (net_trans.py:553-554)
+    ew(ctx, EW_COPY, rowb, DT_F32, F32(params[DGSCT_P_BN]), NOARG, NOARG, N, 0.f, 1);
+    rowsum_f32(ctx, params[DGSCT_P_WC], C, Co, colb);
+    ew(ctx, EW_COPY, colb2, DT_F32, F32(params[DGSCT_P_BC]), NOARG, NOARG, C, 0.f, 1);
+  } else {
+    // Yp = Wfix.(Y.Wc^T + bc) = Wfix.Y.Wc^T + rowsum(Wfix) (x) bc        (PVT_AVSModel.py:190-197)
+    rowsum_f32(ctx, params[DGSCT_P_WN], N, No, rowb);
+    ew(ctx, EW_COPY, colb, DT_F32, F32(params[DGSCT_P_BC]), NOARG, NOARG, C, 0.f, 1);
+    zero(ctx, colb2, (size_t)C * 4);
+  }
+  return has_error() ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int Plan::forward(float* const* params, const void* prep, const void* X, const void* Y, void* out, float* map,
+                  float* tmap, void* saved, void* ws, void* stream) const {
+  Bound b(*this, params, prep, saved, ws, stream);
+  const Ctx& ctx = b.ctx;
+  const float invN = 1.f / (float)N;
+  zero(ctx, b.S(0), (size_t)s.zero_end);
+
+  // F1 ---- cross-modal remap                                            net_trans.py:553-555
+  void* Yp = b.S(s.Yp);
+  if (orderA) {
+    Gemm g1 = mk(N, Co, No, B);                                  // T1[b] = Wn . Y[b]
+    g1.A = km(b.W(DGSCT_P_WN), No);
+    g1.B = mn(Y, Co, (long)No * Co);
+    outE(g1, b.S(s.T), E, Co, (long)N * Co);
+    gemm(ctx, g1);
+    Gemm g2 = mk((int)R, C, Co);                                 // Yp = T1 . Wc^T + rank-1 bias
+    g2.A = km(b.S(s.T), Co);
+    g2.B = km(b.W(DGSCT_P_WC), Co);
+    g2.r1_m = b.rowb(); g2.r1_n = b.colb(); g2.m_mod = N; g2.bias_n = b.colb2();
+    outE(g2, Yp, E, C);
+    gemm(ctx, g2);
+  } else {
+    Gemm g1 = mk(C, No, Co, B);                                  // T2t[b] = Wc . Y[b]^T   [C][No]
+    g1.A = km(b.W(DGSCT_P_WC), Co);
+    g1.B = km(Y, Co, (long)No * Co);
+    outE(g1, b.S(s.T), E, Nop, (long)C * Nop);
+    gemm(ctx, g1);
+    Gemm g2 = mk(N, C, No, B);                                   // Yp[b] = Wn . T2[b]
+    g2.A = km(b.W(DGSCT_P_WN), No);
+    g2.B = km(b.S(s.T), Nop, (long)C * Nop);
+    g2.r1_m = b.rowb(); g2.r1_n = b.colb(); g2.bias_n = b.colb2();
+    outE(g2, Yp, E, C, (long)N * C);
+    gemm(ctx, g2);
+  }
+  // F2 ---- latent tokens attend to the remapped tokens                  :572-580, :592
+  {
+    Gemm g1 = mk(tk, N, C, B);                                   // S1 = T0 . Yp^T
+    g1.A = km(b.W(DGSCT_P_TOKENS), C);
+    g1.B = km(Yp, C, (long)N * C);
+    outF(g1, b.Wk<float>(wf.S1), Np, (long)tk * Np);
+    gemm(ctx, g1);
+    softmax_rows(ctx, b.Wk<float>(wf.S1), Np, b.S(s.P1), E, Np, (long)B * tk, N, 0);
+    Gemm g2 = mk(tk, C, N, B);                                   // tok = T0 + P1 . Yp
+    g2.A = km(b.S(s.P1), Np, (long)tk * Np);
+    g2.B = mn(Yp, C, (long)N * C);
+    resid(g2, b.W(DGSCT_P_TOKENS), E, C, 0);
+    outE(g2, b.S(s.tok), E, C, (long)tk * C);
+    gemm(ctx, g2);
+    colsum_batched(ctx, Yp, C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.a), C);   // a = mean_N(Yp)
+    cvt(ctx, b.S<float>(s.a), b.S(s.aE), E, (long)B * C);
+  }
+  // F3 ---- X attends to the latent tokens                               :583-589
+  {
+    Gemm g1 = mk(N, tk, C, B);                                   // S2 = X . tok^T
+    g1.A = km(X, C, (long)N * C);
+    g1.B = km(b.S(s.tok), C, (long)tk * C);
+    outF(g1, b.Wk<float>(wf.S2), tkp, (long)N * tkp);
+    gemm(ctx, g1);
+    softmax_rows(ctx, b.Wk<float>(wf.S2), tkp, b.S(s.P2), E, tkp, R, tk, 0);
+    Gemm g2 = mk(N, C, tk, B);                                   // X1 = X + gate_av * P2 . tok
+    g2.A = km(b.S(s.P2), tkp, (long)N * tkp);
+    g2.B = mn(b.S(s.tok), C, (long)tk * C);
+    g2.alpha_ptr = b.F(DGSCT_P_GATE_AV);
+    resid(g2, X, E, C, (long)N * C);
+    outE(g2, b.S(s.X1), E, C, (long)N * C);
+    gemm(ctx, g2);
+  }
+  // F4-F6 ---- channel gate                                              :593-598
+  {
+    Gemm g1 = mk(B, C, C);                                       // aq1 = relu(a Wa1^T + b)
+    g1.A = km(b.S(s.aE), C); g1.B = km(b.W(DGSCT_P_WA1), C); g1.bias_n = b.F(DGSCT_P_BA1); g1.act = ACT_RELU;
+    outE(g1, b.S(s.aq1), E, C);
+    gemm(ctx, g1);
+    Gemm g2 = mk(B, dd, C);                                      // aq2 = relu(a Wa2^T + b)
+    g2.A = km(b.S(s.aE), C); g2.B = km(b.W(DGSCT_P_WA2), C); g2.bias_n = b.F(DGSCT_P_BA2); g2.act = ACT_RELU;
+    outE(g2, b.S(s.aq2), E, dd);
+    gemm(ctx, g2);
+    Gemm g3 = mk((int)R, C, C);                                  // vq1 = relu(X1 Wv1^T + b)
+    g3.A = km(b.S(s.X1), C); g3.B = km(b.W(DGSCT_P_WV1), C); g3.bias_n = b.F(DGSCT_P_BV1); g3.act = ACT_RELU;
+    outE(g3, b.S(s.vq1), E, C);
+    gemm(ctx, g3);
+    colsum_batched(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C);
+    ew(ctx, EW_MUL, b.S(s.m1), E, Earg(b.S(s.aq1), E), F32(b.S(s.mvq1)), NOARG, (long)B * C, 0.f, 1);
+    Gemm g4 = mk(B, dd, C);                                      // q = relu(m1 Wb^T + b)
+    g4.A = km(b.S(s.m1), C); g4.B = km(b.W(DGSCT_P_WB), C); g4.bias_n = b.F(DGSCT_P_BB); g4.act = ACT_RELU;
+    outE(g4, b.S(s.q), E, dd);
+    gemm(ctx, g4);
+    Gemm g5 = mk(B, C, dd);                                      // ch = sigmoid(q Wcatt^T + b)
+    g5.A = km(b.S(s.q), dd); g5.B = km(b.W(DGSCT_P_WCATT), dd); g5.bias_n = b.F(DGSCT_P_BCATT); g5.act = ACT_SIGMOID;
+    outF(g5, b.S<float>(s.ch), C);
+    gemm(ctx, g5);
+  }
+  // F7 ---- spatial gate and the returned map                            :601-608
+  {
+    scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);        // Xc = X1 * (1 + ch)
+    Gemm g1 = mk((int)R, dd, C);                                 // vq2 = relu(Xc Wv2^T + b)
+    g1.A = km(b.S(s.Xc), C); g1.B = km(b.W(DGSCT_P_WV2), C); g1.bias_n = b.F(DGSCT_P_BV2); g1.act = ACT_RELU;
+    outE(g1, b.S(s.vq2), E, dd);
+    gemm(ctx, g1);
+    rowdot_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.S(s.aq2), E, dd, b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
+                   b.S<float>(s.sl));
+    spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map));
+    ew(ctx, EW_COPY, map, DT_F32, F32(b.S(s.map)), NOARG, NOARG, R, 0.f, 1);
+    if (d.temporal) {
+      temporal_fwd(ctx, b.S<float>(s.a), b.F(DGSCT_P_WT), b.F(DGSCT_P_BT), B, C, b.S<float>(s.tg));
+      if (tmap) ew(ctx, EW_COPY, tmap, DT_F32, F32(b.S(s.tg)), NOARG, NOARG, B, 0.f, 1);
+    }
+  }
+  // F8 ---- modulation + ln_before                                       :611-627
+  modln_fwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta,
+            d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C,
+            b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b));
+  // F9-F10 ---- grouped bottleneck + BatchNorm                           :629-643
+  float* bn1 = b.S<float>(s.bn1);
+  float* bn2 = b.S<float>(s.bn2);
+  {
+    Gemm g1 = mk((int)R, ds / g, C / g, g);                      // Zp = X3 (x)_g Wd
+    g1.A = km(b.S(s.X3), C, C / g);
+    g1.B = km(b.W(DGSCT_P_WD), C / g, (long)(ds / g) * (C / g));
+    outE(g1, b.S(s.Zp), E, ds, ds / g);
+    gemm(ctx, g1);
+    if (d.use_bn) {
+      if (d.training) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
+      bn_finalize(ctx, b.S<float>(s.bnacc1), R, ds, b.F(DGSCT_P_BN1_W), b.F(DGSCT_P_BN1_B), b.Fm(DGSCT_P_BN1_RM),
+                  b.Fm(DGSCT_P_BN1_RV), d.bn_momentum, d.eps, d.training, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds);
+    }
+    affine_act(ctx, b.S(s.Zp), b.S(s.Z), R, ds, d.use_bn ? bn1 + 2 * ds : nullptr, d.use_bn ? bn1 + 3 * ds : nullptr, 1);
+    Gemm g2 = mk((int)R, C / g, ds / g, g);                      // Op = Z (x)_g Wu
+    g2.A = km(b.S(s.Z), ds, ds / g);
+    g2.B = km(b.W(DGSCT_P_WU), ds / g, (long)(C / g) * (ds / g));
+    outE(g2, b.S(s.Op), E, C, C / g);
+    gemm(ctx, g2);
+    if (d.use_bn) {
+      if (d.training) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
+      bn_finalize(ctx, b.S<float>(s.bnacc2), R, C, b.F(DGSCT_P_BN2_W), b.F(DGSCT_P_BN2_B), b.Fm(DGSCT_P_BN2_RM),
+                  b.Fm(DGSCT_P_BN2_RV), d.bn_momentum, d.eps, d.training, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C);
+    }
+  }
+  // F11 ---- ln_post / gate                                              :668-671
+  tail_fwd(ctx, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr,
+           d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
+           d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, d.eps, R, C, out, b.S<float>(s.mu_p),
+           b.S<float>(s.rstd_p));
+  return has_error() ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int Plan::backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved_c,
+                   const void* dOut, const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws,
+                   void* stream) const {
+  Bound b(*this, params, prep, const_cast<void*>(saved_c), ws, stream);
+  const Ctx& ctx = b.ctx;
+  auto G = [&](int id) -> float* { return grad_off[id] >= 0 ? grads + grad_off[id] : nullptr; };
+  zero(ctx, b.Wk(0), (size_t)wb.zero_end);
+  zero(ctx, grads, (size_t)grad_floats * 4);
+  const float* bn1 = b.S<float>(s.bn1);
+  const float* bn2 = b.S<float>(s.bn2);
+  const float* tg = d.temporal ? b.S<float>(s.tg) : nullptr;
+  const int cg = C / g, dg = ds / g;
+
+  // B11 ---- ln_post / gate, BN2 sums
+  void* dO = b.Wk(wb.dO);
+  tail_bwd(ctx, dOut, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr, bn2, bn2 + C,
+           d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
+           d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, b.S<float>(s.mu_p), b.S<float>(s.rstd_p), R, C,
+           dO, G(DGSCT_P_LNP_W), G(DGSCT_P_LNP_B), G(DGSCT_P_GATE), d.use_bn ? b.Wk<float>(wb.bnsums2) : nullptr);
+  // B10 ---- BN2 backward, up projection
+  if (d.use_bn) {
+    bn_bwd_apply(ctx, dO, b.S(s.Op), dO, R, C, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C, b.Wk<float>(wb.bnsums2), 0, 1,
+                 d.training);
+    ew(ctx, EW_COPY, G(DGSCT_P_BN2_B), DT_F32, F32(b.Wk<float>(wb.bnsums2)), NOARG, NOARG, C, 0.f, 1);
+    ew(ctx, EW_COPY, G(DGSCT_P_BN2_W), DT_F32, F32(b.Wk<float>(wb.bnsums2) + C), NOARG, NOARG, C, 0.f, 1);
+  }
+  {
+    Gemm g1 = mk(cg, dg, (int)R, g);                             // dWu = dOp^T (x)_g Z
+    g1.A = mn(dO, C, cg);
+    g1.B = mn(b.S(s.Z), ds, dg);
+    outF(g1, G(DGSCT_P_WU), dg, (long)cg * dg);
+    atomic_out(g1);
+    gemm(ctx, g1);
+    Gemm g2 = mk((int)R, dg, cg, g);                             // dZ = dOp (x)_g Wu
+    g2.A = km(dO, C, cg);
+    g2.B = mn(b.W(DGSCT_P_WU), dg, (long)cg * dg);
+    outE(g2, b.Wk(wb.dZ), E, ds, dg);
+    gemm(ctx, g2);
+  }
+  // B9 ---- relu, BN1 backward, down projection
+  void* dZ = b.Wk(wb.dZ);
+  if (d.use_bn) {
+    bn_bwd_stats(ctx, dZ, b.S(s.Zp), R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, 1, b.Wk<float>(wb.bnsums1));
+    bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, b.Wk<float>(wb.bnsums1), 1, 1,
+                 d.training);
+    ew(ctx, EW_COPY, G(DGSCT_P_BN1_B), DT_F32, F32(b.Wk<float>(wb.bnsums1)), NOARG, NOARG, ds, 0.f, 1);
+    ew(ctx, EW_COPY, G(DGSCT_P_BN1_W), DT_F32, F32(b.Wk<float>(wb.bnsums1) + ds), NOARG, NOARG, ds, 0.f, 1);
+  } else {
+    bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0);
+  }
+  {
+    Gemm g1 = mk(dg, cg, (int)R, g);                             // dWd = dZp^T (x)_g X3
+    g1.A = mn(dZ, ds, dg);
+    g1.B = mn(b.S(s.X3), C, cg);
+    outF(g1, G(DGSCT_P_WD), cg, (long)dg * cg);
+    atomic_out(g1);
+    gemm(ctx, g1);
+    Gemm g2 = mk((int)R, cg, dg, g);                             // dX3 = dZp (x)_g Wd
+    g2.A = km(dZ, ds, dg);
+    g2.B = mn(b.W(DGSCT_P_WD), cg, (long)dg * cg);
+    outE(g2, b.Wk(wb.dX3), E, C, cg);
+    gemm(ctx, g2);
+  }
+  // B8 ---- ln_before, modulation
+  void* dX1 = b.Wk(wb.dX1);
+  modln_bwd(ctx, b.Wk(wb.dX3), b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), tg, d.alpha, d.beta, d.gamma,
+            d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, b.S<float>(s.mu_b), b.S<float>(s.rstd_b), B, N, C, dX1,
+            G(DGSCT_P_LNB_W), G(DGSCT_P_LNB_B), b.Wk<float>(wb.dch), b.Wk<float>(wb.dsg), b.Wk<float>(wb.dtg));
+  // B7 ---- spatial gate
+  {
+    spatial_bwd(ctx, b.S<float>(s.sl), b.S<float>(s.sg), b.S<float>(s.map), b.Wk<float>(wb.dsg), dMap, B, N,
+                b.Wk<float>(wb.dsl), G(DGSCT_P_BS));
+    colsum_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd);  // u
+    ew(ctx, EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1);
+    sum_batch(ctx, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 0);                 // dws
+    ew(ctx, EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd);
+    // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
+    relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f);
+    Gemm g1 = mk((int)R, C, dd);                                 // dXc = dvq2 . Wv2
+    g1.A = km(b.S(s.vq2), dd);
+    g1.B = mn(b.W(DGSCT_P_WV2), C);
+    outE(g1, b.Wk(wb.dXc), E, C);
+    gemm(ctx, g1);
+    Gemm g2 = mk(dd, C, (int)R);                                 // dWv2 = dvq2^T . Xc
+    g2.A = mn(b.S(s.vq2), dd);
+    g2.B = mn(b.S(s.Xc), C);
+    outF(g2, G(DGSCT_P_WV2), C);
+    atomic_out(g2);
+    gemm(ctx, g2);
+    colsum_batched(ctx, b.S(s.vq2), dd, 0, 1, (int)R, dd, nullptr, 0, 1.f, G(DGSCT_P_BV2), 0);
+    xc_bwd(ctx, b.Wk(wb.dXc), b.S(s.X1), dX1, B, N, C, b.S<float>(s.ch), b.Wk<float>(wb.dch));
+  }
+  // B6 ---- channel-gate head
+  {
+    ew(ctx, EW_SIGMOID_BWD, b.Wk(wb.dpre_c), E, F32(b.Wk(wb.dch)), F32(b.S(s.ch)), NOARG, (long)B * C, 0.f, 1);
+    Gemm g1 = mk(C, dd, B);                                      // dWcatt = dpre^T . q
+    g1.A = mn(b.Wk(wb.dpre_c), C); g1.B = mn(b.S(s.q), dd);
+    outF(g1, G(DGSCT_P_WCATT), dd);
+    gemm(ctx, g1);
+    colsum_batched(ctx, b.Wk(wb.dpre_c), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BCATT), 0);
+    Gemm g2 = mk(B, dd, C);                                      // dq = (dpre . Wcatt) * (q > 0)
+    g2.A = km(b.Wk(wb.dpre_c), C); g2.B = mn(b.W(DGSCT_P_WCATT), dd);
+    g2.mask = b.S(s.q); g2.ldmask = dd;
+    outE(g2, b.Wk(wb.dq), E, dd);
+    gemm(ctx, g2);
+    Gemm g3 = mk(dd, C, B);                                      // dWb = dq^T . m1
+    g3.A = mn(b.Wk(wb.dq), dd); g3.B = mn(b.S(s.m1), C);
+    outF(g3, G(DGSCT_P_WB), C);
+    gemm(ctx, g3);
+    colsum_batched(ctx, b.Wk(wb.dq), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BB), 0);
+    Gemm g4 = mk(B, C, dd);                                      // dm1 = dq . Wb
+    g4.A = km(b.Wk(wb.dq), dd); g4.B = mn(b.W(DGSCT_P_WB), C);
+    outF(g4, b.Wk<float>(wb.dm1), C);
+    gemm(ctx, g4);
+    ew(ctx, EW_MUL_MASK, b.Wk(wb.dpa1), E, F32(b.Wk(wb.dm1)), F32(b.S(s.mvq1)), Earg(b.S(s.aq1), E), (long)B * C, 0.f, 1);
+    ew(ctx, EW_MUL, b.Wk(wb.coef), DT_F32, F32(b.Wk(wb.dm1)), Earg(b.S(s.aq1), E), NOARG, (long)B * C, 0.f, 1);
+  }
+  // B5 ---- video query 1
+  {
+    relu_bwd_scale(ctx, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N);
+    Gemm g1 = mk((int)R, C, C);                                  // dX1 += dvq1 . Wv1
+    g1.A = km(b.S(s.vq1), C); g1.B = mn(b.W(DGSCT_P_WV1), C);
+    resid(g1, dX1, E, C);
+    outE(g1, dX1, E, C);
+    gemm(ctx, g1);
+    Gemm g2 = mk(C, C, (int)R);                                  // dWv1 = dvq1^T . X1
+    g2.A = mn(b.S(s.vq1), C); g2.B = mn(b.S(s.X1), C);
+    outF(g2, G(DGSCT_P_WV1), C);
+    atomic_out(g2);
+    gemm(ctx, g2);
+    colsum_batched(ctx, b.S(s.vq1), C, 0, 1, (int)R, C, nullptr, 0, 1.f, G(DGSCT_P_BV1), 0);
+  }
+  // B4 ---- audio queries
+  {
+    Gemm g1 = mk(C, C, B);                                       // dWa1 = dpa1^T . a
+    g1.A = mn(b.Wk(wb.dpa1), C); g1.B = mn(b.S(s.aE), C);
+    outF(g1, G(DGSCT_P_WA1), C);
+    gemm(ctx, g1);
+    colsum_batched(ctx, b.Wk(wb.dpa1), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BA1), 0);
+    Gemm g2 = mk(dd, C, B);                                      // dWa2 = dpa2^T . a
+    g2.A = mn(b.Wk(wb.dpa2), dd); g2.B = mn(b.S(s.aE), C);
+    outF(g2, G(DGSCT_P_WA2), C);
+    gemm(ctx, g2);
+    colsum_batched(ctx, b.Wk(wb.dpa2), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BA2), 0);
+    Gemm g3 = mk(B, C, C);                                       // da = dpa1 . Wa1 + dpa2 . Wa2
+    g3.A = km(b.Wk(wb.dpa1), C); g3.B = mn(b.W(DGSCT_P_WA1), C);
+    outF(g3, b.Wk<float>(wb.da), C);
+    gemm(ctx, g3);
+    Gemm g4 = mk(B, C, dd);
+    g4.A = km(b.Wk(wb.dpa2), dd); g4.B = mn(b.W(DGSCT_P_WA2), C);
+    resid(g4, b.Wk(wb.da), DT_F32, C);
+    outF(g4, b.Wk<float>(wb.da), C);
+    gemm(ctx, g4);
+    if (d.temporal) {
+      float* dtg = b.Wk<float>(wb.dtg);
+      if (dTmap) ew(ctx, EW_ADD_BCAST, dtg, DT_F32, F32(dtg), F32(dTmap), NOARG, B, 1.f, 1);
+      ew(ctx, EW_SIGMOID_BWD, b.Wk(wb.dpre_t), DT_F32, F32(dtg), F32(tg), NOARG, B, 0.f, 1);
+      colsum_batched(ctx, b.S(s.aE), C, 0, 1, B, C, b.Wk<float>(wb.dpre_t), 0, 1.f, G(DGSCT_P_WT), 0);
+      sum_batch(ctx, b.Wk<float>(wb.dpre_t), 1, B, 1, G(DGSCT_P_BT), 1.f, 0);
+      ew(ctx, EW_OUTER_ACC, b.Wk(wb.da), DT_F32, F32(b.Wk(wb.dpre_t)), F32(b.F(DGSCT_P_WT)), NOARG, (long)B * C, 0.f, C);
+    }
+  }
+  // B3 ---- X <- tokens attention
+  {
+    Gemm g1 = mk(N, tk, C, B);                                   // U = dX1 . tok^T
+    g1.A = km(dX1, C, (long)N * C);
+    g1.B = km(b.S(s.tok), C, (long)tk * C);
+    outF(g1, b.Wk<float>(wb.U), tkp, (long)N * tkp);
+    gemm(ctx, g1);
+    softmax_bwd_rows(ctx, b.S(s.P2), tkp, b.Wk<float>(wb.U), tkp, b.Wk(wb.dS2), E, tkp, R, tk, b.F(DGSCT_P_GATE_AV),
+                     G(DGSCT_P_GATE_AV));
+    Gemm g2 = mk(N, C, tk, B);                                   // dX = dX1 + dS2 . tok
+    g2.A = km(b.Wk(wb.dS2), tkp, (long)N * tkp);
+    g2.B = mn(b.S(s.tok), C, (long)tk * C);
+    resid(g2, dX1, E, C, (long)N * C);
+    outE(g2, dX, E, C, (long)N * C);
+    gemm(ctx, g2);
+    Gemm g3 = mk(tk, C, N, B);                                   // dtok = gate_av * P2^T . dX1
+    g3.A = mn(b.S(s.P2), tkp, (long)N * tkp);
+    g3.B = mn(dX1, C, (long)N * C);
+    g3.alpha_ptr = b.F(DGSCT_P_GATE_AV);
+    outF(g3, b.Wk<float>(wb.dtokF), C, (long)tk * C);
+    gemm(ctx, g3);
+    Gemm g4 = mk(tk, C, N, B);                                   //      + dS2^T . X
+    g4.A = mn(b.Wk(wb.dS2), tkp, (long)N * tkp);
+    g4.B = mn(X, C, (long)N * C);
+    resid(g4, b.Wk(wb.dtokF), DT_F32, C, (long)tk * C);
+    outF(g4, b.Wk<float>(wb.dtokF), C, (long)tk * C);
+    gemm(ctx, g4);
+    cvt(ctx, b.Wk<float>(wb.dtokF), b.Wk(wb.dtokE), E, (long)B * tk * C);
+  }
+  // B2 ---- tokens <- remapped tokens attention
+  void* dYp = b.Wk(wb.dYp);
+  {
+    const void* Yp = b.S(s.Yp);
+    Gemm g1 = mk(tk, N, C, B);                                   // dP1 = dtok . Yp^T
+    g1.A = km(b.Wk(wb.dtokE), C, (long)tk * C);
+    g1.B = km(Yp, C, (long)N * C);
+    outF(g1, b.Wk<float>(wb.dP1), Np, (long)tk * Np);
+    gemm(ctx, g1);
+    softmax_bwd_rows(ctx, b.S(s.P1), Np, b.Wk<float>(wb.dP1), Np, b.Wk(wb.dS1), E, Np, (long)B * tk, N, nullptr, nullptr);
+    Gemm g2 = mk(tk, C, N, B);                                   // dtokF += dS1 . Yp      (then summed over b -> dT0)
+    g2.A = km(b.Wk(wb.dS1), Np, (long)tk * Np);
+    g2.B = mn(Yp, C, (long)N * C);
+    resid(g2, b.Wk(wb.dtokF), DT_F32, C, (long)tk * C);
+    outF(g2, b.Wk<float>(wb.dtokF), C, (long)tk * C);
+    gemm(ctx, g2);
+    sum_batch(ctx, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 0);
+    ew(ctx, EW_SCALE, b.Wk(wb.daN), DT_F32, F32(b.Wk(wb.da)), NOARG, NOARG, (long)B * C, 1.f / (float)N, 1);
+    Gemm g3 = mk(N, C, tk, B);                                   // dYp = P1^T . dtok + da/N
+    g3.A = mn(b.S(s.P1), Np, (long)tk * Np);
+    g3.B = mn(b.Wk(wb.dtokE), C, (long)tk * C);
+    g3.bias_n = b.Wk<float>(wb.daN); g3.bias_n_bs = C;
+    outE(g3, dYp, E, C, (long)N * C);
+    gemm(ctx, g3);
+    Gemm g4 = mk(N, C, tk, B);                                   //      + dS1^T . T0
+    g4.A = mn(b.Wk(wb.dS1), Np, (long)tk * Np);
+    g4.B = mn(b.W(DGSCT_P_TOKENS), C, 0);
+    resid(g4, dYp, E, C, (long)N * C);
+    outE(g4, dYp, E, C, (long)N * C);
+    gemm(ctx, g4);
+  }
+  // B1 ---- remap
+  {
+    const bool conv = d.remap == DGSCT_REMAP_CONV;
+    if (conv) {
+      colsum_batched(ctx, dYp, C, 0, 1, (int)R, C, nullptr, 0, 1.f, G(DGSCT_P_BC), 0);                    // dbc
+      rowdot_batched(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
+      sum_batch(ctx, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 0);                             // dbn
+      colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);    // d rowsum(Wc)
+    } else {
+      colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);
+    }
+    if (orderA) {
+      Gemm g1 = mk((int)R, Co, C);                               // dT1 = dYp . Wc
+      g1.A = km(dYp, C); g1.B = mn(b.W(DGSCT_P_WC), Co);
+      outE(g1, b.Wk(wb.dT), E, Co);
+      gemm(ctx, g1);
+      Gemm g2 = mk(C, Co, (int)R);                               // dWc = dYp^T . T1
+      g2.A = mn(dYp, C); g2.B = mn(b.S(s.T), Co);
+      outF(g2, G(DGSCT_P_WC), Co);
+      atomic_out(g2);
+      gemm(ctx, g2);
+      Gemm g3 = mk(No, Co, N, B);                                // dY[b] = Wn^T . dT1[b]
+      g3.A = mn(b.W(DGSCT_P_WN), No);
+      g3.B = mn(b.Wk(wb.dT), Co, (long)N * Co);
+      outE(g3, dY, E, Co, (long)No * Co);
+      gemm(ctx, g3);
+      if (conv) {
+        Gemm g4 = mk(N, No, Co);                                 // dWn = sum_b dT1[b] . Y[b]^T
+        g4.KB = B;
+        g4.A = km(b.Wk(wb.dT), Co, 0, (long)N * Co);
+        g4.B = km(Y, Co, 0, (long)No * Co);
+        outF(g4, G(DGSCT_P_WN), No);
+        atomic_out(g4);
+        gemm(ctx, g4);
+      }
+    } else {
+      Gemm g1 = mk(C, No, N, B);                                 // dT2t[b] = dYp[b]^T . Wn     [C][No]
+      g1.A = mn(dYp, C, (long)N * C);
+      g1.B = mn(b.W(DGSCT_P_WN), No);
+      outE(g1, b.Wk(wb.dT), E, Nop, (long)C * Nop);
+      gemm(ctx, g1);
+      if (conv) {
+        Gemm g2 = mk(N, No, C);                                  // dWn = sum_b dYp[b] . T2[b]^T
+        g2.KB = B;
+        g2.A = km(dYp, C, 0, (long)N * C);
+        g2.B = mn(b.S(s.T), Nop, 0, (long)C * Nop);
+        outF(g2, G(DGSCT_P_WN), No);
+        atomic_out(g2);
+        gemm(ctx, g2);
+      }
+      Gemm g3 = mk(No, Co, C, B);                                // dY[b] = dT2[b] . Wc
+      g3.A = mn(b.Wk(wb.dT), Nop, (long)C * Nop);
+      g3.B = mn(b.W(DGSCT_P_WC), Co);
+      outE(g3, dY, E, Co, (long)No * Co);
+      gemm(ctx, g3);
+      Gemm g4 = mk(C, Co, No);                                   // dWc = sum_b dT2t[b] . Y[b]
+      g4.KB = B;
+      g4.A = km(b.Wk(wb.dT), Nop, 0, (long)C * Nop);
+      g4.B = mn(Y, Co, 0, (long)No * Co);
+      outF(g4, G(DGSCT_P_WC), Co);
+      atomic_out(g4);
+      gemm(ctx, g4);
+    }
+    if (conv)   // + d rowsum(Wc)[c] broadcast over co
+      ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
+  }
+  return has_error() ? 1 : 0;
+}
+
+}  // namespace dgsct

@@ -1,0 +1,53 @@
+// Buffer layout + kernel schedule of one adapter call (see plan.cpp).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/dgsct.h"
+
+namespace dgsct {
+
+struct Region { std::string name; int64_t offset, bytes; };
+
+struct Plan {
+  explicit Plan(const dgsct_adapter_desc& d);
+  bool ok = false;
+  dgsct_adapter_desc d;
+  int B, N, C, No, Co, tk, g, dd, ds, E, Np, Nop, tkp;
+  int64_t es, R;
+  bool orderA;   // remap association: (Wn.Y).Wc^T (A) or Wn.(Y.Wc^T) (B), whichever is cheaper
+
+  // prep
+  int64_t prep_w[DGSCT_P_COUNT], wnumel[DGSCT_P_COUNT], prep_rowb, prep_colb, prep_colb2, prep_bytes;
+  // saved
+  struct {
+    int64_t a, mvq1, bnacc1, bnacc2, zero_end;
+    int64_t Yp, T, P1, tok, aE, P2, X1, aq1, aq2, vq1, m1, q, ch, Xc, vq2, sl, sg, map, tg, X3, mu_b, rstd_b, Zp, Z, Op,
+        bn1, bn2, mu_p, rstd_p;
+  } s;
+  std::vector<Region> saved_regions;
+  int64_t saved_bytes;
+  // forward / backward scratch
+  struct { int64_t S1, S2; } wf;
+  struct {
+    int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, zero_end;
+    int64_t dO, dZ, dX3, dX1, dXc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, daN, dpre_t, U, dS2, dtokF,
+        dtokE, dP1, dS1, dYp, dT, rowtmp;
+  } wb;
+  int64_t ws_fwd_bytes, ws_bwd_bytes;
+  // gradients
+  int64_t grad_off[DGSCT_P_COUNT], grad_numel[DGSCT_P_COUNT], grad_floats;
+
+  int prepare(float* const* params, void* prep, void* stream) const;
+  int forward(float* const* params, const void* prep, const void* X, const void* Y, void* out, float* map, float* tmap,
+              void* saved, void* ws, void* stream) const;
+  int backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved, const void* dOut,
+               const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws, void* stream) const;
+
+ private:
+  bool validate();
+  void layout();
+};
+
+}  // namespace dgsct

@@ -1,0 +1,143 @@
+// Primitive operations of the DG-SCT adapter path.
+//
+// plan.cpp (the kernel schedule of one adapter forward / backward) is written against this
+// interface only.  The product library links it with prims_hip.hip + gemm.hip (hand-written gfx950
+// kernels).  tests/emu/prims_host.cpp implements the same interface with plain host loops so that
+// the schedule itself (offsets, strides, operand roles) can be checked against the oracle in the
+// CPU-only container; that object is TEST INFRASTRUCTURE and is never linked into libdgsct.so.
+//
+// Conventions: "E" is the storage/MFMA-operand dtype of the call (ctx.mode: F32 or BF16), "F" is
+// fp32.  All reductions and transcendental math are fp32.  Every pointer is a device pointer (host
+// pointer in the emulation), nothing is allocated or freed here, every launch goes to ctx.stream.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace dgsct {
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+struct Ctx {
+  void* stream;   // hipStream_t
+  int mode;       // DType of E
+};
+
+// One GEMM operand X[r][k] (r = M- or N-index, k = contraction index), element type E.
+//   kmajor = 1 : &X[r][k] = p + r*ld + k     (k contiguous)
+//   kmajor = 0 : &X[r][k] = p + k*ld + r     (r contiguous; staged to LDS and transpose-read)
+// Batched by bs (0 = shared by all batches).  Two-level contraction: k = kb*K + ki, kb < KB adds kb*kbs.
+struct MatOp {
+  const void* p = nullptr;
+  long ld = 0;
+  int kmajor = 1;
+  long bs = 0;
+  long kbs = 0;
+};
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+// D[b][m][n] = epi( sum_{kb<KB} sum_{k<K} A[b][m][(kb,k)] * B[b][n][(kb,k)] )
+//   v  = alpha * (alpha_ptr ? *alpha_ptr : 1) * acc
+//        + bias_m[m % m_mod] + bias_n[b*bias_n_bs + n] + r1_m[m % m_mod] * r1_n[n]
+//   v  = act(v);  if (mask) v *= (mask[b][m][n] > 0);  if (R) v += beta * R[b][m][n]
+//   atomic ? atomicAdd(D, v) (D fp32, pre-zeroed, used with splitk > 1) : D = v
+struct Gemm {
+  int M = 0, N = 0, K = 0, KB = 1, batch = 1, splitk = 1, atomic = 0;
+  MatOp A, B;
+  void* D = nullptr; int ddt = DT_F32; long ldd = 0, dbs = 0;
+  float alpha = 1.f; const float* alpha_ptr = nullptr;
+  const float* bias_m = nullptr; const float* bias_n = nullptr; long bias_n_bs = 0; int m_mod = 0;
+  const float* r1_m = nullptr; const float* r1_n = nullptr;
+  int act = ACT_NONE;
+  const void* R = nullptr; int rdt = DT_F32; long ldr = 0, rbs = 0; float beta = 1.f;
+  const void* mask = nullptr; long ldmask = 0, maskbs = 0;   // dtype E
+};
+
+void gemm(const Ctx&, const Gemm&);
+void zero(const Ctx&, void* p, size_t bytes);
+
+// out[r][0..L) = softmax(pre_tanh ? tanh(in[r][.]) : in[r][.]); out[r][L..ld_out) = 0.  out dtype odt.
+void softmax_rows(const Ctx&, const float* in, long ld_in, void* out, int odt, long ld_out, long rows, int L, int pre_tanh);
+// out = P * (s*dP - sum_j P_j*s*dP_j), s = scale_ptr ? *scale_ptr : 1; if dot_accum: *dot_accum += sum P*dP (unscaled).
+// P is E; out dtype odt; out[r][L..ldo) = 0.
+void softmax_bwd_rows(const Ctx&, const void* P, long ldp, const float* dP, long lddp, void* out, int odt, long ldo,
+                      long rows, int L, const float* scale_ptr, float* dot_accum);
+
+// out[b][c] += scale * sum_n roww[b*roww_bs + n] * x[b][n][c]     (roww == null -> 1).  x is E [B][N][ld]; out pre-zeroed.
+void colsum_batched(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const float* roww, long roww_bs,
+                    float scale, float* out, long out_bs);
+// out[b][n] = sum_c x[b][n][c] * w[b*w_bs + c] * (w2 ? w2[c] : 1) + (bias ? *bias : 0).   w dtype wdt.
+void rowdot_batched(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const void* w, int wdt, long w_bs,
+                    const float* w2, const float* bias, float* out);
+// out[i] = (accumulate ? out[i] : 0) + scale * sum_b in[b*bs + i]
+void sum_batch(const Ctx&, const float* in, long bs, int B, long n, float* out, float scale, int accumulate);
+// y[b][n][c] = x[b][n][c] * (add + colw[b][c])         x,y are E (may alias)
+void scale_cols(const Ctx&, const void* x, void* y, int B, int N, int C, const float* colw, float add);
+// y[b][n][c] = (x[b][n][c] > 0) * (roww ? roww[b][n] : 1) * colw[b][c] * (colw2 ? colw2[c] : 1) * scale     x,y E (may alias)
+void relu_bwd_scale(const Ctx&, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
+                    const float* colw2, float scale);
+// dX1[b][n][c] += dXc[b][n][c] * (1 + ch[b][c]);  dch[b][c] += sum_n dXc * X1        (all big tensors E, dch pre-initialised)
+void xc_bwd(const Ctx&, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch);
+
+// sg = sigmoid(sl); map = softmax_N(tanh(sl))                [B][N] fp32
+void spatial_fwd(const Ctx&, const float* sl, int B, int N, float* sg, float* map);
+// dsl = dsg*sg*(1-sg) + [dMap] map*(dMap - sum map*dMap)*(1 - tanh(sl)^2);  *dbs += sum dsl
+void spatial_bwd(const Ctx&, const float* sl, const float* sg, const float* map, const float* dsg, const float* dMap,
+                 int B, int N, float* dsl, float* dbs);
+
+// X2 = X1 * (alpha*ch[b][c] + beta*sg[b][n] + gamma*tg[b] + 1 - alpha); X3 = lnw ? LN(X2) : X2; mu/rstd [B*N] (if lnw)
+void modln_fwd(const Ctx&, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta,
+               float gamma, const float* lnw, const float* lnb, float eps, int B, int N, int C, void* X3, float* mu, float* rstd);
+// inverse of the above: dX1 = dX2 * mod (written, not accumulated); dlnw/dlnb[c] += ...; dch[b][c] += alpha*sum_n dX2*X1;
+// dsg[b][n] = beta * sum_c dX2*X1; dtg[b] += gamma * sum_{n,c} dX2*X1 (if tg)
+void modln_bwd(const Ctx&, const void* dX3, const void* X1, const float* ch, const float* sg, const float* tg, float alpha,
+               float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N, int C,
+               void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg);
+
+// acc = [shift | sum(x-shift) | sum((x-shift)^2)] per column, 3*C floats, pre-zeroed.  x is E [rows][C].
+void bn_stats(const Ctx&, const void* x, long rows, int C, float* acc);
+// training: mean/var from acc, running stats updated (momentum, unbiased var); eval: mean/var = running.
+// Writes mean, rstd, sc = w*rstd, sh = b - mean*sc  (each [C]).
+void bn_finalize(const Ctx&, const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
+                 float* run_var, float momentum, float eps, int training, float* mean, float* rstd, float* sc, float* sh);
+// y = x*sc + sh (sc == null -> identity), optional relu.  E -> E
+void affine_act(const Ctx&, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu);
+// sums[0][c] += sum dyb, sums[1][c] += sum dyb*xh with dyb = dy * (relu ? (x*sc+sh > 0) : 1), xh = (x-mean)*rstd
+void bn_bwd_stats(const Ctx&, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
+                  const float* sc, const float* sh, int relu, float* sums);
+// dx = training ? sc*(dyb - sums0/rows - xh*sums1/rows) : sc*dyb ;  has_bn == 0: dx = dyb.   in place allowed
+void bn_bwd_apply(const Ctx&, const void* dy, const void* x, void* dx, long rows, int C, const float* mean, const float* rstd,
+                  const float* sc, const float* sh, const float* sums, int relu, int has_bn, int training);
+
+// O = Op*sc2 + sh2 (sc2 null -> Op).  gate_first: G = gate*O, out = lnw ? LN(G) : G.
+// else: L = lnw ? LN(O) : O, out = gate ? gate*L : L.  mu/rstd [B*N] written when lnw.
+void tail_fwd(const Ctx&, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
+              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd);
+// backward of tail_fwd: writes dO (E); accumulates dlnw, dlnb [C], *dgate, and (if bnsums) bnsums[0][c] += sum dO,
+// bnsums[1][c] += sum dO * (Op - mean2)*rstd2.
+void tail_bwd(const Ctx&, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
+              const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
+              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums);
+
+// Small fp32/E elementwise helpers on [n]-sized vectors (n <= a few 100k).
+enum EwOp : int {
+  EW_MUL = 0,          // o = a*b
+  EW_MUL_MASK = 1,     // o = a*b*(c>0)
+  EW_SIGMOID_BWD = 2,  // o = a*b*(1-b)
+  EW_SCALE = 3,        // o = s*a
+  EW_ADD_BCAST = 4,    // o[i] = a[i] + s*b[i / div]            (b broadcast over the fast dim of size div)
+  EW_OUTER_ACC = 5,    // o[i] += a[i / div] * b[i % div]       (rank-1 accumulate, fp32 o)
+  EW_COPY = 6,         // o = a
+  EW_MULB_MASK = 7,    // o[i] = a[i] * b[i % div] * (c[i] > 0)
+};
+struct EwArg { const void* p = nullptr; int dt = DT_F32; };
+void ew(const Ctx&, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n, float s, long div);
+// tg[b] = sigmoid(a[b][:] . wt + bt)
+void temporal_fwd(const Ctx&, const float* a, const float* wt, const float* bt, int B, int C, float* tg);
+// out[i] = (E) in[i]   i < n, for weights: fp32 master -> E copy
+void cvt(const Ctx&, const float* in, void* out, int odt, long n);
+// out[r] = sum_c W[r][c]  (fp32 [R][C] -> fp32 [R])
+void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out);
+
+}  // namespace dgsct

@@ -1,0 +1,1067 @@
+// Non-GEMM kernels of the DG-SCT adapter path for gfx950 (wave64, 256-thread workgroups).
+//
+// Two access patterns cover everything:
+//  * "row" kernels (LayerNorm-like): a power-of-two group of GS <= 64 lanes owns one token row of C
+//    channels, each lane holds NV 16-byte vectors in registers; row statistics are wave-shuffle
+//    reductions (no LDS); per-channel sums across rows (parameter gradients, BatchNorm sums) stay in
+//    registers across the row loop, are combined in LDS (ds_add_f32) and leave the workgroup as one
+//    fp32 atomic per channel.
+//  * "column-strip" kernels (per-channel affine / reductions over tokens): a thread owns VE consecutive
+//    channels and walks rows; loads are 16 B per lane and coalesced along the channel axis.
+// All of them are HBM-bound; they read and write each big tensor exactly once.
+#include <hip/hip_runtime.h>
+#include "prims.h"
+#include "device_util.h"
+#include "err.h"
+
+namespace dgsct {
+
+#define STREAM(ctx) ((hipStream_t)(ctx).stream)
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+void zero(const Ctx& ctx, void* p, size_t bytes) {
+  if (bytes) (void)hipMemsetAsync(p, 0, bytes, STREAM(ctx));
+}
+
+// ================================================================================================
+// row-kernel geometry
+// ================================================================================================
+struct RowGeom { int gs, nv, rpp, rpc, chunks; };
+static RowGeom row_geom(int C, int VE, int N, int B) {
+  RowGeom g;
+  int nvec = C / VE;
+  g.gs = 1;
+  while (g.gs < nvec && g.gs < 64) g.gs <<= 1;
+  g.nv = (nvec + g.gs - 1) / g.gs;
+  g.rpp = 256 / g.gs;
+  long want = cdiv(2048, B);                      // ~2048 workgroups in flight
+  long maxc = cdiv(N, g.rpp);
+  long chunks = want < 1 ? 1 : (want > maxc ? maxc : want);
+  g.rpc = (int)(cdiv(cdiv(N, chunks), g.rpp) * g.rpp);
+  g.chunks = (int)cdiv(N, g.rpc);
+  return g;
+}
+// dispatch on (mode, vector width): bf16 -> 8 (C%8==0) or 4; f32 -> 4.  C % 4 == 0 is required.
+#define ROW_DISPATCH(ctx, C, KERNEL, GRID, ...)                                                            \
+  do {                                                                                                      \
+    if ((C) % 4 != 0 || (C) > 1536) { set_error("row kernel: C=%d must be a multiple of 4 and <= 1536", (int)(C)); break; } \
+    if ((ctx).mode == DT_BF16) {                                                                            \
+      if ((C) % 8 == 0) hipLaunchKernelGGL((KERNEL<DT_BF16, 8, 3>), GRID, dim3(256), 0, STREAM(ctx), __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<DT_BF16, 4, 6>), GRID, dim3(256), 0, STREAM(ctx), __VA_ARGS__);       \
+    } else {                                                                                                \
+      hipLaunchKernelGGL((KERNEL<DT_F32, 4, 6>), GRID, dim3(256), 0, STREAM(ctx), __VA_ARGS__);             \
+    }                                                                                                       \
+  } while (0)
+static inline int row_ve(const Ctx& ctx, int C) { return ctx.mode == DT_BF16 ? (C % 8 == 0 ? 8 : 4) : 4; }
+
+// flush per-lane channel accumulators: LDS combine across the row-groups of the workgroup, then one
+// global atomic per channel.  lds: NQ*C floats (zeroed here).
+template <int NQ, int VE, int MAXNV>
+__device__ __forceinline__ void flush_cols(float (&acc)[NQ][MAXNV][VE], float* lds, int C, int gs, int nv, int gl,
+                                           float* const (&dst)[NQ]) {
+  for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v) {
+    const int col = (v * gs + gl) * VE;
+    if (v < nv && col < C) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) atomicAdd(&lds[q * C + col + e], acc[q][v][e]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) {
+    const int q = i / C;
+    if (dst[q]) unsafeAtomicAdd(dst[q] + (i - q * C), lds[i]);
+  }
+}
+
+// ================================================================================================
+// modulation + ln_before                                   (reference net_trans.py:611-627)
+// ================================================================================================
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256) void modln_fwd_k(const void* X1, const float* ch, const float* sg, const float* tg,
+                                                   float alpha, float beta, float gamma, const float* lnw,
+                                                   const float* lnb, float eps, int N, int C, int gs, int nv, int rpc,
+                                                   void* X3, float* mu, float* rstd) {
+  const int b = blockIdx.y, gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
+  float cm[MAXNV][VE], w[MAXNV][VE], bb[MAXNV][VE];
+  const float tgv = tg ? gamma * tg[b] : 0.f;
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v) {
+    const int col = (v * gs + gl) * VE;
+    if (v < nv && col < C) {
+      float t[VE];
+      ldf<VE>(ch + (long)b * C, col, t);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) cm[v][e] = alpha * t[e] + 1.f - alpha + tgv;
+      if (lnw) { ldf<VE>(lnw, col, w[v]); ldf<VE>(lnb, col, bb[v]); }
+    }
+  }
+  for (int n = blockIdx.x * rpc + sub; n < n_end; n += rpp) {
+    const long row = (long)b * N + n;
+    const float sgv = beta * sg[row];
+    float x[MAXNV][VE];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        ldv<DT, VE>(X1, row * C + col, x[v]);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { x[v][e] *= (cm[v][e] + sgv); s += x[v][e]; }
+      }
+    }
+    if (lnw) {
+      const float mean = group_sum(s, gs) / C;
+      float q = 0.f;
+#pragma unroll
+      for (int v = 0; v < MAXNV; ++v) {
+        const int col = (v * gs + gl) * VE;
+        if (v < nv && col < C) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) { const float d = x[v][e] - mean; q += d * d; }
+        }
+      }
+      const float rs = rsqrtf(group_sum(q, gs) / C + eps);
+#pragma unroll
+      for (int v = 0; v < MAXNV; ++v) {
+        const int col = (v * gs + gl) * VE;
+        if (v < nv && col < C) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) x[v][e] = (x[v][e] - mean) * rs * w[v][e] + bb[v][e];
+        }
+      }
+      if (gl == 0) { mu[row] = mean; rstd[row] = rs; }
+    }
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) stv<DT, VE>(X3, row * C + col, x[v]);
+    }
+  }
+}
+
+void modln_fwd(const Ctx& ctx, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta,
+               float gamma, const float* lnw, const float* lnb, float eps, int B, int N, int C, void* X3, float* mu,
+               float* rstd) {
+  RowGeom g = row_geom(C, row_ve(ctx, C), N, B);
+  ROW_DISPATCH(ctx, C, modln_fwd_k, dim3(g.chunks, B), X1, ch, sg, tg, alpha, beta, gamma, lnw, lnb, eps, N, C, g.gs, g.nv,
+               g.rpc, X3, mu, rstd);
+}
+
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* X1, const float* ch, const float* sg,
+                                                   const float* tg, float alpha, float beta, float gamma,
+                                                   const float* lnw, const float* mu, const float* rstd, int N, int C,
+                                                   int gs, int nv, int rpc, void* dX1, float* dlnw, float* dlnb,
+                                                   float* dch, float* dsg, float* dtg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y, gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
+  float cm[MAXNV][VE], w[MAXNV][VE];
+  float acc[3][MAXNV][VE];   // 0: dlnw, 1: dlnb, 2: sum_n dX2*X1 (-> dch)
+  const float tgv = tg ? gamma * tg[b] : 0.f;
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v) {
+    const int col = (v * gs + gl) * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { acc[0][v][e] = 0.f; acc[1][v][e] = 0.f; acc[2][v][e] = 0.f; }
+    if (v < nv && col < C) {
+      float t[VE];
+      ldf<VE>(ch + (long)b * C, col, t);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) cm[v][e] = alpha * t[e] + 1.f - alpha + tgv;
+      if (lnw) ldf<VE>(lnw, col, w[v]);
+    }
+  }
+  float tsum = 0.f;
+  for (int n = blockIdx.x * rpc + sub; n < n_end; n += rpp) {
+    const long row = (long)b * N + n;
+    const float sgv = beta * sg[row];
+    float g[MAXNV][VE], x1[MAXNV][VE], xh[MAXNV][VE];
+    float s1 = 0.f, s2 = 0.f;
+    const float mean = lnw ? mu[row] : 0.f, rs = lnw ? rstd[row] : 1.f;
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        ldv<DT, VE>(dX3, row * C + col, g[v]);
+        ldv<DT, VE>(X1, row * C + col, x1[v]);
+        if (lnw) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            xh[v][e] = (x1[v][e] * (cm[v][e] + sgv) - mean) * rs;
+            acc[0][v][e] += g[v][e] * xh[v][e];
+            acc[1][v][e] += g[v][e];
+            g[v][e] *= w[v][e];
+            s1 += g[v][e];
+            s2 += g[v][e] * xh[v][e];
+          }
+        }
+      }
+    }
+    if (lnw) {
+      s1 = group_sum(s1, gs) / C;
+      s2 = group_sum(s2, gs) / C;
+    }
+    float rsum = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        float o[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float dx2 = lnw ? rs * (g[v][e] - s1 - xh[v][e] * s2) : g[v][e];
+          const float dm = dx2 * x1[v][e];
+          acc[2][v][e] += dm;
+          rsum += dm;
+          o[e] = dx2 * (cm[v][e] + sgv);
+        }
+        stv<DT, VE>(dX1, row * C + col, o);
+      }
+    }
+    rsum = group_sum(rsum, gs);
+    if (gl == 0) { dsg[row] = beta * rsum; tsum += rsum; }
+  }
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v)
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[2][v][e] *= alpha;
+  float* const dst[3] = {dlnw, dlnb, dch + (long)b * C};
+  flush_cols<3, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst);
+  if (dtg) {
+    const float t = block_sum(tsum, lds);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dtg + b, gamma * t);
+  }
+}
+
+void modln_bwd(const Ctx& ctx, const void* dX3, const void* X1, const float* ch, const float* sg, const float* tg,
+               float alpha, float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N,
+               int C, void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg) {
+  RowGeom g = row_geom(C, row_ve(ctx, C), N, B);
+  const size_t sh = (size_t)3 * C * sizeof(float);
+#define K_(DT_, VE_, NV_) hipLaunchKernelGGL((modln_bwd_k<DT_, VE_, NV_>), dim3(g.chunks, B), dim3(256), sh, STREAM(ctx), dX3, X1, \
+        ch, sg, tg, alpha, beta, gamma, lnw, mu, rstd, N, C, g.gs, g.nv, g.rpc, dX1, dlnw, dlnb, dch, dsg, tg ? dtg : nullptr)
+  if (C % 4 != 0 || C > 1536) { set_error("modln_bwd: C=%d must be a multiple of 4 and <= 1536", C); return; }
+  if (ctx.mode == DT_BF16) { if (C % 8 == 0) K_(DT_BF16, 8, 3); else K_(DT_BF16, 4, 6); }
+  else K_(DT_F32, 4, 6);
+#undef K_
+}
+
+// ================================================================================================
+// tail: BN2 affine -> ln_post / gate                        (reference net_trans.py:643,668-671)
+// ================================================================================================
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256) void tail_fwd_k(const void* Op, const float* sc2, const float* sh2, const float* lnw,
+                                                  const float* lnb, const float* gate, int gate_first, float eps,
+                                                  long rows, int C, int gs, int nv, int rpc, void* out, float* mu,
+                                                  float* rstd) {
+  const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
+  const float gv = gate ? *gate : 1.f;
+  float sc[MAXNV][VE], sh[MAXNV][VE], w[MAXNV][VE], bb[MAXNV][VE];
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v) {
+    const int col = (v * gs + gl) * VE;
+    if (v < nv && col < C) {
+      if (sc2) { ldf<VE>(sc2, col, sc[v]); ldf<VE>(sh2, col, sh[v]); }
+      if (lnw) { ldf<VE>(lnw, col, w[v]); ldf<VE>(lnb, col, bb[v]); }
+    }
+  }
+  for (long row = (long)blockIdx.x * rpc + sub; row < r_end; row += rpp) {
+    float x[MAXNV][VE];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        ldv<DT, VE>(Op, row * C + col, x[v]);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          if (sc2) x[v][e] = x[v][e] * sc[v][e] + sh[v][e];
+          if (gate_first) x[v][e] *= gv;
+          s += x[v][e];
+        }
+      }
+    }
+    if (lnw) {
+      const float mean = group_sum(s, gs) / C;
+      float q = 0.f;
+#pragma unroll
+      for (int v = 0; v < MAXNV; ++v) {
+        const int col = (v * gs + gl) * VE;
+        if (v < nv && col < C) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) { const float d = x[v][e] - mean; q += d * d; }
+        }
+      }
+      const float rs = rsqrtf(group_sum(q, gs) / C + eps);
+#pragma unroll
+      for (int v = 0; v < MAXNV; ++v) {
+        const int col = (v * gs + gl) * VE;
+        if (v < nv && col < C) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) x[v][e] = (x[v][e] - mean) * rs * w[v][e] + bb[v][e];
+        }
+      }
+      if (gl == 0) { mu[row] = mean; rstd[row] = rs; }
+    }
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        if (!gate_first) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) x[v][e] *= gv;
+        }
+        stv<DT, VE>(out, row * C + col, x[v]);
+      }
+    }
+  }
+}
+
+void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
+              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd) {
+  RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1);
+  ROW_DISPATCH(ctx, C, tail_fwd_k, dim3(g.chunks), Op, sc2, sh2, lnw, lnb, gate, gate_first, eps, rows, C, g.gs, g.nv, g.rpc,
+               out, mu, rstd);
+}
+
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256) void tail_bwd_k(const void* dOut, const void* Op, const float* sc2, const float* sh2,
+                                                  const float* mean2, const float* rstd2, const float* lnw,
+                                                  const float* lnb, const float* gate, int gate_first, const float* mu,
+                                                  const float* rstd, long rows, int C, int gs, int nv, int rpc, void* dO,
+                                                  float* dlnw, float* dlnb, float* dgate, float* bnsums) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
+  const float gv = gate ? *gate : 1.f;
+  float sc[MAXNV][VE], sh[MAXNV][VE], w[MAXNV][VE], bb[MAXNV][VE], m2[MAXNV][VE], r2[MAXNV][VE];
+  float acc[4][MAXNV][VE];   // 0: dlnw 1: dlnb 2: sum dO 3: sum dO*xh2
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v) {
+    const int col = (v * gs + gl) * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { acc[0][v][e] = acc[1][v][e] = acc[2][v][e] = acc[3][v][e] = 0.f; }
+    if (v < nv && col < C) {
+      if (sc2) { ldf<VE>(sc2, col, sc[v]); ldf<VE>(sh2, col, sh[v]); ldf<VE>(mean2, col, m2[v]); ldf<VE>(rstd2, col, r2[v]); }
+      if (lnw) { ldf<VE>(lnw, col, w[v]); ldf<VE>(lnb, col, bb[v]); }
+    }
+  }
+  float gsum = 0.f;
+  for (long row = (long)blockIdx.x * rpc + sub; row < r_end; row += rpp) {
+    float g[MAXNV][VE], o[MAXNV][VE], xh[MAXNV][VE], op[MAXNV][VE];
+    const float mean = lnw ? mu[row] : 0.f, rs = lnw ? rstd[row] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        ldv<DT, VE>(dOut, row * C + col, g[v]);
+        ldv<DT, VE>(Op, row * C + col, op[v]);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          o[v][e] = sc2 ? op[v][e] * sc[v][e] + sh[v][e] : op[v][e];
+          if (gate_first) {
+            // G = gate*O ; out = LN(G)
+            if (lnw) {
+              xh[v][e] = (o[v][e] * gv - mean) * rs;
+              acc[0][v][e] += g[v][e] * xh[v][e];
+              acc[1][v][e] += g[v][e];
+              g[v][e] *= w[v][e];
+              s1 += g[v][e];
+              s2 += g[v][e] * xh[v][e];
+            }
+          } else {
+            // L = LN(O) ; out = gate*L
+            float L;
+            if (lnw) { xh[v][e] = (o[v][e] - mean) * rs; L = xh[v][e] * w[v][e] + bb[v][e]; }
+            else L = o[v][e];
+            if (gate) gsum += g[v][e] * L;
+            g[v][e] *= gv;                      // dL
+            if (lnw) {
+              acc[0][v][e] += g[v][e] * xh[v][e];
+              acc[1][v][e] += g[v][e];
+              g[v][e] *= w[v][e];
+              s1 += g[v][e];
+              s2 += g[v][e] * xh[v][e];
+            }
+          }
+        }
+      }
+    }
+    if (lnw) { s1 = group_sum(s1, gs) / C; s2 = group_sum(s2, gs) / C; }
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        float d[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          float t = lnw ? rs * (g[v][e] - s1 - xh[v][e] * s2) : g[v][e];   // dG (gate_first) or dO
+          if (gate_first) {
+            if (gate) gsum += t * o[v][e];
+            t *= gv;
+          }
+          d[e] = t;
+          if (sc2) {
+            acc[2][v][e] += t;
+            acc[3][v][e] += t * (op[v][e] - m2[v][e]) * r2[v][e];
+          }
+        }
+        stv<DT, VE>(dO, row * C + col, d);
+      }
+    }
+  }
+  float* const dst[4] = {dlnw, dlnb, bnsums, bnsums ? bnsums + C : nullptr};
+  flush_cols<4, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst);
+  if (gate) {
+    const float t = block_sum(gsum, lds);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dgate, t);
+  }
+}
+
+void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
+              const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
+              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums) {
+  RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1);
+  const size_t sh = (size_t)4 * C * sizeof(float);
+#define K_(DT_, VE_, NV_) hipLaunchKernelGGL((tail_bwd_k<DT_, VE_, NV_>), dim3(g.chunks), dim3(256), sh, STREAM(ctx), dOut, Op, sc2, \
+        sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu, rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums)
+  if (C % 4 != 0 || C > 1536) { set_error("tail_bwd: C=%d must be a multiple of 4 and <= 1536", C); return; }
+  if (ctx.mode == DT_BF16) { if (C % 8 == 0) K_(DT_BF16, 8, 3); else K_(DT_BF16, 4, 6); }
+  else K_(DT_F32, 4, 6);
+#undef K_
+}
+
+// ================================================================================================
+// rowdot: out[b][n] = sum_c x[b][n][c] * w[b][c] * w2[c] + bias
+// ================================================================================================
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256) void rowdot_k(const void* x, long ld, long bs, int N, int C, const void* w, int wdt,
+                                                long w_bs, const float* w2, const float* bias, int gs, int nv, int rpc,
+                                                float* out) {
+  const int b = blockIdx.y, gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
+  float ww[MAXNV][VE];
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v) {
+    const int col = (v * gs + gl) * VE;
+    if (v < nv && col < C) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        ww[v][e] = lde_rt(w, wdt, (long)b * w_bs + col + e);
+        if (w2) ww[v][e] *= w2[col + e];
+      }
+    }
+  }
+  const float bv = bias ? *bias : 0.f;
+  for (int n = blockIdx.x * rpc + sub; n < n_end; n += rpp) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        float t[VE];
+        ldv<DT, VE>(x, (long)b * bs + (long)n * ld + col, t);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s += t[e] * ww[v][e];
+      }
+    }
+    s = group_sum(s, gs);
+    if (gl == 0) out[(long)b * N + n] = s + bv;
+  }
+}
+
+void rowdot_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const void* w, int wdt, long w_bs,
+                    const float* w2, const float* bias, float* out) {
+  int ve = row_ve(ctx, C);
+  if (ld % ve != 0 || bs % ve != 0) { set_error("rowdot_batched: unaligned ld/bs"); return; }
+  RowGeom g = row_geom(C, ve, N, B);
+  ROW_DISPATCH(ctx, C, rowdot_k, dim3(g.chunks, B), x, ld, bs, N, C, w, wdt, w_bs, w2, bias, g.gs, g.nv, g.rpc, out);
+}
+
+// ================================================================================================
+// column-strip kernels
+// ================================================================================================
+struct ColGeom { int nvr, tpr, rpp, rpc, chunks; };
+static ColGeom col_geom(int C, int VE, long rows, int B) {
+  ColGeom g;
+  g.nvr = C / VE;
+  g.tpr = imin(g.nvr, 256);
+  g.rpp = 256 / g.tpr;
+  long want = cdiv(2048, B);
+  long maxc = cdiv(rows, (long)g.rpp * 4);
+  long chunks = want < 1 ? 1 : (want > maxc ? maxc : want);
+  if (chunks < 1) chunks = 1;
+  g.rpc = (int)(cdiv(cdiv(rows, chunks), g.rpp) * g.rpp);
+  g.chunks = (int)cdiv(rows, g.rpc);
+  return g;
+}
+static inline int col_ve(const Ctx& ctx, int C) {
+  const int vmax = ctx.mode == DT_BF16 ? 8 : 4;
+  return C % vmax == 0 ? vmax : 1;
+}
+#define COL_DISPATCH(ctx, C, KERNEL, GRID, SHMEM, ...)                                                    \
+  do {                                                                                                      \
+    if ((ctx).mode == DT_BF16) {                                                                            \
+      if ((C) % 8 == 0) hipLaunchKernelGGL((KERNEL<DT_BF16, 8>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<DT_BF16, 1>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__);      \
+    } else {                                                                                                \
+      if ((C) % 4 == 0) hipLaunchKernelGGL((KERNEL<DT_F32, 4>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<DT_F32, 1>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__);       \
+    }                                                                                                       \
+  } while (0)
+
+// combine NQ per-thread channel accumulators across the row-slots of the workgroup and emit one atomic per channel
+template <int NQ, int VE>
+__device__ __forceinline__ void flush_strip(float (&acc)[NQ][VE], float* lds, int C, int col, bool active,
+                                            float* const (&dst)[NQ]) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) atomicAdd(&lds[q * C + col + e], acc[q][e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) {
+    const int q = i / C;
+    if (dst[q]) unsafeAtomicAdd(dst[q] + (i - q * C), lds[i]);
+  }
+}
+
+// ---- colsum_batched ------------------------------------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void colsum_k(const void* x, long ld, long bs, int N, int C, const float* roww,
+                                                long roww_bs, float scale, int tpr, int rpp, int rpc, float* out,
+                                                long out_bs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y, tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
+  const int nvr = C / VE;
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[1][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = 0.f;
+    if (active) {
+      for (int n = blockIdx.x * rpc + tr; n < n_end; n += rpp) {
+        float t[VE];
+        ldv<DT, VE>(x, (long)b * bs + (long)n * ld + vc * VE, t);
+        const float rw = roww ? roww[(long)b * roww_bs + n] : 1.f;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[0][e] += rw * t[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[0][e] *= scale;
+    }
+    float* const dst[1] = {out + (long)b * out_bs};
+    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
+  }
+}
+
+void colsum_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const float* roww, long roww_bs,
+                    float scale, float* out, long out_bs) {
+  int ve = col_ve(ctx, C);
+  if (ld % ve != 0 || bs % ve != 0) ve = 1;
+  ColGeom g = col_geom(C, ve, N, B);
+  const size_t sh = (size_t)C * sizeof(float);
+  if (ve == 1) {
+    if (ctx.mode == DT_BF16) hipLaunchKernelGGL((colsum_k<DT_BF16, 1>), dim3(g.chunks, B), dim3(256), sh, STREAM(ctx), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr, g.rpp, g.rpc, out, out_bs);
+    else hipLaunchKernelGGL((colsum_k<DT_F32, 1>), dim3(g.chunks, B), dim3(256), sh, STREAM(ctx), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr, g.rpp, g.rpc, out, out_bs);
+  } else {
+    COL_DISPATCH(ctx, C, colsum_k, dim3(g.chunks, B), sh, x, ld, bs, N, C, roww, roww_bs, scale, g.tpr, g.rpp, g.rpc, out, out_bs);
+  }
+}
+
+// ---- BatchNorm statistics ------------------------------------------------------------------------
+// acc[0..C) = shift (first row), acc[C..2C) += sum(x - shift), acc[2C..3C) += sum((x-shift)^2)
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void bn_stats_k(const void* x, long rows, int C, int tpr, int rpp, int rpc, float* acc3) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
+  const int nvr = C / VE;
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[2][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+      float sft[VE];
+      ldv<DT, VE>(x, (long)vc * VE, sft);            // row 0
+      if (blockIdx.x == 0 && tr == 0) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc3[vc * VE + e] = sft[e];
+      }
+      for (long r = (long)blockIdx.x * rpc + tr; r < r_end; r += rpp) {
+        float t[VE];
+        ldv<DT, VE>(x, r * C + vc * VE, t);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { const float d = t[e] - sft[e]; acc[0][e] += d; acc[1][e] += d * d; }
+      }
+    }
+    float* const dst[2] = {acc3 + C, acc3 + 2 * C};
+    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst);
+  }
+}
+
+void bn_stats(const Ctx& ctx, const void* x, long rows, int C, float* acc) {
+  ColGeom g = col_geom(C, col_ve(ctx, C), rows, 1);
+  COL_DISPATCH(ctx, C, bn_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), x, rows, C, g.tpr, g.rpp, g.rpc, acc);
+}
+
+__global__ void bn_finalize_k(const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
+                              float* run_var, float momentum, float eps, int training, float* mean, float* rstd,
+                              float* sc, float* sh) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float m, v;
+  if (training) {
+    const float s1 = acc[C + c] / rows, s2 = acc[2 * C + c] / rows;
+    m = acc[c] + s1;
+    v = fmaxf(s2 - s1 * s1, 0.f);
+    const float unb = rows > 1 ? v * ((float)rows / (float)(rows - 1)) : v;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+  } else {
+    m = run_mean[c];
+    v = run_var[c];
+  }
+  const float rs = rsqrtf(v + eps);
+  mean[c] = m;
+  rstd[c] = rs;
+  const float s = w[c] * rs;
+  sc[c] = s;
+  sh[c] = b[c] - m * s;
+}
+
+void bn_finalize(const Ctx& ctx, const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
+                 float* run_var, float momentum, float eps, int training, float* mean, float* rstd, float* sc, float* sh) {
+  hipLaunchKernelGGL(bn_finalize_k, dim3((C + 255) / 256), dim3(256), 0, STREAM(ctx), acc, rows, C, w, b, run_mean, run_var,
+                     momentum, eps, training, mean, rstd, sc, sh);
+}
+
+// ---- per-channel affine (+relu), flat elementwise ---------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long nvec, int nvr, const float* sc,
+                                                    const float* sh, int relu) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int vc = (int)(i % nvr);
+    float t[VE];
+    ldv<DT, VE>(x, i * VE, t);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      if (sc) t[e] = t[e] * sc[vc * VE + e] + sh[vc * VE + e];
+      if (relu) t[e] = fmaxf(t[e], 0.f);
+    }
+    stv<DT, VE>(y, i * VE, t);
+  }
+}
+static inline int flat_grid(long nvec) { long g = cdiv(nvec, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu) {
+  const int ve = col_ve(ctx, C);
+  const long nvec = rows * C / ve;
+  COL_DISPATCH(ctx, C, affine_act_k, dim3(flat_grid(nvec)), 0, x, y, nvec, C / ve, sc, sh, relu);
+}
+
+// ---- BatchNorm backward -----------------------------------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void* x, long rows, int C, const float* mean,
+                                                      const float* rstd, const float* sc, const float* sh, int relu,
+                                                      int tpr, int rpp, int rpc, float* sums) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
+  const int nvr = C / VE;
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[2][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+      float m[VE], rs[VE], a[VE], bsh[VE];
+      ldf<VE>(mean, vc * VE, m); ldf<VE>(rstd, vc * VE, rs); ldf<VE>(sc, vc * VE, a); ldf<VE>(sh, vc * VE, bsh);
+      for (long r = (long)blockIdx.x * rpc + tr; r < r_end; r += rpp) {
+        float g[VE], t[VE];
+        ldv<DT, VE>(dy, r * C + vc * VE, g);
+        ldv<DT, VE>(x, r * C + vc * VE, t);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          float gg = g[e];
+          if (relu && !(t[e] * a[e] + bsh[e] > 0.f)) gg = 0.f;
+          acc[0][e] += gg;
+          acc[1][e] += gg * (t[e] - m[e]) * rs[e];
+        }
+      }
+    }
+    float* const dst[2] = {sums, sums + C};
+    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst);
+  }
+}
+
+void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
+                  const float* sc, const float* sh, int relu, float* sums) {
+  ColGeom g = col_geom(C, col_ve(ctx, C), rows, 1);
+  COL_DISPATCH(ctx, C, bn_bwd_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), dy, x, rows, C, mean, rstd, sc, sh, relu,
+               g.tpr, g.rpp, g.rpc, sums);
+}
+
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const void* dy, const void* x, void* dx, long nvec, int nvr, long rows,
+                                                      const float* mean, const float* rstd, const float* sc,
+                                                      const float* sh, const float* sums, int relu, int has_bn,
+                                                      int training) {
+  const int C = nvr * VE;
+  const float inv = 1.f / (float)rows;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int vc = (int)(i % nvr);
+    float g[VE], t[VE];
+    ldv<DT, VE>(dy, i * VE, g);
+    ldv<DT, VE>(x, i * VE, t);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int c = vc * VE + e;
+      float gg = g[e];
+      if (has_bn) {
+        if (relu && !(t[e] * sc[c] + sh[c] > 0.f)) gg = 0.f;
+        if (training) gg = sc[c] * (gg - sums[c] * inv - (t[e] - mean[c]) * rstd[c] * sums[C + c] * inv);
+        else gg = sc[c] * gg;
+      } else {
+        if (relu && !(t[e] > 0.f)) gg = 0.f;
+      }
+      g[e] = gg;
+    }
+    stv<DT, VE>(dx, i * VE, g);
+  }
+}
+
+void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long rows, int C, const float* mean,
+                  const float* rstd, const float* sc, const float* sh, const float* sums, int relu, int has_bn, int training) {
+  const int ve = col_ve(ctx, C);
+  const long nvec = rows * C / ve;
+  COL_DISPATCH(ctx, C, bn_bwd_apply_k, dim3(flat_grid(nvec)), 0, dy, x, dx, nvec, C / ve, rows, mean, rstd, sc, sh, sums, relu,
+               has_bn, training);
+}
+
+// ---- scale_cols / relu_bwd_scale (flat over [B][N][C]) -----------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void scale_cols_k(const void* x, void* y, long nvec, int nvr, long vec_per_batch,
+                                                    const float* colw, float add) {
+  const int C = nvr * VE;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int vc = (int)(i % nvr);
+    const long b = i / vec_per_batch;
+    float t[VE];
+    ldv<DT, VE>(x, i * VE, t);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) t[e] *= add + colw[b * C + vc * VE + e];
+    stv<DT, VE>(y, i * VE, t);
+  }
+}
+void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* colw, float add) {
+  const int ve = col_ve(ctx, C);
+  const long nvec = (long)B * N * C / ve;
+  COL_DISPATCH(ctx, C, scale_cols_k, dim3(flat_grid(nvec)), 0, x, y, nvec, C / ve, (long)N * C / ve, colw, add);
+}
+
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, long nvec, int nvr, long vec_per_batch,
+                                                        const float* roww, const void* colw, int cdt,
+                                                        const float* colw2, float scale) {
+  const int C = nvr * VE;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int vc = (int)(i % nvr);
+    const long b = i / vec_per_batch;
+    const float rw = (roww ? roww[i / nvr] : 1.f) * scale;
+    float t[VE];
+    ldv<DT, VE>(x, i * VE, t);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int c = vc * VE + e;
+      float cw = lde_rt(colw, cdt, b * C + c);
+      if (colw2) cw *= colw2[c];
+      t[e] = t[e] > 0.f ? rw * cw : 0.f;
+    }
+    stv<DT, VE>(y, i * VE, t);
+  }
+}
+void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
+                    const float* colw2, float scale) {
+  const int ve = col_ve(ctx, C);
+  const long nvec = (long)B * N * C / ve;
+  COL_DISPATCH(ctx, C, relu_bwd_scale_k, dim3(flat_grid(nvec)), 0, x, y, nvec, C / ve, (long)N * C / ve, roww, colw, cdt, colw2,
+               scale);
+}
+
+// ---- xc_bwd: dX1 += dXc*(1+ch); dch += sum_n dXc*X1 --------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void xc_bwd_k(const void* dXc, const void* X1, void* dX1, int N, int C, const float* ch,
+                                                int tpr, int rpp, int rpc, float* dch) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y, tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
+  const int nvr = C / VE;
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[1][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = 0.f;
+    if (active) {
+      float cv[VE];
+      ldf<VE>(ch + (long)b * C, vc * VE, cv);
+      for (int n = blockIdx.x * rpc + tr; n < n_end; n += rpp) {
+        const long o = ((long)b * N + n) * C + vc * VE;
+        float g[VE], x[VE], d[VE];
+        ldv<DT, VE>(dXc, o, g);
+        ldv<DT, VE>(X1, o, x);
+        ldv<DT, VE>(dX1, o, d);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { acc[0][e] += g[e] * x[e]; d[e] += g[e] * (1.f + cv[e]); }
+        stv<DT, VE>(dX1, o, d);
+      }
+    }
+    float* const dst[1] = {dch + (long)b * C};
+    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
+  }
+}
+void xc_bwd(const Ctx& ctx, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch) {
+  ColGeom g = col_geom(C, col_ve(ctx, C), N, B);
+  COL_DISPATCH(ctx, C, xc_bwd_k, dim3(g.chunks, B), (size_t)C * sizeof(float), dXc, X1, dX1, N, C, ch, g.tpr, g.rpp, g.rpc, dch);
+}
+
+// ================================================================================================
+// softmax over rows (fp32 logits in, E/fp32 probabilities out)
+// ================================================================================================
+// short rows (L <= 64): a group of GS lanes per row
+__global__ __launch_bounds__(256) void softmax_short_k(const float* in, long ld_in, void* out, int odt, long ld_out, long rows,
+                                                       int L, int gs, int pre_tanh) {
+  const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  for (long r = (long)blockIdx.x * rpp + sub; r < rows; r += (long)gridDim.x * rpp) {
+    float x = -INFINITY;
+    if (gl < L) { x = in[r * ld_in + gl]; if (pre_tanh) x = tanhf(x); }
+    const float m = group_max(x, gs);
+    const float e = gl < L ? __expf(x - m) : 0.f;
+    const float s = group_sum(e, gs);
+    for (int c = gl; c < ld_out; c += gs) ste_rt(out, odt, r * ld_out + c, c < L ? e / s : 0.f);
+  }
+}
+// long rows: one workgroup per row, three passes (logits are L2-resident: just written by the GEMM)
+__global__ __launch_bounds__(256) void softmax_long_k(const float* in, long ld_in, void* out, int odt, long ld_out, int L,
+                                                      int pre_tanh) {
+  __shared__ float red[4];
+  const long r = blockIdx.x;
+  const float* x = in + r * ld_in;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < L; c += 256) { float v = x[c]; if (pre_tanh) v = tanhf(v); m = fmaxf(m, v); }
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < L; c += 256) { float v = x[c]; if (pre_tanh) v = tanhf(v); s += __expf(v - m); }
+  s = block_sum(s, red);
+  const float inv = 1.f / s;
+  for (int c = threadIdx.x; c < ld_out; c += 256) {
+    float o = 0.f;
+    if (c < L) { float v = x[c]; if (pre_tanh) v = tanhf(v); o = __expf(v - m) * inv; }
+    ste_rt(out, odt, r * ld_out + c, o);
+  }
+}
+static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+void softmax_rows(const Ctx& ctx, const float* in, long ld_in, void* out, int odt, long ld_out, long rows, int L, int pre_tanh) {
+  if (rows <= 0) return;
+  if (L <= 64) {
+    const int gs = imax(pow2ceil(L), 1);
+    const long nb = cdiv(rows, 256 / gs);
+    hipLaunchKernelGGL(softmax_short_k, dim3((int)(nb > 8192 ? 8192 : nb)), dim3(256), 0, STREAM(ctx), in, ld_in, out, odt, ld_out,
+                       rows, L, gs, pre_tanh);
+  } else {
+    hipLaunchKernelGGL(softmax_long_k, dim3((int)rows), dim3(256), 0, STREAM(ctx), in, ld_in, out, odt, ld_out, L, pre_tanh);
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_short_k(const void* P, int pdt, long ldp, const float* dP, long lddp, void* out,
+                                                           int odt, long ldo, long rows, int L, int gs,
+                                                           const float* scale_ptr, float* dot_accum) {
+  __shared__ float red[4];
+  const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const float sc = scale_ptr ? *scale_ptr : 1.f;
+  float dacc = 0.f;
+  for (long r = (long)blockIdx.x * rpp + sub; r < rows; r += (long)gridDim.x * rpp) {
+    float p = 0.f, g = 0.f;
+    if (gl < L) { p = lde_rt(P, pdt, r * ldp + gl); g = dP[r * lddp + gl]; }
+    const float pd = group_sum(p * g, gs);
+    if (gl == 0) dacc += pd;
+    for (int c = gl; c < ldo; c += gs) ste_rt(out, odt, r * ldo + c, c < L ? sc * p * (g - pd) : 0.f);
+  }
+  if (dot_accum) {
+    const float t = block_sum(dacc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_accum, t);
+  }
+}
+__global__ __launch_bounds__(256) void softmax_bwd_long_k(const void* P, int pdt, long ldp, const float* dP, long lddp, void* out,
+                                                          int odt, long ldo, int L, const float* scale_ptr, float* dot_accum) {
+  __shared__ float red[4];
+  const long r = blockIdx.x;
+  const float sc = scale_ptr ? *scale_ptr : 1.f;
+  float pd = 0.f;
+  for (int c = threadIdx.x; c < L; c += 256) pd += lde_rt(P, pdt, r * ldp + c) * dP[r * lddp + c];
+  pd = block_sum(pd, red);
+  for (int c = threadIdx.x; c < ldo; c += 256) {
+    float o = 0.f;
+    if (c < L) o = sc * lde_rt(P, pdt, r * ldp + c) * (dP[r * lddp + c] - pd);
+    ste_rt(out, odt, r * ldo + c, o);
+  }
+  if (dot_accum && threadIdx.x == 0) unsafeAtomicAdd(dot_accum, pd);
+}
+
+void softmax_bwd_rows(const Ctx& ctx, const void* P, long ldp, const float* dP, long lddp, void* out, int odt, long ldo,
+                      long rows, int L, const float* scale_ptr, float* dot_accum) {
+  if (rows <= 0) return;
+  const int pdt = ctx.mode;
+  if (L <= 64) {
+    const int gs = imax(pow2ceil(L), 1);
+    const long nb = cdiv(rows, 256 / gs);
+    hipLaunchKernelGGL(softmax_bwd_short_k, dim3((int)(nb > 2048 ? 2048 : nb)), dim3(256), 0, STREAM(ctx), P, pdt, ldp, dP, lddp,
+                       out, odt, ldo, rows, L, gs, scale_ptr, dot_accum);
+  } else {
+    hipLaunchKernelGGL(softmax_bwd_long_k, dim3((int)rows), dim3(256), 0, STREAM(ctx), P, pdt, ldp, dP, lddp, out, odt, ldo, L,
+                       scale_ptr, dot_accum);
+  }
+}
+
+// ================================================================================================
+// spatial gate                                                 (reference net_trans.py:604-608)
+// ================================================================================================
+__global__ __launch_bounds__(256) void spatial_fwd_k(const float* sl, int N, float* sg, float* map) {
+  __shared__ float red[4];
+  const long o = (long)blockIdx.x * N;
+  float m = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += 256) m = fmaxf(m, tanhf(sl[o + n]));
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) s += __expf(tanhf(sl[o + n]) - m);
+  s = block_sum(s, red);
+  const float inv = 1.f / s;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float v = sl[o + n];
+    sg[o + n] = sigmoidf_(v);
+    map[o + n] = __expf(tanhf(v) - m) * inv;
+  }
+}
+void spatial_fwd(const Ctx& ctx, const float* sl, int B, int N, float* sg, float* map) {
+  hipLaunchKernelGGL(spatial_fwd_k, dim3(B), dim3(256), 0, STREAM(ctx), sl, N, sg, map);
+}
+__global__ __launch_bounds__(256) void spatial_bwd_k(const float* sl, const float* sg, const float* map, const float* dsg,
+                                                     const float* dMap, int N, float* dsl, float* dbs) {
+  __shared__ float red[4];
+  const long o = (long)blockIdx.x * N;
+  float pd = 0.f;
+  if (dMap) {
+    for (int n = threadIdx.x; n < N; n += 256) pd += map[o + n] * dMap[o + n];
+    pd = block_sum(pd, red);
+  }
+  float acc = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float s = sg[o + n];
+    float d = dsg[o + n] * s * (1.f - s);
+    if (dMap) {
+      const float t = tanhf(sl[o + n]);
+      d += map[o + n] * (dMap[o + n] - pd) * (1.f - t * t);
+    }
+    dsl[o + n] = d;
+    acc += d;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(dbs, acc);
+}
+void spatial_bwd(const Ctx& ctx, const float* sl, const float* sg, const float* map, const float* dsg, const float* dMap,
+                 int B, int N, float* dsl, float* dbs) {
+  hipLaunchKernelGGL(spatial_bwd_k, dim3(B), dim3(256), 0, STREAM(ctx), sl, sg, map, dsg, dMap, N, dsl, dbs);
+}
+
+// ================================================================================================
+// small helpers
+// ================================================================================================
+__global__ void sum_batch_k(const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += in[(long)b * bs + i];
+  s *= scale;
+  out[i] = accumulate ? out[i] + s : s;
+}
+void sum_batch(const Ctx& ctx, const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
+  hipLaunchKernelGGL(sum_batch_k, dim3((int)cdiv(n, 256)), dim3(256), 0, STREAM(ctx), in, bs, B, n, out, scale, accumulate);
+}
+
+__global__ void ew_k(int op, void* o, int odt, const void* a, int adt, const void* b, int bdt, const void* c, int cdt, long n,
+                     float s, long div) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r;
+  switch (op) {
+    case EW_MUL: r = lde_rt(a, adt, i) * lde_rt(b, bdt, i); break;
+    case EW_MUL_MASK: r = lde_rt(c, cdt, i) > 0.f ? lde_rt(a, adt, i) * lde_rt(b, bdt, i) : 0.f; break;
+    case EW_SIGMOID_BWD: { const float y = lde_rt(b, bdt, i); r = lde_rt(a, adt, i) * y * (1.f - y); break; }
+    case EW_SCALE: r = s * lde_rt(a, adt, i); break;
+    case EW_ADD_BCAST: r = lde_rt(a, adt, i) + s * lde_rt(b, bdt, i / div); break;
+    case EW_MULB_MASK: r = lde_rt(c, cdt, i) > 0.f ? lde_rt(a, adt, i) * lde_rt(b, bdt, i % div) : 0.f; break;
+    case EW_OUTER_ACC: r = lde_rt(o, odt, i) + lde_rt(a, adt, i / div) * lde_rt(b, bdt, i % div); break;
+    default: r = lde_rt(a, adt, i); break;
+  }
+  ste_rt(o, odt, i, r);
+}
+void ew(const Ctx& ctx, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n, float s, long div) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(ew_k, dim3((int)cdiv(n, 256)), dim3(256), 0, STREAM(ctx), op, o, odt, a.p, a.dt, b.p, b.dt, c.p, c.dt, n, s,
+                     div < 1 ? 1 : div);
+}
+
+__global__ __launch_bounds__(64) void temporal_fwd_k(const float* a, const float* wt, const float* bt, int C, float* tg) {
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 64) s += a[(long)b * C + c] * wt[c];
+  s = group_sum(s, 64);
+  if (threadIdx.x == 0) tg[b] = sigmoidf_(s + bt[0]);
+}
+void temporal_fwd(const Ctx& ctx, const float* a, const float* wt, const float* bt, int B, int C, float* tg) {
+  hipLaunchKernelGGL(temporal_fwd_k, dim3(B), dim3(64), 0, STREAM(ctx), a, wt, bt, C, tg);
+}
+
+__global__ void cvt_k(const float* in, void* out, int odt, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ste_rt(out, odt, i, in[i]);
+}
+void cvt(const Ctx& ctx, const float* in, void* out, int odt, long n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(cvt_k, dim3(flat_grid(n)), dim3(256), 0, STREAM(ctx), in, out, odt, n);
+}
+
+__global__ __launch_bounds__(64) void rowsum_f32_k(const float* W, int C, float* out) {
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 64) s += W[(long)r * C + c];
+  s = group_sum(s, 64);
+  if (threadIdx.x == 0) out[r] = s;
+}
+void rowsum_f32(const Ctx& ctx, const float* W, int R, int C, float* out) {
+  hipLaunchKernelGGL(rowsum_f32_k, dim3(R), dim3(64), 0, STREAM(ctx), W, C, out);
+}
+
+}  // namespace dgsct

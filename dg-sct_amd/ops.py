@@ -1,0 +1,186 @@
+"""Functional layer over the C ABI: buffer ownership (torch allocates, the library only borrows),
+stream selection, and the autograd.Function that replaces the reference's ~45-op autograd graph
+(DG-SCT/AVE/nets/net_trans.py:552-674) by one forward and one backward library call."""
+from __future__ import annotations
+
+import dataclasses
+import threading
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AdapterDesc, Lib, P_COUNT, P_INDEX, PARAM_NAMES
+
+
+@dataclasses.dataclass(frozen=True)
+class AdapterSpec:
+    """Static description of one adapter (everything in dgsct_adapter_desc except BT/dtype/training)."""
+    N: int
+    C: int
+    No: int
+    Co: int
+    tk: int = 32
+    r: int = 8
+    g: int = 2
+    use_bn: bool = True
+    use_gate: bool = True
+    ln_before: bool = True
+    ln_post: bool = True
+    gate_before_ln_post: bool = False
+    remap: str = "conv"          # "conv" | "bicubic"
+    alpha: float = 0.3
+    beta: float = 0.05
+    gamma: float = 0.0
+    temporal: bool = False
+    T: int = 10
+    eps: float = 1e-5
+    bn_momentum: float = 0.1
+
+    def desc(self, BT: int, dtype: torch.dtype, training: bool) -> AdapterDesc:
+        d = AdapterDesc()
+        d.BT, d.T, d.N, d.C, d.No, d.Co, d.tk, d.r, d.g = BT, self.T, self.N, self.C, self.No, self.Co, self.tk, self.r, self.g
+        d.dtype = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+        d.remap = _lib.REMAP_CONV if self.remap == "conv" else _lib.REMAP_FIXED
+        d.use_bn, d.use_gate, d.ln_before, d.ln_post = int(self.use_bn), int(self.use_gate), int(self.ln_before), int(self.ln_post)
+        d.gate_before_ln_post, d.temporal, d.training = int(self.gate_before_ln_post), int(self.temporal), int(training)
+        d.alpha, d.beta, d.gamma, d.eps, d.bn_momentum = self.alpha, self.beta, self.gamma, self.eps, self.bn_momentum
+        return d
+
+
+# ---------------------------------------------------------------------------------------------
+# scratch: one growing buffer per (device, stream); calls on a stream serialise, so sharing is safe.
+_WS: Dict[Tuple, torch.Tensor] = {}
+_WS_LOCK = threading.Lock()
+
+
+def _stream_of(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def _workspace(device: torch.device, stream: int, nbytes: int) -> torch.Tensor:
+    key = (device.type, device.index, stream)
+    with _WS_LOCK:
+        buf = _WS.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.0) + 256, dtype=torch.uint8, device=device)
+            _WS[key] = buf
+    return buf
+
+
+def release_workspaces():
+    with _WS_LOCK:
+        _WS.clear()
+
+
+def _ptrs(params: List[Optional[torch.Tensor]]):
+    return Lib.ptr_table([p.data_ptr() if p is not None else None for p in params])
+
+
+def check_param(name: str, p: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    if p is None:
+        return None
+    if p.dtype != torch.float32 or not p.is_contiguous() or p.device != device:
+        raise RuntimeError(f"dg-sct_amd: parameter {name} must be a contiguous fp32 tensor on {device}")
+    return p
+
+
+def prepare(lib: Lib, spec: AdapterSpec, params: List[Optional[torch.Tensor]], dtype: torch.dtype, device) -> torch.Tensor:
+    """fp32 master parameters -> MFMA-operand copies + derived bias vectors (dgsct_prepare)."""
+    d = spec.desc(spec.T, dtype, False)
+    sz = lib.query(d)
+    prep = torch.empty(max(int(sz.prep_bytes), 256), dtype=torch.uint8, device=device)
+    some = next(p for p in params if p is not None)
+    lib.prepare(d, _ptrs(params), prep.data_ptr(), _stream_of(some))
+    return prep
+
+
+def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: torch.Tensor, training: bool):
+    """X [BT,N,C], Y [BT,No,Co] contiguous, same dtype (fp32|bf16).  Returns (out, map, tmap, saved, desc)."""
+    BT = X.shape[0]
+    if X.shape != (BT, spec.N, spec.C) or Y.shape != (BT, spec.No, spec.Co):
+        raise RuntimeError(f"dg-sct_amd: expected X [BT,{spec.N},{spec.C}] and Y [BT,{spec.No},{spec.Co}], got "
+                           f"{tuple(X.shape)} and {tuple(Y.shape)}")
+    if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("dg-sct_amd: X and Y must both be float32 or both bfloat16")
+    d = spec.desc(BT, X.dtype, training)
+    sz = lib.query(d)
+    dev = X.device
+    out = torch.empty_like(X)
+    amap = torch.empty(BT, spec.N, dtype=torch.float32, device=dev)
+    tmap = torch.empty(BT, dtype=torch.float32, device=dev) if spec.temporal else None
+    saved = torch.empty(int(sz.saved_bytes), dtype=torch.uint8, device=dev)
+    stream = _stream_of(X)
+    ws = _workspace(dev, stream, int(sz.ws_fwd_bytes))
+    lib.forward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), out.data_ptr(), amap.data_ptr(),
+                tmap.data_ptr() if tmap is not None else None, saved.data_ptr(), ws.data_ptr(), stream)
+    return out, amap, tmap, saved, d
+
+
+def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y, saved, dOut, dMap, dTmap):
+    sz = lib.query(d)
+    dev = X.device
+    dX = torch.empty_like(X)
+    dY = torch.empty_like(Y)
+    grads = torch.empty(int(sz.grad_floats), dtype=torch.float32, device=dev)
+    stream = _stream_of(X)
+    ws = _workspace(dev, stream, int(sz.ws_bwd_bytes))
+    lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
+                 dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
+                 dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream)
+    per_param: List[Optional[torch.Tensor]] = []
+    for i in range(P_COUNT):
+        off, n = int(sz.grad_offset[i]), int(sz.grad_numel[i])
+        per_param.append(grads[off:off + n] if off >= 0 else None)
+    return dX, dY, per_param
+
+
+class _AdapterFn(torch.autograd.Function):
+    """forward(X, Y, *params) -> (out, map[, tmap]); one library call each way."""
+
+    @staticmethod
+    def forward(ctx, lib, spec, training, prep, X, Y, *params):
+        plist = list(params)
+        out, amap, tmap, saved, d = raw_forward(lib, spec, plist, prep, X, Y, training)
+        ctx.lib, ctx.spec, ctx.desc, ctx.prep = lib, spec, d, prep
+        ctx.saved_buf = saved
+        ctx.save_for_backward(X, Y, *[p for p in plist if p is not None])
+        ctx.present = [p is not None for p in plist]
+        ctx.shapes = [tuple(p.shape) if p is not None else None for p in plist]
+        ctx.mark_non_differentiable()
+        if tmap is None:
+            tmap = torch.empty(0, device=X.device)
+        return out, amap, tmap
+
+    @staticmethod
+    def backward(ctx, dOut, dMap, dTmap):
+        if ctx.saved_buf is None:
+            raise RuntimeError("dg-sct_amd: backward through an adapter call twice is not supported "
+                               "(the saved-activation buffer is consumed in place)")
+        tensors = ctx.saved_tensors
+        X, Y = tensors[0], tensors[1]
+        it = iter(tensors[2:])
+        plist = [next(it) if pres else None for pres in ctx.present]
+        spec = ctx.spec
+        dOut = dOut.contiguous()
+        if dOut.dtype != X.dtype:
+            dOut = dOut.to(X.dtype)
+        dMap = dMap.contiguous().float() if dMap is not None else None
+        dTm = dTmap.contiguous().float() if (spec.temporal and dTmap is not None and dTmap.numel()) else None
+        dX, dY, grads = raw_backward(ctx.lib, spec, ctx.desc, plist, ctx.prep, X, Y, ctx.saved_buf, dOut, dMap, dTm)
+        ctx.saved_buf = None
+        pg = []
+        for i, g in enumerate(grads):
+            if not ctx.present[i]:
+                pg.append(None)
+            elif g is None:
+                pg.append(None)
+            else:
+                pg.append(g.view(ctx.shapes[i]))
+        return (None, None, None, None, dX, dY, *pg)
+
+
+def adapter_apply(lib: Lib, spec: AdapterSpec, training: bool, prep: torch.Tensor, X: torch.Tensor, Y: torch.Tensor,
+                  params: List[Optional[torch.Tensor]]):
+    out, amap, tmap = _AdapterFn.apply(lib, spec, training, prep, X, Y, *params)
+    return out, amap, (tmap if spec.temporal else None)

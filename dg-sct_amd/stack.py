@@ -1,0 +1,106 @@
+"""The adapter call schedule of the AVE model (reference ``MMIL_Net``,
+``DG-SCT/AVE/nets/net_trans.py``: per-layer dims ``:775-797``, the four ``ModuleList``s ``:807-845``,
+the interleaving loop ``:880-916``), with the frozen Swin-V2 / HTS-AT blocks as pluggable callables
+(identity stand-ins by default: the backbones are out of scope).
+
+Used by bench.py (the graded workload) and by the identity-backbone stack fixtures.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .adapter import VisualAdapter
+
+# (adapter layers in the stage, visual tokens, audio tokens); widths per backbone below.
+# Swin-V2 @192^2, window 12: 48^2,24^2,12^2,6^2 tokens; HTS-AT spec 256, patch 4: 64^2,...,8^2 (esc_config.py:63-69).
+# Stage 2: Swin has 18 blocks, HTS-AT 6 -> adapters at every 3rd Swin block (net_trans.py:885).
+_STAGE_TOKENS = [(2, 2304, 4096), (2, 576, 1024), (6, 144, 256), (2, 36, 64)]
+_WIDTHS = {
+    "swinv2_large": [192, 384, 768, 1536],   # what the reference code builds (net_trans.py:693)
+    "swinv2_base": [128, 256, 512, 1024],    # BASELINE.json config 2
+}
+_AUDIO_WIDTHS = [96, 192, 384, 768]
+
+
+def ave_stage_shapes(backbone: str = "swinv2_base") -> List[Dict[str, int]]:
+    return [dict(layers=l, Nv=nv, Cv=cv, Na=na, Ca=ca)
+            for (l, nv, na), cv, ca in zip(_STAGE_TOKENS, _WIDTHS[backbone], _AUDIO_WIDTHS)]
+
+
+def default_opt(**over) -> SimpleNamespace:
+    """The adapter-relevant flags of DG-SCT/AVE/train.sh + base_options.py:158-178."""
+    o = dict(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=32,
+             Adapter_downsample=8, is_bn=1, is_gate=1, is_audio_adapter_p1=1, is_audio_adapter_p2=1)
+    o.update(over)
+    return SimpleNamespace(**o)
+
+
+class AdapterStack(nn.Module):
+    """4 x L adapters (audio/visual x p1/p2) in the reference's ModuleLists, plus the layer loop."""
+
+    def __init__(self, stages: Sequence[Dict[str, int]], opt: Optional[SimpleNamespace] = None, flavour: str = "ave",
+                 compute_dtype: Optional[torch.dtype] = None, lib=None):
+        super().__init__()
+        self.opt = opt or default_opt()
+        o = self.opt
+        self.stages = [dict(s) for s in stages]
+        hidden, hidden_a, conv, conv_a = [], [], [], []
+        for s in self.stages:
+            for _ in range(s["layers"]):
+                hidden.append(s["Cv"]); hidden_a.append(s["Ca"]); conv.append(s["Nv"]); conv_a.append(s["Na"])
+        kw = dict(flavour=flavour, compute_dtype=compute_dtype, lib=lib)
+        if flavour in ("ave", "avvp", "pretrain"):
+            kw["num_tk"] = o.num_tokens
+
+        def audio(i):
+            return VisualAdapter(input_dim=hidden_a[i], output_dim=hidden_a[i], adapter_kind="bottleneck", dim_list=hidden_a,
+                                 layer_idx=i, reduction_factor=o.Adapter_downsample, opt=o, use_bn=o.is_bn, use_gate=o.is_gate,
+                                 conv_dim_in=conv[i], conv_dim_out=conv_a[i], linear_in=hidden[i], linear_out=hidden_a[i], **kw)
+
+        def visual(i):
+            return VisualAdapter(input_dim=hidden[i], output_dim=hidden[i], adapter_kind="bottleneck", dim_list=hidden,
+                                 layer_idx=i, reduction_factor=o.Adapter_downsample, opt=o, use_bn=o.is_bn, use_gate=True,
+                                 conv_dim_in=conv_a[i], conv_dim_out=conv[i], linear_in=hidden_a[i], linear_out=hidden[i], **kw)
+
+        n = len(hidden)
+        self.audio_adapter_blocks_p1 = nn.ModuleList([audio(i) for i in range(n)])
+        self.vis_adapter_blocks_p1 = nn.ModuleList([visual(i) for i in range(n)])
+        self.audio_adapter_blocks_p2 = nn.ModuleList([audio(i) for i in range(n)])
+        self.vis_adapter_blocks_p2 = nn.ModuleList([visual(i) for i in range(n)])
+
+    @staticmethod
+    def _view(f: torch.Tensor) -> torch.Tensor:
+        return f.permute(0, 2, 1).unsqueeze(-1)          # the reference's [BT,C,N,1] view of a token-major map
+
+    def forward(self, feats: Sequence[Tuple[torch.Tensor, torch.Tensor]],
+                vis_block: Optional[Callable] = None, aud_block: Optional[Callable] = None):
+        """feats[s] = (f_v [BT,Nv,Cv], f_a [BT,Na,Ca]) entering stage s.  ``vis_block(layer, half, f_v)`` /
+        ``aud_block(layer, f_a)`` return the frozen residual branches (None = identity stand-in).
+        Returns ([(f_v, f_a) leaving each stage], (map_v, map_a) of the last p2 adapters)."""
+        outs = []
+        idx = 0
+        maps = (None, None)
+        for s, (f_v, f_a) in zip(self.stages, feats):
+            for _ in range(s["layers"]):
+                a_res, _ = self.audio_adapter_blocks_p1[idx](self._view(f_a), self._view(f_v))[:2]
+                v_res, _ = self.vis_adapter_blocks_p1[idx](self._view(f_v), self._view(f_a))[:2]
+                if vis_block is not None:
+                    f_v = f_v + vis_block(idx, 0, f_v)
+                f_v = f_v + v_res.squeeze(-1).permute(0, 2, 1)
+                if aud_block is not None:
+                    f_a = aud_block(idx, f_a)
+                f_a = f_a + a_res.squeeze(-1).permute(0, 2, 1)
+                a_res, a_map = self.audio_adapter_blocks_p2[idx](self._view(f_a), self._view(f_v))[:2]
+                v_res, v_map = self.vis_adapter_blocks_p2[idx](self._view(f_v), self._view(f_a))[:2]
+                if vis_block is not None:
+                    f_v = f_v + vis_block(idx, 1, f_v)
+                f_v = f_v + v_res.squeeze(-1).permute(0, 2, 1)
+                f_a = f_a + a_res.squeeze(-1).permute(0, 2, 1)
+                maps = (v_map, a_map)
+                idx += 1
+            outs.append((f_v, f_a))
+        return outs, maps

@@ -1,0 +1,148 @@
+/* dgsct.h -- C ABI of libdgsct.so: the MI355X (gfx950) DG-SCT cross-modal adapter path.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own -- the hot path is the
+ * Python method `VisualAdapter.forward(x, vis_token) -> (output, spatial_att_maps)`
+ * (reference DG-SCT/AVE/nets/net_trans.py:552-674; ctor :437-550) and its autograd backward.
+ * These entry points are what a ctypes/cffi binding of that method binds (INTEGRATION.md shows it):
+ *
+ *   dgsct_query            sizes of every caller-owned buffer + gradient layout     (ctor-time)
+ *   dgsct_prepare          fp32 master parameters -> MFMA-operand copies + derived bias vectors
+ *   dgsct_adapter_forward  replaces VisualAdapter.forward            net_trans.py:552-674
+ *   dgsct_adapter_backward replaces autograd of the same graph       (a-9 in SURVEY.md 8a)
+ *
+ * Rules of the boundary
+ *   - plain C: pointers + sizes only, no torch types; every pointer is a DEVICE pointer owned by the
+ *     caller (PyTorch's caching allocator); the library never allocates, frees or keeps device memory;
+ *   - every call is asynchronous on `stream` (a hipStream_t) and re-entrant (no global mutable state),
+ *     so it is safe under nn.DataParallel's per-replica threads (reference AVS/AVQA call sites);
+ *   - every call returns 0 on success; on failure a non-zero code and dgsct_last_error() (thread
+ *     local) describes it -- the Python wrapper raises RuntimeError, mirroring the reference's
+ *     exception-only error behaviour (NotImplementedError for unsupported adapter kinds, :549-550);
+ *   - tensors are token-major: X [BT][N][C], Y [BT][No][Co], i.e. the memory the reference's
+ *     `f.permute(0,2,1).unsqueeze(-1)` views alias (net_trans.py:891-892), element type = desc.dtype.
+ */
+#ifndef DGSCT_H
+#define DGSCT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGSCT_VERSION 100
+enum { DGSCT_F32 = 0, DGSCT_BF16 = 1 };
+enum { DGSCT_REMAP_CONV = 0,    /* conv_adapter (token axis) + fc           net_trans.py:553-554        */
+       DGSCT_REMAP_FIXED = 1 }; /* fc + fixed token operator (AVS-S4 bicubic resize, PVT_AVSModel.py:190-197);
+                                   params[DGSCT_P_WN] is then the dense [N][No] operator, it gets no gradient */
+
+/* Parameter table: fp32 master pointers in this order (reference state_dict names in comments,
+ * net_trans.py:444-515).  Unused entries may be NULL. */
+enum {
+  DGSCT_P_GATE = 0,   /* gate [1]                         (NULL when use_gate == 0)             */
+  DGSCT_P_TOKENS,     /* my_tokens [tk][C]                                                      */
+  DGSCT_P_GATE_AV,    /* gate_av [1]                                                            */
+  DGSCT_P_WN,         /* conv_adapter.weight [N][No]      (or the fixed remap operator)         */
+  DGSCT_P_BN,         /* conv_adapter.bias [N]            (NULL for DGSCT_REMAP_FIXED)          */
+  DGSCT_P_WC,         /* fc.weight [C][Co]                                                      */
+  DGSCT_P_BC,         /* fc.bias [C]                                                            */
+  DGSCT_P_WA1,        /* fc_affine_audio_1.weight [C][C]                                        */
+  DGSCT_P_BA1,        /* fc_affine_audio_1.bias [C]                                             */
+  DGSCT_P_WV1,        /* fc_affine_video_1.weight [C][C]                                        */
+  DGSCT_P_BV1,        /* fc_affine_video_1.bias [C]                                             */
+  DGSCT_P_WB,         /* fc_affine_bottleneck.weight [C/2][C]                                   */
+  DGSCT_P_BB,         /* fc_affine_bottleneck.bias [C/2]                                        */
+  DGSCT_P_WV2,        /* fc_affine_video_2.weight [C/2][C]                                      */
+  DGSCT_P_BV2,        /* fc_affine_video_2.bias [C/2]                                           */
+  DGSCT_P_WA2,        /* fc_affine_audio_2.weight [C/2][C]                                      */
+  DGSCT_P_BA2,        /* fc_affine_audio_2.bias [C/2]                                           */
+  DGSCT_P_WS,         /* fc_affine_v_s_att.weight [1][C/2]                                      */
+  DGSCT_P_BS,         /* fc_affine_v_s_att.bias [1]                                             */
+  DGSCT_P_WCATT,      /* fc_affine_v_c_att.weight [C][C/2]                                      */
+  DGSCT_P_BCATT,      /* fc_affine_v_c_att.bias [C]                                             */
+  DGSCT_P_WD,         /* down_sampler.weight [C/r][C/g]                                         */
+  DGSCT_P_WU,         /* up_sampler.weight [C][C/r/g]                                           */
+  DGSCT_P_BN1_W, DGSCT_P_BN1_B, DGSCT_P_BN1_RM, DGSCT_P_BN1_RV,   /* bn1.{weight,bias,running_mean,running_var} [C/r] */
+  DGSCT_P_BN2_W, DGSCT_P_BN2_B, DGSCT_P_BN2_RM, DGSCT_P_BN2_RV,   /* bn2.* [C]                  */
+  DGSCT_P_LNB_W, DGSCT_P_LNB_B,                                   /* ln_before.{weight,bias} [C]  */
+  DGSCT_P_LNP_W, DGSCT_P_LNP_B,                                   /* ln_post.{weight,bias} [C]    */
+  DGSCT_P_WT, DGSCT_P_BT,       /* temporal_gated.0.{weight [1][C], bias [1]}  (pretrain/few/zero-shot flavour) */
+  DGSCT_P_COUNT
+};
+
+typedef struct dgsct_adapter_desc {
+  int32_t BT;        /* frames = B*T, T fastest ('(b t)' flattening, net_trans.py:854)            */
+  int32_t T;         /* frames per clip (10; 5 for AVS) -- only checked (BT % T == 0)             */
+  int32_t N, C;      /* own modality: tokens, width   (conv_dim_out, input_dim == linear_out)     */
+  int32_t No, Co;    /* other modality: tokens, width (conv_dim_in, linear_in)                    */
+  int32_t tk;        /* latent tokens (num_tk / opt.num_tokens)                                   */
+  int32_t r, g;      /* reduction_factor (opt.Adapter_downsample), opt.num_conv_group             */
+  int32_t dtype;     /* DGSCT_F32 | DGSCT_BF16: activation storage + MFMA operand type            */
+  int32_t remap;     /* DGSCT_REMAP_*                                                             */
+  int32_t use_bn, use_gate, ln_before, ln_post;
+  int32_t gate_before_ln_post;   /* AVS-S4/MS3 order (PVT_AVSModel.py:308-313)                    */
+  int32_t temporal;  /* + gamma*sigmoid(temporal_gated(a)) in the modulation; returns tmap        */
+  int32_t training;  /* BatchNorm: batch statistics + running-stat update (1) or running stats (0) */
+  float alpha, beta, gamma;      /* modulation weights (0.3, 0.05, 0 for AVE; net_trans.py:611)   */
+  float eps, bn_momentum;        /* 1e-5, 0.1                                                     */
+} dgsct_adapter_desc;
+
+typedef struct dgsct_sizes {
+  int64_t prep_bytes;     /* dgsct_prepare output                                                  */
+  int64_t saved_bytes;    /* activations kept from forward to backward (one per adapter call)      */
+  int64_t ws_fwd_bytes;   /* forward scratch (reusable across adapters on one stream)              */
+  int64_t ws_bwd_bytes;   /* backward scratch                                                      */
+  int64_t grad_floats;    /* length of the flat fp32 gradient buffer                               */
+  int64_t grad_offset[DGSCT_P_COUNT];   /* float offset of each parameter's gradient, -1 = no gradient */
+  int64_t grad_numel[DGSCT_P_COUNT];
+} dgsct_sizes;
+
+int dgsct_version(void);
+const char* dgsct_arch(void);            /* "gfx950" */
+const char* dgsct_last_error(void);      /* thread-local, valid until the next failing call on this thread */
+
+int dgsct_query(const dgsct_adapter_desc* desc, dgsct_sizes* out);
+
+/* params[DGSCT_P_COUNT]: fp32 device pointers.  Writes `prep` (prep_bytes).  Must be re-run whenever a
+ * parameter changed (after every optimizer step); cheap (one pass over the weights). */
+int dgsct_prepare(const dgsct_adapter_desc* desc, float* const* params, void* prep, void* stream);
+
+/* out [BT][N][C] (dtype), map [BT][N] fp32 (softmax over N: the 2nd return value of the reference),
+ * tmap [BT] fp32 or NULL.  When desc.training and use_bn, bn running stats in params[] are updated
+ * in place (num_batches_tracked is the caller's). */
+int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, const void* prep,
+                          const void* X, const void* Y, void* out, float* map, float* tmap,
+                          void* saved, void* ws, void* stream);
+
+/* dOut [BT][N][C] (dtype); dMap [BT][N] fp32 or NULL; dTmap [BT] fp32 or NULL.
+ * Writes dX [BT][N][C], dY [BT][No][Co] (dtype) and the flat fp32 gradient buffer `grads`
+ * (grad_floats; overwritten, not accumulated). */
+int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params, const void* prep,
+                           const void* X, const void* Y, const void* saved,
+                           const void* dOut, const float* dMap, const float* dTmap,
+                           void* dX, void* dY, float* grads, void* ws, void* stream);
+
+/* ---- introspection / test hooks (used by tests/ only) ------------------------------------------ */
+/* i-th named region of the `saved` buffer; returns 0 and fills name/offset/bytes, or 1 past the end. */
+int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes);
+
+/* One GEMM of the engine (see csrc/prims.h: struct Gemm).  Plain-C mirror for unit tests. */
+typedef struct dgsct_gemm_args {
+  int32_t mode;           /* DGSCT_F32 | DGSCT_BF16 */
+  int32_t M, N, K, KB, batch, splitk, atomic;
+  const void* A; int64_t lda; int32_t a_kmajor; int64_t a_bs, a_kbs;
+  const void* B; int64_t ldb; int32_t b_kmajor; int64_t b_bs, b_kbs;
+  void* D; int32_t ddt; int64_t ldd, dbs;
+  float alpha; const float* alpha_ptr;
+  const float* bias_m; const float* bias_n; int64_t bias_n_bs; int32_t m_mod;
+  const float* r1_m; const float* r1_n;
+  int32_t act;
+  const void* R; int32_t rdt; int64_t ldr, rbs; float beta;
+  const void* mask; int64_t ldmask, maskbs;
+} dgsct_gemm_args;
+int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGSCT_H */

@@ -1,0 +1,385 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into libdgsct.so, never loaded by the product package.
+//
+// Plain host-loop implementation of csrc/prims.h.  tests/emu builds csrc/plan.cpp + csrc/capi.cpp
+// against THIS file (g++, no HIP) into tests/emu/libdgsct_emu.so so that the kernel SCHEDULE
+// (plan.cpp: operand roles, strides, offsets, gradient layout) can be checked against the oracle in
+// the CPU-only build container.  The gfx950 kernels themselves are checked on the GPU against torch.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../dg-sct_amd/csrc/prims.h"
+
+namespace dgsct {
+
+static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+static inline uint16_t f2bf(float f) {
+  uint32_t u; std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float ld(const void* p, int dt, long i) { return dt == DT_F32 ? ((const float*)p)[i] : bf2f(((const uint16_t*)p)[i]); }
+static inline void st(void* p, int dt, long i, float v) { if (dt == DT_F32) ((float*)p)[i] = v; else ((uint16_t*)p)[i] = f2bf(v); }
+static inline float sigm(float x) { return 1.f / (1.f + std::exp(-x)); }
+
+void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
+
+void gemm(const Ctx& ctx, const Gemm& g) {
+  const int E = ctx.mode;
+  const float alpha = g.alpha * (g.alpha_ptr ? *g.alpha_ptr : 1.f);
+  for (int b = 0; b < g.batch; ++b)
+    for (int m = 0; m < g.M; ++m)
+      for (int n = 0; n < g.N; ++n) {
+        double acc = 0;
+        for (int kb = 0; kb < g.KB; ++kb)
+          for (int k = 0; k < g.K; ++k) {
+            const long ao = (long)b * g.A.bs + (long)kb * g.A.kbs + (g.A.kmajor ? (long)m * g.A.ld + k : (long)k * g.A.ld + m);
+            const long bo = (long)b * g.B.bs + (long)kb * g.B.kbs + (g.B.kmajor ? (long)n * g.B.ld + k : (long)k * g.B.ld + n);
+            acc += (double)ld(g.A.p, E, ao) * (double)ld(g.B.p, E, bo);
+          }
+        float v = alpha * (float)acc;
+        const int mm = g.m_mod > 0 ? m % g.m_mod : m;
+        if (g.bias_m) v += g.bias_m[mm];
+        if (g.bias_n) v += g.bias_n[(long)b * g.bias_n_bs + n];
+        if (g.r1_m) v += g.r1_m[mm] * g.r1_n[n];
+        if (g.act == ACT_RELU) v = std::max(v, 0.f);
+        else if (g.act == ACT_SIGMOID) v = sigm(v);
+        if (g.mask && !(ld(g.mask, E, (long)b * g.maskbs + (long)m * g.ldmask + n) > 0.f)) v = 0.f;
+        if (g.R) v += g.beta * ld(g.R, g.rdt, (long)b * g.rbs + (long)m * g.ldr + n);
+        const long o = (long)b * g.dbs + (long)m * g.ldd + n;
+        if (g.atomic) ((float*)g.D)[o] += v;
+        else st(g.D, g.ddt, o, v);
+      }
+}
+
+void softmax_rows(const Ctx&, const float* in, long ld_in, void* out, int odt, long ld_out, long rows, int L, int pre_tanh) {
+  for (long r = 0; r < rows; ++r) {
+    float m = -INFINITY;
+    for (int c = 0; c < L; ++c) { float v = in[r * ld_in + c]; if (pre_tanh) v = std::tanh(v); m = std::max(m, v); }
+    double s = 0;
+    for (int c = 0; c < L; ++c) { float v = in[r * ld_in + c]; if (pre_tanh) v = std::tanh(v); s += std::exp(v - m); }
+    for (long c = 0; c < ld_out; ++c) {
+      float o = 0.f;
+      if (c < L) { float v = in[r * ld_in + c]; if (pre_tanh) v = std::tanh(v); o = (float)(std::exp(v - m) / s); }
+      st(out, odt, r * ld_out + c, o);
+    }
+  }
+}
+
+void softmax_bwd_rows(const Ctx& ctx, const void* P, long ldp, const float* dP, long lddp, void* out, int odt, long ldo,
+                      long rows, int L, const float* scale_ptr, float* dot_accum) {
+  const float sc = scale_ptr ? *scale_ptr : 1.f;
+  double tot = 0;
+  for (long r = 0; r < rows; ++r) {
+    double pd = 0;
+    for (int c = 0; c < L; ++c) pd += (double)ld(P, ctx.mode, r * ldp + c) * dP[r * lddp + c];
+    tot += pd;
+    for (long c = 0; c < ldo; ++c)
+      st(out, odt, r * ldo + c, c < L ? sc * ld(P, ctx.mode, r * ldp + c) * (dP[r * lddp + c] - (float)pd) : 0.f);
+  }
+  if (dot_accum) *dot_accum += (float)tot;
+}
+
+void colsum_batched(const Ctx& ctx, const void* x, long ldx, long bs, int B, int N, int C, const float* roww, long roww_bs,
+                    float scale, float* out, long out_bs) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      double s = 0;
+      for (int n = 0; n < N; ++n)
+        s += (double)(roww ? roww[(long)b * roww_bs + n] : 1.f) * ld(x, ctx.mode, (long)b * bs + (long)n * ldx + c);
+      out[(long)b * out_bs + c] += scale * (float)s;
+    }
+}
+
+void rowdot_batched(const Ctx& ctx, const void* x, long ldx, long bs, int B, int N, int C, const void* w, int wdt, long w_bs,
+                    const float* w2, const float* bias, float* out) {
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      double s = 0;
+      for (int c = 0; c < C; ++c)
+        s += (double)ld(x, ctx.mode, (long)b * bs + (long)n * ldx + c) * ld(w, wdt, (long)b * w_bs + c) * (w2 ? w2[c] : 1.f);
+      out[(long)b * N + n] = (float)s + (bias ? *bias : 0.f);
+    }
+}
+
+void sum_batch(const Ctx&, const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
+  for (long i = 0; i < n; ++i) {
+    double s = 0;
+    for (int b = 0; b < B; ++b) s += in[(long)b * bs + i];
+    out[i] = (accumulate ? out[i] : 0.f) + scale * (float)s;
+  }
+}
+
+void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* colw, float add) {
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < C; ++c) {
+        const long o = ((long)b * N + n) * C + c;
+        st(y, ctx.mode, o, ld(x, ctx.mode, o) * (add + colw[(long)b * C + c]));
+      }
+}
+
+void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
+                    const float* colw2, float scale) {
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < C; ++c) {
+        const long o = ((long)b * N + n) * C + c;
+        float v = 0.f;
+        if (ld(x, ctx.mode, o) > 0.f)
+          v = (roww ? roww[(long)b * N + n] : 1.f) * scale * ld(colw, cdt, (long)b * C + c) * (colw2 ? colw2[c] : 1.f);
+        st(y, ctx.mode, o, v);
+      }
+}
+
+void xc_bwd(const Ctx& ctx, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      double s = 0;
+      for (int n = 0; n < N; ++n) {
+        const long o = ((long)b * N + n) * C + c;
+        const float g = ld(dXc, ctx.mode, o);
+        s += (double)g * ld(X1, ctx.mode, o);
+        st(dX1, ctx.mode, o, ld(dX1, ctx.mode, o) + g * (1.f + ch[(long)b * C + c]));
+      }
+      dch[(long)b * C + c] += (float)s;
+    }
+}
+
+void spatial_fwd(const Ctx&, const float* sl, int B, int N, float* sg, float* map) {
+  for (int b = 0; b < B; ++b) {
+    const float* x = sl + (long)b * N;
+    float m = -INFINITY;
+    for (int n = 0; n < N; ++n) m = std::max(m, std::tanh(x[n]));
+    double s = 0;
+    for (int n = 0; n < N; ++n) s += std::exp(std::tanh(x[n]) - m);
+    for (int n = 0; n < N; ++n) {
+      sg[(long)b * N + n] = sigm(x[n]);
+      map[(long)b * N + n] = (float)(std::exp(std::tanh(x[n]) - m) / s);
+    }
+  }
+}
+
+void spatial_bwd(const Ctx&, const float* sl, const float* sg, const float* map, const float* dsg, const float* dMap,
+                 int B, int N, float* dsl, float* dbs) {
+  double tot = 0;
+  for (int b = 0; b < B; ++b) {
+    const long o = (long)b * N;
+    double pd = 0;
+    if (dMap) for (int n = 0; n < N; ++n) pd += (double)map[o + n] * dMap[o + n];
+    for (int n = 0; n < N; ++n) {
+      const float s = sg[o + n];
+      float d = dsg[o + n] * s * (1.f - s);
+      if (dMap) { const float t = std::tanh(sl[o + n]); d += map[o + n] * (dMap[o + n] - (float)pd) * (1.f - t * t); }
+      dsl[o + n] = d;
+      tot += d;
+    }
+  }
+  *dbs += (float)tot;
+}
+
+static void ln_row(std::vector<float>& x, const float* w, const float* b, float eps, float* mu, float* rstd) {
+  const int C = (int)x.size();
+  double s = 0; for (float v : x) s += v;
+  const float mean = (float)(s / C);
+  double q = 0; for (float v : x) q += (double)(v - mean) * (v - mean);
+  const float rs = 1.f / std::sqrt((float)(q / C) + eps);
+  for (int c = 0; c < C; ++c) x[c] = (x[c] - mean) * rs * w[c] + b[c];
+  *mu = mean; *rstd = rs;
+}
+
+void modln_fwd(const Ctx& ctx, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta,
+               float gamma, const float* lnw, const float* lnb, float eps, int B, int N, int C, void* X3, float* mu, float* rstd) {
+  std::vector<float> x(C);
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      const long row = (long)b * N + n;
+      for (int c = 0; c < C; ++c)
+        x[c] = ld(X1, ctx.mode, row * C + c) * (alpha * ch[(long)b * C + c] + beta * sg[row] + (tg ? gamma * tg[b] : 0.f) + 1.f - alpha);
+      if (lnw) ln_row(x, lnw, lnb, eps, mu + row, rstd + row);
+      for (int c = 0; c < C; ++c) st(X3, ctx.mode, row * C + c, x[c]);
+    }
+}
+
+void modln_bwd(const Ctx& ctx, const void* dX3, const void* X1, const float* ch, const float* sg, const float* tg, float alpha,
+               float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N, int C,
+               void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg) {
+  std::vector<float> g(C), xh(C), md(C), x1(C);
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      const long row = (long)b * N + n;
+      double s1 = 0, s2 = 0;
+      for (int c = 0; c < C; ++c) {
+        md[c] = alpha * ch[(long)b * C + c] + beta * sg[row] + (tg ? gamma * tg[b] : 0.f) + 1.f - alpha;
+        x1[c] = ld(X1, ctx.mode, row * C + c);
+        g[c] = ld(dX3, ctx.mode, row * C + c);
+        if (lnw) {
+          xh[c] = (x1[c] * md[c] - mu[row]) * rstd[row];
+          dlnw[c] += g[c] * xh[c];
+          dlnb[c] += g[c];
+          g[c] *= lnw[c];
+          s1 += g[c]; s2 += (double)g[c] * xh[c];
+        }
+      }
+      double rsum = 0;
+      for (int c = 0; c < C; ++c) {
+        const float dx2 = lnw ? rstd[row] * (g[c] - (float)(s1 / C) - xh[c] * (float)(s2 / C)) : g[c];
+        const float dm = dx2 * x1[c];
+        dch[(long)b * C + c] += alpha * dm;
+        rsum += dm;
+        st(dX1, ctx.mode, row * C + c, dx2 * md[c]);
+      }
+      dsg[row] = beta * (float)rsum;
+      if (tg && dtg) dtg[b] += gamma * (float)rsum;
+    }
+}
+
+void bn_stats(const Ctx& ctx, const void* x, long rows, int C, float* acc) {
+  for (int c = 0; c < C; ++c) {
+    const float sft = ld(x, ctx.mode, c);
+    double s1 = 0, s2 = 0;
+    for (long r = 0; r < rows; ++r) { const double d = ld(x, ctx.mode, r * C + c) - sft; s1 += d; s2 += d * d; }
+    acc[c] = sft; acc[C + c] += (float)s1; acc[2 * C + c] += (float)s2;
+  }
+}
+
+void bn_finalize(const Ctx&, const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
+                 float* run_var, float momentum, float eps, int training, float* mean, float* rstd, float* sc, float* sh) {
+  for (int c = 0; c < C; ++c) {
+    float m, v;
+    if (training) {
+      const float s1 = acc[C + c] / rows, s2 = acc[2 * C + c] / rows;
+      m = acc[c] + s1;
+      v = std::max(s2 - s1 * s1, 0.f);
+      const float unb = rows > 1 ? v * ((float)rows / (float)(rows - 1)) : v;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+    } else { m = run_mean[c]; v = run_var[c]; }
+    const float rs = 1.f / std::sqrt(v + eps);
+    mean[c] = m; rstd[c] = rs; sc[c] = w[c] * rs; sh[c] = b[c] - m * sc[c];
+  }
+}
+
+void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu) {
+  for (long r = 0; r < rows; ++r)
+    for (int c = 0; c < C; ++c) {
+      float v = ld(x, ctx.mode, r * C + c);
+      if (sc) v = v * sc[c] + sh[c];
+      if (relu) v = std::max(v, 0.f);
+      st(y, ctx.mode, r * C + c, v);
+    }
+}
+
+void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
+                  const float* sc, const float* sh, int relu, float* sums) {
+  for (int c = 0; c < C; ++c) {
+    double s0 = 0, s1 = 0;
+    for (long r = 0; r < rows; ++r) {
+      const float t = ld(x, ctx.mode, r * C + c);
+      float g = ld(dy, ctx.mode, r * C + c);
+      if (relu && !(t * sc[c] + sh[c] > 0.f)) g = 0.f;
+      s0 += g; s1 += (double)g * (t - mean[c]) * rstd[c];
+    }
+    sums[c] += (float)s0; sums[C + c] += (float)s1;
+  }
+}
+
+void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long rows, int C, const float* mean,
+                  const float* rstd, const float* sc, const float* sh, const float* sums, int relu, int has_bn, int training) {
+  for (long r = 0; r < rows; ++r)
+    for (int c = 0; c < C; ++c) {
+      const float t = ld(x, ctx.mode, r * C + c);
+      float g = ld(dy, ctx.mode, r * C + c);
+      if (has_bn) {
+        if (relu && !(t * sc[c] + sh[c] > 0.f)) g = 0.f;
+        if (training) g = sc[c] * (g - sums[c] / rows - (t - mean[c]) * rstd[c] * sums[C + c] / rows);
+        else g = sc[c] * g;
+      } else if (relu && !(t > 0.f)) g = 0.f;
+      st(dx, ctx.mode, r * C + c, g);
+    }
+}
+
+void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
+              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd) {
+  std::vector<float> x(C);
+  const float gv = gate ? *gate : 1.f;
+  for (long r = 0; r < rows; ++r) {
+    for (int c = 0; c < C; ++c) {
+      float v = ld(Op, ctx.mode, r * C + c);
+      if (sc2) v = v * sc2[c] + sh2[c];
+      if (gate_first) v *= gv;
+      x[c] = v;
+    }
+    if (lnw) ln_row(x, lnw, lnb, eps, mu + r, rstd + r);
+    for (int c = 0; c < C; ++c) st(out, ctx.mode, r * C + c, gate_first ? x[c] : x[c] * gv);
+  }
+}
+
+void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
+              const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
+              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums) {
+  std::vector<float> g(C), o(C), xh(C), op(C);
+  const float gv = gate ? *gate : 1.f;
+  double gsum = 0;
+  for (long r = 0; r < rows; ++r) {
+    double s1 = 0, s2 = 0;
+    for (int c = 0; c < C; ++c) {
+      op[c] = ld(Op, ctx.mode, r * C + c);
+      o[c] = sc2 ? op[c] * sc2[c] + sh2[c] : op[c];
+      g[c] = ld(dOut, ctx.mode, r * C + c);
+      if (gate_first) {
+        if (lnw) { xh[c] = (o[c] * gv - mu[r]) * rstd[r]; dlnw[c] += g[c] * xh[c]; dlnb[c] += g[c]; g[c] *= lnw[c]; s1 += g[c]; s2 += (double)g[c] * xh[c]; }
+      } else {
+        float L;
+        if (lnw) { xh[c] = (o[c] - mu[r]) * rstd[r]; L = xh[c] * lnw[c] + lnb[c]; } else L = o[c];
+        if (gate) gsum += (double)g[c] * L;
+        g[c] *= gv;
+        if (lnw) { dlnw[c] += g[c] * xh[c]; dlnb[c] += g[c]; g[c] *= lnw[c]; s1 += g[c]; s2 += (double)g[c] * xh[c]; }
+      }
+    }
+    for (int c = 0; c < C; ++c) {
+      float t = lnw ? rstd[r] * (g[c] - (float)(s1 / C) - xh[c] * (float)(s2 / C)) : g[c];
+      if (gate_first) { if (gate) gsum += (double)t * o[c]; t *= gv; }
+      st(dO, ctx.mode, r * C + c, t);
+      if (sc2 && bnsums) { bnsums[c] += t; bnsums[C + c] += t * (op[c] - mean2[c]) * rstd2[c]; }
+    }
+  }
+  if (gate) *dgate += (float)gsum;
+}
+
+void ew(const Ctx&, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n, float s, long div) {
+  if (div < 1) div = 1;
+  for (long i = 0; i < n; ++i) {
+    float r;
+    switch (op) {
+      case EW_MUL: r = ld(a.p, a.dt, i) * ld(b.p, b.dt, i); break;
+      case EW_MUL_MASK: r = ld(c.p, c.dt, i) > 0.f ? ld(a.p, a.dt, i) * ld(b.p, b.dt, i) : 0.f; break;
+      case EW_SIGMOID_BWD: { const float y = ld(b.p, b.dt, i); r = ld(a.p, a.dt, i) * y * (1.f - y); break; }
+      case EW_SCALE: r = s * ld(a.p, a.dt, i); break;
+      case EW_ADD_BCAST: r = ld(a.p, a.dt, i) + s * ld(b.p, b.dt, i / div); break;
+      case EW_OUTER_ACC: r = ld(o, odt, i) + ld(a.p, a.dt, i / div) * ld(b.p, b.dt, i % div); break;
+      case EW_MULB_MASK: r = ld(c.p, c.dt, i) > 0.f ? ld(a.p, a.dt, i) * ld(b.p, b.dt, i % div) : 0.f; break;
+      default: r = ld(a.p, a.dt, i); break;
+    }
+    st(o, odt, i, r);
+  }
+}
+
+void temporal_fwd(const Ctx&, const float* a, const float* wt, const float* bt, int B, int C, float* tg) {
+  for (int b = 0; b < B; ++b) {
+    double s = 0;
+    for (int c = 0; c < C; ++c) s += (double)a[(long)b * C + c] * wt[c];
+    tg[b] = sigm((float)s + bt[0]);
+  }
+}
+
+void cvt(const Ctx&, const float* in, void* out, int odt, long n) { for (long i = 0; i < n; ++i) st(out, odt, i, in[i]); }
+
+void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out) {
+  for (int r = 0; r < R; ++r) { double s = 0; for (int c = 0; c < C; ++c) s += W[(long)r * C + c]; out[r] = (float)s; }
+}
+
+}  // namespace dgsct

@@ -1,0 +1,94 @@
+"""Shared test plumbing: golden fixtures, oracle <-> library parameter tables, error metrics."""
+import dataclasses
+import glob
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import dgsct_amd  # noqa: E402
+from dgsct_amd import ops  # noqa: E402
+from dgsct_amd._lib import PARAM_NAMES  # noqa: E402
+from oracle import dgsct_oracle as O  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.pt")))
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=False)
+
+
+def spec_of(cfg) -> ops.AdapterSpec:
+    c = dataclasses.asdict(cfg) if dataclasses.is_dataclass(cfg) else dict(cfg)
+    return ops.AdapterSpec(**{k: c[k] for k in c if k in {f.name for f in dataclasses.fields(ops.AdapterSpec)}})
+
+
+def oracle_cfg(cfg_dict) -> O.AdapterConfig:
+    return O.AdapterConfig(**cfg_dict)
+
+
+def param_table(state, spec: ops.AdapterSpec, device):
+    """reference-named state dict -> list in the C-ABI parameter order (fp32, contiguous, 2-D weights)."""
+    out = []
+    for name in PARAM_NAMES:
+        t = state.get(name)
+        if name == "conv_adapter.weight":
+            t = state["_bicubic"] if spec.remap == "bicubic" else t.reshape(spec.N, spec.No)
+        elif name == "conv_adapter.bias" and spec.remap == "bicubic":
+            t = None
+        elif name in ("down_sampler.weight", "up_sampler.weight"):
+            t = t.reshape(t.shape[0], t.shape[1])
+        elif name.startswith("temporal_gated") and not spec.temporal:
+            t = None
+        elif name.startswith("ln_before") and not spec.ln_before:
+            t = None
+        elif name.startswith(("bn1", "bn2")) and not spec.use_bn:
+            t = None
+        elif name.startswith("ln_post") and not spec.ln_post:
+            t = None
+        elif name == "gate" and not spec.use_gate:
+            t = None
+        out.append(None if t is None else t.detach().clone().float().contiguous().to(device))
+    return out
+
+
+def rel_err(a, b):
+    """max |a-b| / max(1, max|b|)"""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / max(1.0, b.abs().max().item())).item()
+
+
+def nrm_err(a, b):
+    """max |a-b| / max|b|   (scale-free; used for bf16 where tensors can be small)"""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / max(1e-12, b.abs().max().item())).item()
+
+
+def run_library(lib, fx, device, dtype=torch.float32, training=True):
+    """Run prepare + forward + backward of `lib` on a golden fixture.  Returns a dict of results."""
+    cfg = fx["cfg"]
+    spec = spec_of(cfg)
+    state = {k: v.clone() for k, v in fx["state0"].items()}
+    if spec.remap == "bicubic":
+        state["_bicubic"] = O.bicubic_matrix(spec.No, spec.N)
+    params = param_table(state, spec, device)
+    X = fx["X"].to(device=device, dtype=dtype).contiguous()
+    Y = fx["Y"].to(device=device, dtype=dtype).contiguous()
+    prep = ops.prepare(lib, spec, params, dtype, device)
+    out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, training)
+    res = dict(out=out, map=amap, tmap=tmap, params=params, spec=spec, saved=saved, desc=d)
+    if training:
+        dOut = fx["dOut"].to(device=device, dtype=dtype).contiguous()
+        dMap = fx["dMap"].to(device)
+        dTmap = fx["dTmap"].to(device) if fx["dTmap"] is not None else None
+        dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, dTmap)
+        res.update(dX=dX, dY=dY, grads={PARAM_NAMES[i]: g for i, g in enumerate(grads) if g is not None})
+    return res

@@ -1,0 +1,147 @@
+"""GPU parity: libdgsct.so (hand-written gfx950 kernels, through the C ABI) against the reference golden
+vectors and against the oracle at real AVE shapes.  Tolerances are BASELINE.json's: 1e-3 (fp32), 1e-2 (bf16),
+measured as max|err| / max(1, max|ref|) (fp32) and max|err| / max|ref| (bf16, tensors can be small)."""
+import pytest
+import torch
+
+from helpers import golden_names, load_golden, nrm_err, oracle_cfg, param_table, rel_err, run_library, spec_of
+from dgsct_amd import ops
+from dgsct_amd._lib import P_INDEX, PARAM_NAMES, default_lib
+from oracle import dgsct_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL_F32 = 1e-3
+TOL_BF16 = 1e-2
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fp32(name):
+    fx = load_golden(name)
+    r = run_library(default_lib(), fx, DEV, torch.float32, training=True)
+    torch.cuda.synchronize()
+    assert rel_err(r["out"], fx["out"]) < TOL_F32
+    assert rel_err(r["map"], fx["map"]) < TOL_F32
+    if fx["tmap"] is not None:
+        assert rel_err(r["tmap"], fx["tmap"]) < TOL_F32
+    assert rel_err(r["dX"], fx["dX"]) < TOL_F32
+    assert rel_err(r["dY"], fx["dY"]) < TOL_F32
+    for k, g in fx["grads"].items():
+        assert k in r["grads"], k
+        assert rel_err(r["grads"][k].reshape(g.shape), g) < TOL_F32, k
+    assert not (set(r["grads"]) - set(fx["grads"]))
+    for k, v in fx["buffers1"].items():
+        if "running" in k:
+            assert rel_err(r["params"][P_INDEX[k]], v) < TOL_F32, k
+
+
+@pytest.mark.parametrize("name", ["ave_orderA", "avs_s4", "avqa", "pretrain"])
+def test_golden_eval_fp32(name):
+    fx = dict(load_golden(name))
+    st = dict(fx["state0"]); st.update(fx["buffers1"]); fx["state0"] = st
+    r = run_library(default_lib(), fx, DEV, torch.float32, training=False)
+    assert rel_err(r["out"], fx["eval_out"]) < TOL_F32
+    assert rel_err(r["map"], fx["eval_map"]) < TOL_F32
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_bf16(name):
+    """bf16 storage + bf16 MFMA on tiny un-averaged problems: outputs within 1e-2; gradients of the tiny
+    problems (C=16..64, K as small as 2) are checked at 3e-2 of the tensor's max."""
+    fx = load_golden(name)
+    r = run_library(default_lib(), fx, DEV, torch.bfloat16, training=True)
+    assert nrm_err(r["out"], fx["out"]) < TOL_BF16 * 2
+    assert nrm_err(r["map"], fx["map"]) < TOL_BF16 * 2
+    assert nrm_err(r["dX"], fx["dX"]) < 3e-2
+    assert nrm_err(r["dY"], fx["dY"]) < 3e-2
+
+
+def _real_case(N, C, No, Co, BT, dtype, seed=0):
+    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
+    p = O.random_params(cfg, "ave", seed=seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    X = torch.randn(BT, N, C, generator=gen)
+    Y = torch.randn(BT, No, Co, generator=gen)
+    dOut = torch.randn(BT, N, C, generator=gen)
+    dMap = torch.randn(BT, N, generator=gen)
+    if dtype == torch.bfloat16:   # the oracle sees the same rounded inputs
+        X, Y, dOut = X.bfloat16().float(), Y.bfloat16().float(), dOut.bfloat16().float()
+    po = {k: v.clone() for k, v in p.items()}
+    out_o, map_o, _, s = O.forward(po, X, Y, cfg, training=True)
+    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, None, training=True)
+    spec = spec_of(cfg)
+    params = param_table(p, spec, DEV)
+    lib = default_lib()
+    Xd, Yd = X.to(DEV, dtype).contiguous(), Y.to(DEV, dtype).contiguous()
+    prep = ops.prepare(lib, spec, params, dtype, DEV)
+    out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
+    dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(DEV, dtype).contiguous(),
+                                     dMap.to(DEV), None)
+    return dict(out=(out, out_o), map=(amap, map_o), dX=(dX, dX_o), dY=(dY, dY_o),
+                grads={PARAM_NAMES[i]: (g, g_o[PARAM_NAMES[i]]) for i, g in enumerate(grads) if g is not None})
+
+
+# (N, C, No, Co) of AVE stage 2 / stage 3, visual and audio direction, Swin-V2-B widths (BASELINE config 2)
+REAL = [(144, 512, 256, 384), (256, 384, 144, 512), (36, 1024, 64, 768), (64, 768, 36, 1024)]
+
+
+@pytest.mark.parametrize("shape", REAL)
+def test_real_shapes_fp32(shape):
+    r = _real_case(*shape, BT=10, dtype=torch.float32)
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(*r[k]) < TOL_F32, k
+    for k, (g, go) in r["grads"].items():
+        assert rel_err(g, go.reshape(-1)) < TOL_F32, k
+
+
+@pytest.mark.parametrize("shape", REAL)
+def test_real_shapes_bf16(shape):
+    r = _real_case(*shape, BT=10, dtype=torch.bfloat16)
+    for k in ("out", "map", "dX", "dY"):
+        assert nrm_err(*r[k]) < TOL_BF16, k
+    for k, (g, go) in r["grads"].items():
+        assert nrm_err(g, go.reshape(-1)) < 2 * TOL_BF16, k
+
+
+def test_module_dropin_matches_oracle():
+    """nn.Module boundary: reference call convention ([BT,C,N,1] views), state_dict names, autograd."""
+    from types import SimpleNamespace
+    from dgsct_amd import VisualAdapter
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=8)
+    torch.manual_seed(0)
+    m = VisualAdapter(64, 64, "bottleneck", reduction_factor=8, opt=opt, use_bn=True, use_gate=True, num_tk=8,
+                      conv_dim_in=49, conv_dim_out=25, linear_in=48, linear_out=64).to(DEV)
+    with torch.no_grad():
+        m.gate.fill_(0.7); m.gate_av.fill_(0.3)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    cfg = O.AdapterConfig(N=25, C=64, No=49, Co=48, tk=8, r=8, g=2)
+    BT = 10
+    f = torch.randn(BT, 25, 64, device=DEV, requires_grad=True)
+    fo = torch.randn(BT, 49, 48, device=DEV, requires_grad=True)
+    out, amap = m(f.permute(0, 2, 1).unsqueeze(-1), fo.permute(0, 2, 1).unsqueeze(-1))
+    assert out.shape == (BT, 64, 25, 1) and amap.shape == (BT, 1, 25)
+    g_out = torch.randn_like(out); g_map = torch.randn_like(amap)
+    (out * g_out).sum().add((amap * g_map).sum()).backward()
+    po = {k: v.clone() for k, v in sd.items()}
+    out_o, map_o, _, s = O.forward(po, f.detach().cpu(), fo.detach().cpu(), cfg, training=True)
+    dX_o, dY_o, g_o = O.backward(po, s, cfg, g_out.squeeze(-1).permute(0, 2, 1).cpu(), g_map.squeeze(1).cpu(), None)
+    assert rel_err(out.squeeze(-1).permute(0, 2, 1), out_o) < TOL_F32
+    assert rel_err(amap.squeeze(1), map_o) < TOL_F32
+    assert rel_err(f.grad, dX_o) < TOL_F32 and rel_err(fo.grad, dY_o) < TOL_F32
+    for k, p in m.named_parameters():
+        if k in g_o:
+            assert rel_err(p.grad, g_o[k].reshape(p.shape)) < TOL_F32, k
+        else:
+            assert p.grad is None or k in ("gate_tk",), k
+    assert int(m.bn1.num_batches_tracked) == 1
+    assert rel_err(m.bn2.running_mean, po["bn2.running_mean"]) < TOL_F32
+
+
+def test_cpu_tensors_raise():
+    from types import SimpleNamespace
+    from dgsct_amd import VisualAdapter
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=4)
+    m = VisualAdapter(32, 32, "bottleneck", reduction_factor=8, opt=opt, num_tk=4, conv_dim_in=36, conv_dim_out=16,
+                      linear_in=16, linear_out=32)
+    with pytest.raises(RuntimeError):
+        m(torch.randn(10, 32, 16, 1), torch.randn(10, 16, 36, 1))

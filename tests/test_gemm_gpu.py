@@ -1,0 +1,136 @@
+"""GPU: the MFMA GEMM engine (csrc/gemm.hip) against torch, through the C ABI test hook.
+Covers both modes (bf16 / fp32 MFMA), all four operand-layout combinations (K-major = ds_read_b128
+fragments, MN-major = ds_read_b64_tr_b16 transpose reads), every tile configuration, ragged sizes,
+two-level contraction, split-K with atomics and every epilogue feature."""
+import ctypes
+
+import pytest
+import torch
+
+import dgsct_amd
+from dgsct_amd._lib import GemmArgs, default_lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _operand(batch, KB, rows, K, kmajor, shared, dtype, pad, gen):
+    """logical X[b][r][(kb,k)] -> (memory tensor, ld, bs, kbs, logical fp64 tensor [batch,rows,KB*K])"""
+    nb = 1 if shared else batch
+    if kmajor:
+        ld = K + pad
+        mem = torch.randn(nb, KB, rows, ld, generator=gen).to(dtype)
+        logical = mem[..., :K].double().permute(0, 2, 1, 3).reshape(nb, rows, KB * K)
+        kbs, bs = rows * ld, KB * rows * ld
+    else:
+        ld = rows + pad
+        mem = torch.randn(nb, KB, K, ld, generator=gen).to(dtype)
+        logical = mem[..., :rows].double().permute(0, 3, 1, 2).reshape(nb, rows, KB * K)
+        kbs, bs = K * ld, KB * K * ld
+    if shared:
+        logical = logical.expand(batch, -1, -1)
+        bs = 0
+    return mem.to(DEV).contiguous(), ld, bs, kbs, logical
+
+
+def run_case(mode, M, N, K, ak, bk, batch=1, KB=1, shared_a=False, pad=0, epi=None, out_bf16=False, atomic=False,
+             splitk=1, seed=0):
+    lib = default_lib()
+    epi = epi or {}
+    gen = torch.Generator().manual_seed(seed)
+    dtype = torch.bfloat16 if mode == 1 else torch.float32
+    Am, lda, a_bs, a_kbs, Al = _operand(batch, KB, M, K, ak, shared_a, dtype, pad, gen)
+    Bm, ldb, b_bs, b_kbs, Bl = _operand(batch, KB, N, K, bk, False, dtype, pad, gen)
+    ref = torch.einsum("bmk,bnk->bmn", Al, Bl)
+    ldd = N + (pad if not atomic else 0)
+    ddt = 1 if out_bf16 else 0
+    D = torch.full((batch, M, ldd), float("nan"), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=DEV)
+    if atomic:
+        D.zero_()
+    a = GemmArgs()
+    a.mode, a.M, a.N, a.K, a.KB, a.batch, a.splitk, a.atomic = mode, M, N, K, KB, batch, splitk, int(atomic)
+    a.A, a.lda, a.a_kmajor, a.a_bs, a.a_kbs = Am.data_ptr(), lda, int(ak), a_bs, a_kbs
+    a.B, a.ldb, a.b_kmajor, a.b_bs, a.b_kbs = Bm.data_ptr(), ldb, int(bk), b_bs, b_kbs
+    a.D, a.ddt, a.ldd, a.dbs = D.data_ptr(), ddt, ldd, M * ldd
+    a.alpha, a.beta = epi.get("alpha", 1.0), epi.get("beta", 1.0)
+    keep = []
+    alpha = a.alpha
+    if epi.get("alpha_ptr"):
+        t = torch.tensor([0.37], device=DEV); keep.append(t); a.alpha_ptr = t.data_ptr(); alpha *= 0.37
+    ref = alpha * ref
+    m_mod = epi.get("m_mod", 0)
+    a.m_mod = m_mod
+    midx = torch.arange(M) % m_mod if m_mod else torch.arange(M)
+    if epi.get("bias_m"):
+        t = torch.randn(m_mod or M, generator=gen); keep.append(t.to(DEV)); a.bias_m = keep[-1].data_ptr()
+        ref = ref + t.double()[midx][None, :, None]
+    if epi.get("bias_n"):
+        per_batch = epi.get("bias_n_batched", False)
+        t = torch.randn(batch if per_batch else 1, N, generator=gen); keep.append(t.to(DEV)); a.bias_n = keep[-1].data_ptr()
+        a.bias_n_bs = N if per_batch else 0
+        ref = ref + t.double()[:, None, :]
+    if epi.get("r1"):
+        t1 = torch.randn(m_mod or M, generator=gen); t2 = torch.randn(N, generator=gen)
+        keep += [t1.to(DEV), t2.to(DEV)]; a.r1_m, a.r1_n = keep[-2].data_ptr(), keep[-1].data_ptr()
+        ref = ref + (t1.double()[midx][:, None] * t2.double()[None, :])[None]
+    a.act = epi.get("act", 0)
+    if a.act == 1:
+        ref = ref.clamp_min(0)
+    elif a.act == 2:
+        ref = torch.sigmoid(ref)
+    if epi.get("mask"):
+        t = torch.randn(batch, M, N, generator=gen).to(dtype); keep.append(t.to(DEV)); a.mask = keep[-1].data_ptr()
+        a.ldmask, a.maskbs = N, M * N
+        ref = ref * (t.double() > 0)
+    if epi.get("R"):
+        rdt = epi.get("rdt", 0)
+        t = torch.randn(batch, M, N, generator=gen).to(torch.bfloat16 if rdt else torch.float32)
+        keep.append(t.to(DEV)); a.R, a.rdt, a.ldr, a.rbs = keep[-1].data_ptr(), rdt, N, M * N
+        ref = ref + a.beta * t.double()
+    lib.test_gemm(a, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = D[..., :N].double().cpu()
+    scale = max(1.0, ref.abs().max().item())
+    err = ((got - ref).abs().max() / scale).item()
+    tol = (4e-3 if out_bf16 else 2e-4) if mode == 1 else (4e-3 if out_bf16 else 2e-5)
+    assert err == err and err < tol, f"gemm mode={mode} M={M} N={N} K={K} ak={ak} bk={bk} batch={batch} KB={KB}: err {err:.3e}"
+    if pad and not atomic:
+        assert torch.isnan(D[..., N:].float()).all(), "GEMM wrote outside its N columns"
+
+
+LAYOUTS = [(1, 1), (1, 0), (0, 1), (0, 0)]
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("ak,bk", LAYOUTS)
+def test_gemm_tile_configs(mode, ak, bk):
+    # 128x128, 128x96, 128x32, 32x128, 64x64 tiles (see gemm_mode's heuristic)
+    for (M, N, K, batch) in [(256, 256, 96, 3), (256, 96, 160, 2), (200, 24, 64, 2), (32, 300, 64, 2), (100, 72, 40, 2)]:
+        run_case(mode, M, N, K, ak, bk, batch=batch)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("ak,bk", LAYOUTS)
+def test_gemm_ragged_unaligned(mode, ak, bk):
+    # sizes that are multiples of nothing, leading dimensions that break 16-byte alignment
+    for (M, N, K, pad) in [(36, 36, 36, 0), (37, 5, 19, 3), (130, 131, 33, 1), (4, 2, 2, 0), (65, 97, 8, 6)]:
+        run_case(mode, M, N, K, ak, bk, batch=2, pad=pad)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("ak,bk", LAYOUTS)
+def test_gemm_two_level_k_splitk_atomic(mode, ak, bk):
+    run_case(mode, 144, 100, 24, ak, bk, batch=1, KB=7, atomic=True, splitk=0)       # dWn-style contraction over (b, c)
+    run_case(mode, 64, 48, 1000, ak, bk, batch=2, atomic=True, splitk=0)            # weight-gradient style, K = tokens
+    run_case(mode, 64, 48, 1000, ak, bk, batch=1, atomic=True, splitk=3)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_gemm_shared_a_and_epilogues(mode):
+    run_case(mode, 150, 96, 70, 1, 0, batch=4, shared_a=True)
+    run_case(mode, 80, 64, 32, 1, 1, batch=2, epi=dict(bias_n=True, act=1), out_bf16=(mode == 1))
+    run_case(mode, 80, 64, 32, 1, 1, batch=2, epi=dict(bias_n=True, bias_n_batched=True, act=2))
+    run_case(mode, 120, 40, 48, 1, 1, batch=1, epi=dict(r1=True, bias_n=True, m_mod=30))
+    run_case(mode, 90, 40, 16, 1, 0, batch=3, epi=dict(alpha_ptr=True, R=True, rdt=mode), out_bf16=(mode == 1))
+    run_case(mode, 33, 40, 64, 1, 0, batch=1, epi=dict(mask=True, bias_m=True))
+    run_case(mode, 64, 64, 4, 1, 0, batch=2, epi=dict(R=True, beta=1.0))           # K smaller than one k-tile (tk = 2 / 4)
