@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Benchmark of the DG-SCT adapter hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5                       # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W         # N GPUs, one rank per GPU (RCCL)
+
+One "step" = the whole AVE adapter stack (48 adapters = 12 layer positions x {p1,p2} x {audio,visual},
+reference schedule net_trans.py:880-916) forward + backward on B=16 clips x T=10 frames per GPU of
+synthetic feature maps at the BASELINE config-2 shapes (Swin-V2-B + HTS-AT), bf16, followed by the
+data-parallel gradient all-reduce (N > 1) and an Adam step on the adapter parameters (the reference
+trains them with Adam, main_trans.py:276); weights change every step, so the MFMA-operand weight copies
+are re-made every step inside the timed region as well.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import dgsct_amd  # noqa: E402
+from dgsct_amd import AdapterStack, GradAllReducer, ave_stage_shapes  # noqa: E402
+from dgsct_amd._lib import default_lib  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARCH.md
+
+
+def alg_flops_per_frame(stages, tk=32, r=8, g=2):
+    """F = remap + 8 tk C N + 3 N C^2 + 5 C^2 + N C + 4 N C ds/g per adapter forward per frame."""
+    tot = 0.0
+    for s in stages:
+        for (N, C, No, Co) in ((s["Nv"], s["Cv"], s["Na"], s["Ca"]), (s["Na"], s["Ca"], s["Nv"], s["Cv"])):
+            remap = min(2 * N * No * Co + 2 * N * Co * C, 2 * No * Co * C + 2 * N * No * C)
+            f = remap + 8 * tk * C * N + 3 * N * C * C + 5 * C * C + N * C + 4 * N * C * (C // r) // g
+            tot += f * 2 * s["layers"]            # p1 + p2
+    return tot
+
+
+def build_stack(backbone, dtype, device, concurrent=True):
+    torch.manual_seed(0)
+    stages = ave_stage_shapes(backbone)
+    stack = AdapterStack(stages, compute_dtype=dtype, concurrent=concurrent).to(device)
+    with torch.no_grad():
+        for n, p in stack.named_parameters():
+            if n.endswith("gate") or n.endswith("gate_av"):
+                p.fill_(0.5)                       # default 0 makes the path degenerate
+    return stages, stack
+
+
+def make_inputs(stages, BT, dtype, device, seed):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    feats, cots = [], []
+    for s in stages:
+        fv = torch.randn(BT, s["Nv"], s["Cv"], generator=gen).to(device=device, dtype=dtype).requires_grad_(True)
+        fa = torch.randn(BT, s["Na"], s["Ca"], generator=gen).to(device=device, dtype=dtype).requires_grad_(True)
+        feats.append((fv, fa))
+        cots.append((torch.randn(BT, s["Nv"], s["Cv"], generator=gen).to(device=device, dtype=dtype),
+                     torch.randn(BT, s["Na"], s["Ca"], generator=gen).to(device=device, dtype=dtype)))
+    s = stages[-1]
+    mcots = (torch.randn(BT, 1, s["Nv"], generator=gen).to(device), torch.randn(BT, 1, s["Na"], generator=gen).to(device))
+    return feats, cots, mcots
+
+
+def cpu_baseline(backbone, max_seconds=30.0):
+    """The oracle's autograd 'port' (op-for-op ATen restatement of the reference adapter, token-major) timed on the
+    host cores: ONE clip (BT = 10 frames) through all 48 adapters, forward + backward, fp32."""
+    from oracle import dgsct_oracle as O
+    stages = ave_stage_shapes(backbone)
+    BT = 10
+    torch.manual_seed(0)
+    adapters = []
+    for s in stages:
+        for (N, C, No, Co) in ((s["Na"], s["Ca"], s["Nv"], s["Cv"]), (s["Nv"], s["Cv"], s["Na"], s["Ca"])):
+            cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
+            for _ in range(2 * s["layers"]):
+                p = O.random_params(cfg, "ave", seed=len(adapters))
+                p = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.startswith("_") else v)
+                     for k, v in p.items()}
+                adapters.append((cfg, p))
+
+    def one_pass():
+        t0 = time.perf_counter()
+        for cfg, p in adapters:
+            X = torch.randn(BT, cfg.N, cfg.C, requires_grad=True)
+            Y = torch.randn(BT, cfg.No, cfg.Co, requires_grad=True)
+            out, amap, _ = O.forward_autograd(p, X, Y, cfg, training=True)
+            torch.autograd.backward([out, amap], [torch.randn_like(out), torch.randn_like(amap)])
+            for v in p.values():
+                if v.requires_grad:
+                    v.grad = None
+        return time.perf_counter() - t0
+
+    # pick the intra-op thread count that serves this op mix best on this host (all logical CPUs is rarely it)
+    ncpu = os.cpu_count() or 1
+    best_n, best_t = torch.get_num_threads(), None
+    probe = [a for a in adapters if a[0].N in (144, 256)][:2]
+    for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(n)
+        full, adapters[:] = adapters[:], probe
+        one_pass()
+        t = one_pass()
+        adapters[:] = full
+        if best_t is None or t < best_t:
+            best_n, best_t = n, t
+    torch.set_num_threads(best_n)
+
+    t_warm = one_pass()
+    times = []
+    budget = max_seconds - t_warm
+    while budget > 0 and len(times) < 3:
+        t = one_pass()
+        times.append(t)
+        budget -= t
+    if not times:
+        times = [t_warm]
+    t = sorted(times)[len(times) // 2]
+    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 clip (BT=10) x 48 adapters fwd+bwd, fp32, oracle.forward_autograd (ATen op-for-op port of the "
+                       f"reference adapter), median of {len(times)} passes after 1 warm-up; {t:.2f} s/pass")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU (T=10 frames each)")
+    ap.add_argument("--backbone", default="swinv2_base", choices=["swinv2_base", "swinv2_large"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optim", action="store_true", help="time fwd+bwd(+all-reduce) only")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="one HIP stream (no audio/visual adapter overlap)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)       # "nccl" is RCCL on ROCm
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    T = 10
+    BT = args.batch * T
+
+    stages, stack = build_stack(args.backbone, dtype, device, concurrent=not args.serial)
+    stack.train()
+    params = [p for p in stack.parameters() if p.requires_grad]
+    if world > 1:
+        import torch.distributed as dist
+        for p in stack.parameters():
+            dist.broadcast(p.data, 0)
+    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack)) if world > 1 else None
+    opt = None if args.no_optim else torch.optim.Adam(params, lr=1e-5)
+    feats, cots, mcots = make_inputs(stages, BT, dtype, device, seed=1 + rank)
+
+    def step():
+        outs, maps = stack(feats)
+        tensors = [t for pair in outs for t in pair] + [maps[0], maps[1]]
+        grads = [g for pair in cots for g in pair] + [mcots[0], mcots[1]]
+        torch.autograd.backward(tensors, grads)
+        if reducer is not None:
+            reducer.finish()
+        if opt is not None:
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in params:
+                p.grad = None
+        for fv, fa in feats:
+            fv.grad = None
+            fa.grad = None
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    clips_per_s = args.batch * world / (elapsed / args.steps)
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel family = the MFMA GEMM engine (gemm_kernel<...>): time every launch of two extra steps
+        # with HIP events on the launch stream (the library records them itself: dgsct_prof_enable).
+        lib = default_lib()
+        lib.prof_enable(True)
+        nprof = 2
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        launches, gemm_ms, gemm_flops = lib.prof_collect()
+        lib.prof_enable(False)
+        alg = 3.0 * alg_flops_per_frame(stages) * BT                 # fwd + bwd, per step
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        achieved = alg * nprof / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                        traffic=None, kernel="dgsct::gemm_kernel<*> (all MFMA GEMM launches of a step)",
+                        launches_per_step=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
+                        alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
+                        gemm_ms_per_step=round(gemm_ms / nprof, 3),
+                        step_frac_of_mfma_peak=round(alg / (ms_per_step * 1e-3) / 1e12 / peak, 4))
+    if world > 1:
+        barrier()
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.backbone)
+        line = dict(
+            metric="adapter_fwd_bwd_clips_per_sec", value=round(clips_per_s, 2), unit="clips/s", n_gpus=world,
+            steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak",
+            vs_baseline=None, dtype="bf16" if dtype == torch.bfloat16 else "f32", data="synthetic",
+            config=dict(workload=f"AVE fine-tune adapter stack (BASELINE configs[1]): {args.backbone} + HTS-AT token/width "
+                                 f"shapes, 48 DG-SCT adapters, B={args.batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on",
+                        global_batch=args.batch * world, frames_per_clip=T, parallelism=f"dp{world}",
+                        step="fwd+bwd" + ("+allreduce" if world > 1 else "") + ("" if args.no_optim else "+adam")),
+            roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

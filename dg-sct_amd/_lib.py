@@ -56,7 +56,7 @@ class GemmArgs(C.Structure):
 
 
 EXPORTS = ["dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
-           "dgsct_adapter_backward", "dgsct_saved_region", "dgsct_test_gemm"]
+           "dgsct_adapter_backward", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect"]
 
 _PP = C.POINTER(C.c_void_p)
 
@@ -127,6 +127,14 @@ class Lib:
             out[name.value.decode()] = (off.value, nb.value)
             i += 1
         return out
+
+    def prof_enable(self, on: bool):
+        self.c.dgsct_prof_enable(int(on))
+
+    def prof_collect(self):
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        self.c.dgsct_prof_collect(C.byref(n), C.byref(ms), C.byref(fl))
+        return n.value, ms.value, fl.value
 
     def test_gemm(self, args: GemmArgs, stream: int):
         self._check(self.c.dgsct_test_gemm(C.byref(args), stream), "dgsct_test_gemm")

@@ -95,4 +95,12 @@ int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
   return has_error() ? 1 : 0;
 }
 
+int dgsct_prof_enable(int on) { gemm_prof_enable(on); return 0; }
+int dgsct_prof_collect(int64_t* launches, double* total_ms, double* total_flops) {
+  long n = 0;
+  gemm_prof_collect(&n, total_ms, total_flops);
+  if (launches) *launches = n;
+  return 0;
+}
+
 }  // extern "C"

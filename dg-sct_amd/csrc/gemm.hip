@@ -16,7 +16,11 @@
 //   lane-linear LDS-DMA path cannot express).
 // * blockIdx.x is remapped so that the 8 XCDs each walk a contiguous range of tiles (private L2s).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdio>
+#include <deque>
+#include <mutex>
+#include <vector>
 #include "prims.h"
 #include "device_util.h"
 
@@ -40,6 +44,7 @@ struct GemmK {
   const char* R; int rdt; long ldr, rbs; float beta;
   const char* mask; long ldmask, maskbs;
   int atomic;
+  int wide;
 };
 
 // pitch (bytes) of one k-row of an MN-major bf16 LDS tile holding `rows` elements: >= rows*2, == 64 (mod 128)
@@ -174,7 +179,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
   using GB = TileGeom<MODE, BK, BN>;
   constexpr int BKT = GA::BKT;
   constexpr int ES = GA::ES;
-  __shared__ __attribute__((aligned(16))) char smem[GA::LDS_BYTES + GB::LDS_BYTES];
+  constexpr int STG_BYTES = 4 * 32 * (TN * 32 + 4) * 4;      // wide-epilogue staging, 4 waves
+  constexpr int OPND_BYTES = GA::LDS_BYTES + GB::LDS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[OPND_BYTES > STG_BYTES ? OPND_BYTES : STG_BYTES];
   char* ldsA = smem;
   char* ldsB = smem + GA::LDS_BYTES;
 
@@ -265,6 +272,76 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
   const char* Rb = p.R ? p.R + (long)b * p.rbs * (p.rdt == DT_F32 ? 4 : 2) : nullptr;
   const char* Mb = p.mask ? p.mask + (long)b * p.maskbs * ES : nullptr;
   const float* bias_n = p.bias_n ? p.bias_n + (long)b * p.bias_n_bs : nullptr;
+  if (p.wide) {
+    // Wide path: stage each wave's 32 x (TN*32) block through LDS (fp32) and write full token rows with 16-byte
+    // stores (32-byte for fp32 out); the residual is read the same way.  An MFMA accumulator holds a COLUMN per lane,
+    // so the direct path below can only issue 2-byte stores to 64-byte row segments -- 4-6x slower on the
+    // token-major [rows][C] outputs that dominate this workload (they are HBM-bound GEMMs).
+    constexpr int SP = TN * 32 + 4;                     // staging pitch (floats); 16-byte aligned rows
+    constexpr int CPR = TN * 4;                         // 8-column chunks per row
+    float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SP);
+    const int ncol0 = n0 + wn * TN * 32;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      __syncthreads();                                  // operand tiles / previous block fully consumed
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32 + (lane & 31);
+        const bool nok = n < p.N;
+        const float bn = (bias_n && nok) ? bias_n[n] : 0.f;
+        const float r1n = (p.r1_n && nok) ? p.r1_n[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int m = m0 + (wm * TM + i) * 32 + row;
+          float v = alpha * acc[i][j][r] + bn;
+          if ((p.bias_m || p.r1_m) && m < p.M) {
+            const int mm = p.m_mod > 0 ? m % p.m_mod : m;
+            if (p.bias_m) v += p.bias_m[mm];
+            if (p.r1_m) v += p.r1_m[mm] * r1n;
+          }
+          if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+          stg[row * SP + j * 32 + (lane & 31)] = v;
+        }
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int it = 0; it < (32 * CPR) / 64; ++it) {
+        const int c = it * 64 + lane;
+        const int row = c / CPR, cc = c % CPR;
+        const int m = m0 + (wm * TM + i) * 32 + row;
+        const int n = ncol0 + cc * 8;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        {
+          const float4 a = *reinterpret_cast<const float4*>(stg + row * SP + cc * 8);
+          const float4 c4 = *reinterpret_cast<const float4*>(stg + row * SP + cc * 8 + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c4.x; v[5] = c4.y; v[6] = c4.z; v[7] = c4.w;
+        }
+        const long od = (long)m * p.ldd + n;
+        if (n + 8 <= p.N) {
+          if (Rb) {
+            float rv[8];
+            const long orr = (long)m * p.ldr + n;
+            if (p.rdt == DT_F32) ldv<DT_F32, 4>(Rb, orr, *reinterpret_cast<float(*)[4]>(rv)), ldv<DT_F32, 4>(Rb, orr + 4, *reinterpret_cast<float(*)[4]>(rv + 4));
+            else ldv<DT_BF16, 8>(Rb, orr, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += p.beta * rv[e];
+          }
+          if (p.ddt == DT_F32) { stv<DT_F32, 4>(Db, od, *reinterpret_cast<const float(*)[4]>(v)); stv<DT_F32, 4>(Db, od + 4, *reinterpret_cast<const float(*)[4]>(v + 4)); }
+          else stv<DT_BF16, 8>(Db, od, v);
+        } else {
+          for (int e = 0; e < 8 && n + e < p.N; ++e) {
+            float x = v[e];
+            if (Rb) x += p.beta * lde_rt(Rb, p.rdt, (long)m * p.ldr + n + e);
+            ste_rt(Db, p.ddt, od + e, x);
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -306,6 +383,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Optional per-launch timing of the GEMM family (bench.py's roofline leg): HIP events recorded on the
+// launch stream around every gemm_kernel launch of this thread while enabled.  Off by default.
+struct ProfRec { hipEvent_t e0, e1; double flops; };
+// (process-wide: autograd runs backward on its own thread)
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
+static std::deque<ProfRec>* g_prof = nullptr;
+
+static ProfRec* prof_begin(hipStream_t s, double flops) {
+  if (!g_prof_on.load(std::memory_order_relaxed)) return nullptr;
+  ProfRec r;
+  r.flops = flops;
+  (void)hipEventCreate(&r.e0);
+  (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof) g_prof = new std::deque<ProfRec>();
+  g_prof->push_back(r);
+  return &g_prof->back();          // deque: stable addresses
+}
+static void prof_end(ProfRec* r, hipStream_t s) {
+  if (r) (void)hipEventRecord(r->e1, s);
+}
+void gemm_prof_enable(int on) { g_prof_on.store(on != 0); }
+// Synchronises on the recorded events; returns launches, sum of durations (ms) and of useful FLOPs; clears the log.
+void gemm_prof_collect(long* launches, double* total_ms, double* total_flops) {
+  long n = 0; double ms = 0, fl = 0;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof) {
+    for (auto& r : *g_prof) {
+      (void)hipEventSynchronize(r.e1);
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms += t; fl += r.flops; ++n; }
+      (void)hipEventDestroy(r.e0);
+      (void)hipEventDestroy(r.e1);
+    }
+    g_prof->clear();
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+}
+
 template <int MODE, int WGM, int WGN, int TM, int TN>
 static void launch_cfg(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s) {
   if (ak && bk)       hipLaunchKernelGGL((gemm_kernel<MODE, true, true, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
@@ -335,6 +455,12 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   k.R = (const char*)g.R; k.rdt = g.rdt; k.ldr = g.ldr; k.rbs = g.rbs; k.beta = g.beta;
   k.mask = (const char*)g.mask; k.ldmask = g.ldmask; k.maskbs = g.maskbs;
   k.atomic = g.atomic;
+  {
+    const int dv = g.ddt == DT_F32 ? 4 : 8, rv = g.rdt == DT_F32 ? 4 : 8;
+    bool w = !g.atomic && !g.mask && aligned16(g.D) && g.ldd % dv == 0 && g.dbs % dv == 0 && g.N >= 8;
+    if (g.R) w = w && aligned16(g.R) && g.ldr % rv == 0 && g.rbs % rv == 0;
+    k.wide = w;
+  }
   k.kt_per_kb = (g.K + BKT - 1) / BKT;
   k.kt_total = k.kt_per_kb * g.KB;
 
@@ -363,6 +489,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   dim3 grid(k.tiles_m * k.tiles_n, g.batch, splitk);
   hipStream_t s = (hipStream_t)ctx.stream;
   const int ak = g.A.kmajor, bk = g.B.kmajor;
+  ProfRec* rec = prof_begin(s, 2.0 * g.M * g.N * (double)g.K * g.KB * g.batch);
   switch (cfg) {
     case 0: launch_cfg<MODE, 2, 2, 2, 2>(k, ak, bk, grid, s); break;
     case 1: launch_cfg<MODE, 4, 1, 1, 3>(k, ak, bk, grid, s); break;
@@ -370,6 +497,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     case 3: launch_cfg<MODE, 1, 4, 1, 1>(k, ak, bk, grid, s); break;
     default: launch_cfg<MODE, 2, 2, 1, 1>(k, ak, bk, grid, s); break;
   }
+  prof_end(rec, s);
 }
 
 void gemm(const Ctx& ctx, const Gemm& g) {

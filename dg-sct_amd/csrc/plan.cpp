@@ -486,7 +486,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                 b.Wk<float>(wb.dsl), G(DGSCT_P_BS));
     colsum_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd);  // u
     ew(ctx, EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1);
-    sum_batch(ctx, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 0);                 // dws
+    sum_batch(ctx, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 1);                 // dws
     ew(ctx, EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd);
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
     relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f);
@@ -570,7 +570,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       if (dTmap) ew(ctx, EW_ADD_BCAST, dtg, DT_F32, F32(dtg), F32(dTmap), NOARG, B, 1.f, 1);
       ew(ctx, EW_SIGMOID_BWD, b.Wk(wb.dpre_t), DT_F32, F32(dtg), F32(tg), NOARG, B, 0.f, 1);
       colsum_batched(ctx, b.S(s.aE), C, 0, 1, B, C, b.Wk<float>(wb.dpre_t), 0, 1.f, G(DGSCT_P_WT), 0);
-      sum_batch(ctx, b.Wk<float>(wb.dpre_t), 1, B, 1, G(DGSCT_P_BT), 1.f, 0);
+      sum_batch(ctx, b.Wk<float>(wb.dpre_t), 1, B, 1, G(DGSCT_P_BT), 1.f, 1);
       ew(ctx, EW_OUTER_ACC, b.Wk(wb.da), DT_F32, F32(b.Wk(wb.dpre_t)), F32(b.F(DGSCT_P_WT)), NOARG, (long)B * C, 0.f, C);
     }
   }
@@ -619,7 +619,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     resid(g2, b.Wk(wb.dtokF), DT_F32, C, (long)tk * C);
     outF(g2, b.Wk<float>(wb.dtokF), C, (long)tk * C);
     gemm(ctx, g2);
-    sum_batch(ctx, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 0);
+    sum_batch(ctx, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
     ew(ctx, EW_SCALE, b.Wk(wb.daN), DT_F32, F32(b.Wk(wb.da)), NOARG, NOARG, (long)B * C, 1.f / (float)N, 1);
     Gemm g3 = mk(N, C, tk, B);                                   // dYp = P1^T . dtok + da/N
     g3.A = mn(b.S(s.P1), Np, (long)tk * Np);
@@ -640,7 +640,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     if (conv) {
       colsum_batched(ctx, dYp, C, 0, 1, (int)R, C, nullptr, 0, 1.f, G(DGSCT_P_BC), 0);                    // dbc
       rowdot_batched(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
-      sum_batch(ctx, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 0);                             // dbn
+      sum_batch(ctx, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                             // dbn
       colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);    // d rowsum(Wc)
     } else {
       colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);

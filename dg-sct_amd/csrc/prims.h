@@ -55,6 +55,9 @@ struct Gemm {
 };
 
 void gemm(const Ctx&, const Gemm&);
+// bench-only: time every GEMM launch of this thread with HIP events (see gemm.hip)
+void gemm_prof_enable(int on);
+void gemm_prof_collect(long* launches, double* total_ms, double* total_flops);
 void zero(const Ctx&, void* p, size_t bytes);
 
 // out[r][0..L) = softmax(pre_tanh ? tanh(in[r][.]) : in[r][.]); out[r][L..ld_out) = 0.  out dtype odt.

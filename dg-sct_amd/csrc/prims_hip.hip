@@ -30,14 +30,14 @@ void zero(const Ctx& ctx, void* p, size_t bytes) {
 // row-kernel geometry
 // ================================================================================================
 struct RowGeom { int gs, nv, rpp, rpc, chunks; };
-static RowGeom row_geom(int C, int VE, int N, int B) {
+static RowGeom row_geom(int C, int VE, int N, int B, long target_wgs = 2048) {
   RowGeom g;
   int nvec = C / VE;
   g.gs = 1;
   while (g.gs < nvec && g.gs < 64) g.gs <<= 1;
   g.nv = (nvec + g.gs - 1) / g.gs;
   g.rpp = 256 / g.gs;
-  long want = cdiv(2048, B);                      // ~2048 workgroups in flight
+  long want = cdiv(target_wgs, B);                // workgroups; reductions (bwd kernels) use fewer, fatter ones
   long maxc = cdiv(N, g.rpp);
   long chunks = want < 1 ? 1 : (want > maxc ? maxc : want);
   g.rpc = (int)(cdiv(cdiv(N, chunks), g.rpp) * g.rpp);
@@ -45,16 +45,27 @@ static RowGeom row_geom(int C, int VE, int N, int B) {
   return g;
 }
 // dispatch on (mode, vector width): bf16 -> 8 (C%8==0) or 4; f32 -> 4.  C % 4 == 0 is required.
-#define ROW_DISPATCH(ctx, C, KERNEL, GRID, ...)                                                            \
+// The register arrays of a row kernel are sized by the template NV: pick the smallest instantiation that
+// holds the row (NV = vectors per lane) -- an oversized one costs occupancy (C=128 bf16 needs NV=1, not 3).
+#define ROW_L_(KERNEL, DT_, VE_, NV_, GRID, SHMEM, ...) \
+  hipLaunchKernelGGL((KERNEL<DT_, VE_, NV_>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__)
+#define ROW_DISPATCH_SH(ctx, C, NV, KERNEL, GRID, SHMEM, ...)                                              \
   do {                                                                                                      \
     if ((C) % 4 != 0 || (C) > 1536) { set_error("row kernel: C=%d must be a multiple of 4 and <= 1536", (int)(C)); break; } \
     if ((ctx).mode == DT_BF16) {                                                                            \
-      if ((C) % 8 == 0) hipLaunchKernelGGL((KERNEL<DT_BF16, 8, 3>), GRID, dim3(256), 0, STREAM(ctx), __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<DT_BF16, 4, 6>), GRID, dim3(256), 0, STREAM(ctx), __VA_ARGS__);       \
+      if ((C) % 8 == 0) {                                                                                   \
+        if ((NV) <= 1) ROW_L_(KERNEL, DT_BF16, 8, 1, GRID, SHMEM, __VA_ARGS__);                             \
+        else if ((NV) <= 2) ROW_L_(KERNEL, DT_BF16, 8, 2, GRID, SHMEM, __VA_ARGS__);                        \
+        else ROW_L_(KERNEL, DT_BF16, 8, 3, GRID, SHMEM, __VA_ARGS__);                                       \
+      } else ROW_L_(KERNEL, DT_BF16, 4, 6, GRID, SHMEM, __VA_ARGS__);                                       \
     } else {                                                                                                \
-      hipLaunchKernelGGL((KERNEL<DT_F32, 4, 6>), GRID, dim3(256), 0, STREAM(ctx), __VA_ARGS__);             \
+      if ((NV) <= 1) ROW_L_(KERNEL, DT_F32, 4, 1, GRID, SHMEM, __VA_ARGS__);                                \
+      else if ((NV) <= 2) ROW_L_(KERNEL, DT_F32, 4, 2, GRID, SHMEM, __VA_ARGS__);                           \
+      else if ((NV) <= 3) ROW_L_(KERNEL, DT_F32, 4, 3, GRID, SHMEM, __VA_ARGS__);                           \
+      else ROW_L_(KERNEL, DT_F32, 4, 6, GRID, SHMEM, __VA_ARGS__);                                          \
     }                                                                                                       \
   } while (0)
+#define ROW_DISPATCH(ctx, C, NV, KERNEL, GRID, ...) ROW_DISPATCH_SH(ctx, C, NV, KERNEL, GRID, 0, __VA_ARGS__)
 static inline int row_ve(const Ctx& ctx, int C) { return ctx.mode == DT_BF16 ? (C % 8 == 0 ? 8 : 4) : 4; }
 
 // flush per-lane channel accumulators: LDS combine across the row-groups of the workgroup, then one
@@ -152,7 +163,7 @@ void modln_fwd(const Ctx& ctx, const void* X1, const float* ch, const float* sg,
                float gamma, const float* lnw, const float* lnb, float eps, int B, int N, int C, void* X3, float* mu,
                float* rstd) {
   RowGeom g = row_geom(C, row_ve(ctx, C), N, B);
-  ROW_DISPATCH(ctx, C, modln_fwd_k, dim3(g.chunks, B), X1, ch, sg, tg, alpha, beta, gamma, lnw, lnb, eps, N, C, g.gs, g.nv,
+  ROW_DISPATCH(ctx, C, g.nv, modln_fwd_k, dim3(g.chunks, B), X1, ch, sg, tg, alpha, beta, gamma, lnw, lnb, eps, N, C, g.gs, g.nv,
                g.rpc, X3, mu, rstd);
 }
 
@@ -246,14 +257,10 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
 void modln_bwd(const Ctx& ctx, const void* dX3, const void* X1, const float* ch, const float* sg, const float* tg,
                float alpha, float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N,
                int C, void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg) {
-  RowGeom g = row_geom(C, row_ve(ctx, C), N, B);
+  RowGeom g = row_geom(C, row_ve(ctx, C), N, B, 1024);
   const size_t sh = (size_t)3 * C * sizeof(float);
-#define K_(DT_, VE_, NV_) hipLaunchKernelGGL((modln_bwd_k<DT_, VE_, NV_>), dim3(g.chunks, B), dim3(256), sh, STREAM(ctx), dX3, X1, \
-        ch, sg, tg, alpha, beta, gamma, lnw, mu, rstd, N, C, g.gs, g.nv, g.rpc, dX1, dlnw, dlnb, dch, dsg, tg ? dtg : nullptr)
-  if (C % 4 != 0 || C > 1536) { set_error("modln_bwd: C=%d must be a multiple of 4 and <= 1536", C); return; }
-  if (ctx.mode == DT_BF16) { if (C % 8 == 0) K_(DT_BF16, 8, 3); else K_(DT_BF16, 4, 6); }
-  else K_(DT_F32, 4, 6);
-#undef K_
+  ROW_DISPATCH_SH(ctx, C, g.nv, modln_bwd_k, dim3(g.chunks, B), sh, dX3, X1, ch, sg, tg, alpha, beta, gamma, lnw, mu, rstd, N, C,
+                  g.gs, g.nv, g.rpc, dX1, dlnw, dlnb, dch, dsg, tg ? dtg : nullptr);
 }
 
 // ================================================================================================
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256) void tail_fwd_k(const void* Op, const float* s
 void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
               const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd) {
   RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1);
-  ROW_DISPATCH(ctx, C, tail_fwd_k, dim3(g.chunks), Op, sc2, sh2, lnw, lnb, gate, gate_first, eps, rows, C, g.gs, g.nv, g.rpc,
+  ROW_DISPATCH(ctx, C, g.nv, tail_fwd_k, dim3(g.chunks), Op, sc2, sh2, lnw, lnb, gate, gate_first, eps, rows, C, g.gs, g.nv, g.rpc,
                out, mu, rstd);
 }
 
@@ -433,14 +440,10 @@ __global__ __launch_bounds__(256) void tail_bwd_k(const void* dOut, const void* 
 void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
               const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums) {
-  RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1);
+  RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1, 1024);
   const size_t sh = (size_t)4 * C * sizeof(float);
-#define K_(DT_, VE_, NV_) hipLaunchKernelGGL((tail_bwd_k<DT_, VE_, NV_>), dim3(g.chunks), dim3(256), sh, STREAM(ctx), dOut, Op, sc2, \
-        sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu, rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums)
-  if (C % 4 != 0 || C > 1536) { set_error("tail_bwd: C=%d must be a multiple of 4 and <= 1536", C); return; }
-  if (ctx.mode == DT_BF16) { if (C % 8 == 0) K_(DT_BF16, 8, 3); else K_(DT_BF16, 4, 6); }
-  else K_(DT_F32, 4, 6);
-#undef K_
+  ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu,
+                  rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums);
 }
 
 // ================================================================================================
@@ -487,364 +490,7 @@ void rowdot_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int 
   int ve = row_ve(ctx, C);
   if (ld % ve != 0 || bs % ve != 0) { set_error("rowdot_batched: unaligned ld/bs"); return; }
   RowGeom g = row_geom(C, ve, N, B);
-  ROW_DISPATCH(ctx, C, rowdot_k, dim3(g.chunks, B), x, ld, bs, N, C, w, wdt, w_bs, w2, bias, g.gs, g.nv, g.rpc, out);
-}
-
-// ================================================================================================
-// column-strip kernels
-// ================================================================================================
-struct ColGeom { int nvr, tpr, rpp, rpc, chunks; };
-static ColGeom col_geom(int C, int VE, long rows, int B) {
-  ColGeom g;
-  g.nvr = C / VE;
-  g.tpr = imin(g.nvr, 256);
-  g.rpp = 256 / g.tpr;
-  long want = cdiv(2048, B);
-  long maxc = cdiv(rows, (long)g.rpp * 4);
-  long chunks = want < 1 ? 1 : (want > maxc ? maxc : want);
-  if (chunks < 1) chunks = 1;
-  g.rpc = (int)(cdiv(cdiv(rows, chunks), g.rpp) * g.rpp);
-  g.chunks = (int)cdiv(rows, g.rpc);
-  return g;
-}
-static inline int col_ve(const Ctx& ctx, int C) {
-  const int vmax = ctx.mode == DT_BF16 ? 8 : 4;
-  return C % vmax == 0 ? vmax : 1;
-}
-#define COL_DISPATCH(ctx, C, KERNEL, GRID, SHMEM, ...)                                                    \
-  do {                                                                                                      \
-    if ((ctx).mode == DT_BF16) {                                                                            \
-      if ((C) % 8 == 0) hipLaunchKernelGGL((KERNEL<DT_BF16, 8>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<DT_BF16, 1>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__);      \
-    } else {                                                                                                \
-      if ((C) % 4 == 0) hipLaunchKernelGGL((KERNEL<DT_F32, 4>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<DT_F32, 1>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__);       \
-    }                                                                                                       \
-  } while (0)
-
-// combine NQ per-thread channel accumulators across the row-slots of the workgroup and emit one atomic per channel
-template <int NQ, int VE>
-__device__ __forceinline__ void flush_strip(float (&acc)[NQ][VE], float* lds, int C, int col, bool active,
-                                            float* const (&dst)[NQ]) {
-  __syncthreads();
-  for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.f;
-  __syncthreads();
-  if (active) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int e = 0; e < VE; ++e) atomicAdd(&lds[q * C + col + e], acc[q][e]);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < NQ * C; i += 256) {
-    const int q = i / C;
-    if (dst[q]) unsafeAtomicAdd(dst[q] + (i - q * C), lds[i]);
-  }
-}
-
-// ---- colsum_batched ------------------------------------------------------------------------------
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void colsum_k(const void* x, long ld, long bs, int N, int C, const float* roww,
-                                                long roww_bs, float scale, int tpr, int rpp, int rpc, float* out,
-                                                long out_bs) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int b = blockIdx.y, tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
-  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
-  const int nvr = C / VE;
-  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
-    const int vc = vc0 + tc;
-    const bool active = tr < rpp && vc < nvr;
-    float acc[1][VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) acc[0][e] = 0.f;
-    if (active) {
-      for (int n = blockIdx.x * rpc + tr; n < n_end; n += rpp) {
-        float t[VE];
-        ldv<DT, VE>(x, (long)b * bs + (long)n * ld + vc * VE, t);
-        const float rw = roww ? roww[(long)b * roww_bs + n] : 1.f;
-#pragma unroll
-        for (int e = 0; e < VE; ++e) acc[0][e] += rw * t[e];
-      }
-#pragma unroll
-      for (int e = 0; e < VE; ++e) acc[0][e] *= scale;
-    }
-    float* const dst[1] = {out + (long)b * out_bs};
-    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
-  }
-}
-
-void colsum_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const float* roww, long roww_bs,
-                    float scale, float* out, long out_bs) {
-  int ve = col_ve(ctx, C);
-  if (ld % ve != 0 || bs % ve != 0) ve = 1;
-  ColGeom g = col_geom(C, ve, N, B);
-  const size_t sh = (size_t)C * sizeof(float);
-  if (ve == 1) {
-    if (ctx.mode == DT_BF16) hipLaunchKernelGGL((colsum_k<DT_BF16, 1>), dim3(g.chunks, B), dim3(256), sh, STREAM(ctx), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr, g.rpp, g.rpc, out, out_bs);
-    else hipLaunchKernelGGL((colsum_k<DT_F32, 1>), dim3(g.chunks, B), dim3(256), sh, STREAM(ctx), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr, g.rpp, g.rpc, out, out_bs);
-  } else {
-    COL_DISPATCH(ctx, C, colsum_k, dim3(g.chunks, B), sh, x, ld, bs, N, C, roww, roww_bs, scale, g.tpr, g.rpp, g.rpc, out, out_bs);
-  }
-}
-
-// ---- BatchNorm statistics ------------------------------------------------------------------------
-// acc[0..C) = shift (first row), acc[C..2C) += sum(x - shift), acc[2C..3C) += sum((x-shift)^2)
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void bn_stats_k(const void* x, long rows, int C, int tpr, int rpp, int rpc, float* acc3) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
-  const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
-  const int nvr = C / VE;
-  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
-    const int vc = vc0 + tc;
-    const bool active = tr < rpp && vc < nvr;
-    float acc[2][VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) acc[0][e] = acc[1][e] = 0.f;
-    if (active) {
-      float sft[VE];
-      ldv<DT, VE>(x, (long)vc * VE, sft);            // row 0
-      if (blockIdx.x == 0 && tr == 0) {
-#pragma unroll
-        for (int e = 0; e < VE; ++e) acc3[vc * VE + e] = sft[e];
-      }
-      for (long r = (long)blockIdx.x * rpc + tr; r < r_end; r += rpp) {
-        float t[VE];
-        ldv<DT, VE>(x, r * C + vc * VE, t);
-#pragma unroll
-        for (int e = 0; e < VE; ++e) { const float d = t[e] - sft[e]; acc[0][e] += d; acc[1][e] += d * d; }
-      }
-    }
-    float* const dst[2] = {acc3 + C, acc3 + 2 * C};
-    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst);
-  }
-}
-
-void bn_stats(const Ctx& ctx, const void* x, long rows, int C, float* acc) {
-  ColGeom g = col_geom(C, col_ve(ctx, C), rows, 1);
-  COL_DISPATCH(ctx, C, bn_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), x, rows, C, g.tpr, g.rpp, g.rpc, acc);
-}
-
-__global__ void bn_finalize_k(const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
-                              float* run_var, float momentum, float eps, int training, float* mean, float* rstd,
-                              float* sc, float* sh) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float m, v;
-  if (training) {
-    const float s1 = acc[C + c] / rows, s2 = acc[2 * C + c] / rows;
-    m = acc[c] + s1;
-    v = fmaxf(s2 - s1 * s1, 0.f);
-    const float unb = rows > 1 ? v * ((float)rows / (float)(rows - 1)) : v;
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
-  } else {
-    m = run_mean[c];
-    v = run_var[c];
-  }
-  const float rs = rsqrtf(v + eps);
-  mean[c] = m;
-  rstd[c] = rs;
-  const float s = w[c] * rs;
-  sc[c] = s;
-  sh[c] = b[c] - m * s;
-}
-
-void bn_finalize(const Ctx& ctx, const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
-                 float* run_var, float momentum, float eps, int training, float* mean, float* rstd, float* sc, float* sh) {
-  hipLaunchKernelGGL(bn_finalize_k, dim3((C + 255) / 256), dim3(256), 0, STREAM(ctx), acc, rows, C, w, b, run_mean, run_var,
-                     momentum, eps, training, mean, rstd, sc, sh);
-}
-
-// ---- per-channel affine (+relu), flat elementwise ---------------------------------------------------
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long nvec, int nvr, const float* sc,
-                                                    const float* sh, int relu) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int vc = (int)(i % nvr);
-    float t[VE];
-    ldv<DT, VE>(x, i * VE, t);
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      if (sc) t[e] = t[e] * sc[vc * VE + e] + sh[vc * VE + e];
-      if (relu) t[e] = fmaxf(t[e], 0.f);
-    }
-    stv<DT, VE>(y, i * VE, t);
-  }
-}
-static inline int flat_grid(long nvec) { long g = cdiv(nvec, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
-
-void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu) {
-  const int ve = col_ve(ctx, C);
-  const long nvec = rows * C / ve;
-  COL_DISPATCH(ctx, C, affine_act_k, dim3(flat_grid(nvec)), 0, x, y, nvec, C / ve, sc, sh, relu);
-}
-
-// ---- BatchNorm backward -----------------------------------------------------------------------------
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void* x, long rows, int C, const float* mean,
-                                                      const float* rstd, const float* sc, const float* sh, int relu,
-                                                      int tpr, int rpp, int rpc, float* sums) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
-  const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
-  const int nvr = C / VE;
-  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
-    const int vc = vc0 + tc;
-    const bool active = tr < rpp && vc < nvr;
-    float acc[2][VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) acc[0][e] = acc[1][e] = 0.f;
-    if (active) {
-      float m[VE], rs[VE], a[VE], bsh[VE];
-      ldf<VE>(mean, vc * VE, m); ldf<VE>(rstd, vc * VE, rs); ldf<VE>(sc, vc * VE, a); ldf<VE>(sh, vc * VE, bsh);
-      for (long r = (long)blockIdx.x * rpc + tr; r < r_end; r += rpp) {
-        float g[VE], t[VE];
-        ldv<DT, VE>(dy, r * C + vc * VE, g);
-        ldv<DT, VE>(x, r * C + vc * VE, t);
-#pragma unroll
-        for (int e = 0; e < VE; ++e) {
-          float gg = g[e];
-          if (relu && !(t[e] * a[e] + bsh[e] > 0.f)) gg = 0.f;
-          acc[0][e] += gg;
-          acc[1][e] += gg * (t[e] - m[e]) * rs[e];
-        }
-      }
-    }
-    float* const dst[2] = {sums, sums + C};
-    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst);
-  }
-}
-
-void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
-                  const float* sc, const float* sh, int relu, float* sums) {
-  ColGeom g = col_geom(C, col_ve(ctx, C), rows, 1);
-  COL_DISPATCH(ctx, C, bn_bwd_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), dy, x, rows, C, mean, rstd, sc, sh, relu,
-               g.tpr, g.rpp, g.rpc, sums);
-}
-
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void bn_bwd_apply_k(const void* dy, const void* x, void* dx, long nvec, int nvr, long rows,
-                                                      const float* mean, const float* rstd, const float* sc,
-                                                      const float* sh, const float* sums, int relu, int has_bn,
-                                                      int training) {
-  const int C = nvr * VE;
-  const float inv = 1.f / (float)rows;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int vc = (int)(i % nvr);
-    float g[VE], t[VE];
-    ldv<DT, VE>(dy, i * VE, g);
-    ldv<DT, VE>(x, i * VE, t);
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      const int c = vc * VE + e;
-      float gg = g[e];
-      if (has_bn) {
-        if (relu && !(t[e] * sc[c] + sh[c] > 0.f)) gg = 0.f;
-        if (training) gg = sc[c] * (gg - sums[c] * inv - (t[e] - mean[c]) * rstd[c] * sums[C + c] * inv);
-        else gg = sc[c] * gg;
-      } else {
-        if (relu && !(t[e] > 0.f)) gg = 0.f;
-      }
-      g[e] = gg;
-    }
-    stv<DT, VE>(dx, i * VE, g);
-  }
-}
-
-void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long rows, int C, const float* mean,
-                  const float* rstd, const float* sc, const float* sh, const float* sums, int relu, int has_bn, int training) {
-  const int ve = col_ve(ctx, C);
-  const long nvec = rows * C / ve;
-  COL_DISPATCH(ctx, C, bn_bwd_apply_k, dim3(flat_grid(nvec)), 0, dy, x, dx, nvec, C / ve, rows, mean, rstd, sc, sh, sums, relu,
-               has_bn, training);
-}
-
-// ---- scale_cols / relu_bwd_scale (flat over [B][N][C]) -----------------------------------------------
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void scale_cols_k(const void* x, void* y, long nvec, int nvr, long vec_per_batch,
-                                                    const float* colw, float add) {
-  const int C = nvr * VE;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int vc = (int)(i % nvr);
-    const long b = i / vec_per_batch;
-    float t[VE];
-    ldv<DT, VE>(x, i * VE, t);
-#pragma unroll
-    for (int e = 0; e < VE; ++e) t[e] *= add + colw[b * C + vc * VE + e];
-    stv<DT, VE>(y, i * VE, t);
-  }
-}
-void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* colw, float add) {
-  const int ve = col_ve(ctx, C);
-  const long nvec = (long)B * N * C / ve;
-  COL_DISPATCH(ctx, C, scale_cols_k, dim3(flat_grid(nvec)), 0, x, y, nvec, C / ve, (long)N * C / ve, colw, add);
-}
-
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, long nvec, int nvr, long vec_per_batch,
-                                                        const float* roww, const void* colw, int cdt,
-                                                        const float* colw2, float scale) {
-  const int C = nvr * VE;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int vc = (int)(i % nvr);
-    const long b = i / vec_per_batch;
-    const float rw = (roww ? roww[i / nvr] : 1.f) * scale;
-    float t[VE];
-    ldv<DT, VE>(x, i * VE, t);
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      const int c = vc * VE + e;
-      float cw = lde_rt(colw, cdt, b * C + c);
-      if (colw2) cw *= colw2[c];
-      t[e] = t[e] > 0.f ? rw * cw : 0.f;
-    }
-    stv<DT, VE>(y, i * VE, t);
-  }
-}
-void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
-                    const float* colw2, float scale) {
-  const int ve = col_ve(ctx, C);
-  const long nvec = (long)B * N * C / ve;
-  COL_DISPATCH(ctx, C, relu_bwd_scale_k, dim3(flat_grid(nvec)), 0, x, y, nvec, C / ve, (long)N * C / ve, roww, colw, cdt, colw2,
-               scale);
-}
-
-// ---- xc_bwd: dX1 += dXc*(1+ch); dch += sum_n dXc*X1 --------------------------------------------------
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void xc_bwd_k(const void* dXc, const void* X1, void* dX1, int N, int C, const float* ch,
-                                                int tpr, int rpp, int rpc, float* dch) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int b = blockIdx.y, tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
-  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
-  const int nvr = C / VE;
-  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
-    const int vc = vc0 + tc;
-    const bool active = tr < rpp && vc < nvr;
-    float acc[1][VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) acc[0][e] = 0.f;
-    if (active) {
-      float cv[VE];
-      ldf<VE>(ch + (long)b * C, vc * VE, cv);
-      for (int n = blockIdx.x * rpc + tr; n < n_end; n += rpp) {
-        const long o = ((long)b * N + n) * C + vc * VE;
-        float g[VE], x[VE], d[VE];
-        ldv<DT, VE>(dXc, o, g);
-        ldv<DT, VE>(X1, o, x);
-        ldv<DT, VE>(dX1, o, d);
-#pragma unroll
-        for (int e = 0; e < VE; ++e) { acc[0][e] += g[e] * x[e]; d[e] += g[e] * (1.f + cv[e]); }
-        stv<DT, VE>(dX1, o, d);
-      }
-    }
-    float* const dst[1] = {dch + (long)b * C};
-    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
-  }
-}
-void xc_bwd(const Ctx& ctx, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch) {
-  ColGeom g = col_geom(C, col_ve(ctx, C), N, B);
-  COL_DISPATCH(ctx, C, xc_bwd_k, dim3(g.chunks, B), (size_t)C * sizeof(float), dXc, X1, dX1, N, C, ch, g.tpr, g.rpp, g.rpc, dch);
+  ROW_DISPATCH(ctx, C, g.nv, rowdot_k, dim3(g.chunks, B), x, ld, bs, N, C, w, wdt, w_bs, w2, bias, g.gs, g.nv, g.rpc, out);
 }
 
 // ================================================================================================
@@ -883,6 +529,7 @@ __global__ __launch_bounds__(256) void softmax_long_k(const float* in, long ld_i
   }
 }
 static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+static inline int flat_grid(long nvec) { long g = cdiv(nvec, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 void softmax_rows(const Ctx& ctx, const float* in, long ld_in, void* out, int odt, long ld_out, long rows, int L, int pre_tanh) {
   if (rows <= 0) return;
@@ -999,18 +646,6 @@ void spatial_bwd(const Ctx& ctx, const float* sl, const float* sg, const float* 
 // ================================================================================================
 // small helpers
 // ================================================================================================
-__global__ void sum_batch_k(const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += in[(long)b * bs + i];
-  s *= scale;
-  out[i] = accumulate ? out[i] + s : s;
-}
-void sum_batch(const Ctx& ctx, const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
-  hipLaunchKernelGGL(sum_batch_k, dim3((int)cdiv(n, 256)), dim3(256), 0, STREAM(ctx), in, bs, B, n, out, scale, accumulate);
-}
-
 __global__ void ew_k(int op, void* o, int odt, const void* a, int adt, const void* b, int bdt, const void* c, int cdt, long n,
                      float s, long div) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,508 @@
+// "Column-strip" kernels of the DG-SCT adapter path for gfx950: per-channel affine maps and reductions
+// over tokens on [rows][C] token-major tensors (BatchNorm statistics / backward, channel-gate sums,
+// bias gradients, ReLU-masked cotangents).
+//
+// Mapping: a thread owns VE consecutive channels (16 B per lane when C allows it) and walks rows; the
+// per-channel parameters it needs live in registers for the whole walk.  Rows are processed UNR at a time
+// with all loads issued before the first use, so every lane keeps UNR x 16 B (x number of inputs) in
+// flight -- these kernels are pure HBM streams and latency hiding is the whole game.  Reductions are
+// combined across the row-slots of the workgroup in LDS (ds_add_f32) and leave as one fp32 atomic per
+// channel per workgroup.
+#include <hip/hip_runtime.h>
+#include "prims.h"
+#include "device_util.h"
+#include "err.h"
+
+namespace dgsct {
+
+#define STREAM(ctx) ((hipStream_t)(ctx).stream)
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+constexpr int UNR = 4;
+
+struct ColGeom { int nvr, tpr, rpp, rpc, chunks; };
+// target_wgs: ~4096 for pure streams; ~768 (3 per CU) for reductions, whose per-workgroup LDS combine + one global
+// atomic per channel must be amortised over many rows (3840 workgroups x 128 channels of atomics on 128 addresses
+// cost more than the 94 MB stream itself).
+static ColGeom col_geom(int C, int VE, long rows, int B, long target_wgs = 4096) {
+  ColGeom g;
+  g.nvr = C / VE;
+  g.tpr = imin(g.nvr, 256);
+  g.rpp = 256 / g.tpr;
+  long want = cdiv(target_wgs, B);
+  long maxc = cdiv(rows, (long)g.rpp * UNR);
+  long chunks = want < 1 ? 1 : (want > maxc ? maxc : want);
+  if (chunks < 1) chunks = 1;
+  g.rpc = (int)(cdiv(cdiv(rows, chunks), g.rpp) * g.rpp);
+  g.chunks = (int)cdiv(rows, g.rpc);
+  return g;
+}
+static inline int col_ve(const Ctx& ctx, int C) {
+  const int vmax = ctx.mode == DT_BF16 ? 8 : 4;
+  return C % vmax == 0 ? vmax : 1;
+}
+#define COL_DISPATCH(ctx, VE_, KERNEL, GRID, SHMEM, ...)                                                   \
+  do {                                                                                                      \
+    if ((ctx).mode == DT_BF16) {                                                                            \
+      if ((VE_) == 8) hipLaunchKernelGGL((KERNEL<DT_BF16, 8>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<DT_BF16, 1>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__);      \
+    } else {                                                                                                \
+      if ((VE_) == 4) hipLaunchKernelGGL((KERNEL<DT_F32, 4>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<DT_F32, 1>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__);       \
+    }                                                                                                       \
+  } while (0)
+
+// combine NQ per-thread channel accumulators across the row-slots of the workgroup; one atomic per channel
+template <int NQ, int VE>
+__device__ __forceinline__ void flush_strip(float (&acc)[NQ][VE], float* lds, int C, int col, bool active,
+                                            float* const (&dst)[NQ]) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) atomicAdd(&lds[q * C + col + e], acc[q][e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) {
+    const int q = i / C;
+    if (dst[q]) unsafeAtomicAdd(dst[q] + (i - q * C), lds[i]);
+  }
+}
+
+// Strip iteration skeleton used by every kernel below:
+//   for vc0 (column super-blocks, > 1 iteration only when C/VE > 256)
+//     thread (tc, tr): columns [vc*VE, vc*VE+VE), rows r0+tr, r0+tr+rpp, ... < r_end, UNR rows per trip.
+#define STRIP_PROLOGUE(ROWS_END_EXPR, ROW0_EXPR)                                 \
+  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;                      \
+  const int nvr = C / VE;                                                        \
+  const long r_end = (ROWS_END_EXPR);                                            \
+  const long r_begin = (ROW0_EXPR);
+
+// ---- colsum_batched --------------------------------------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void colsum_k(const void* x, long ld, long bs, int N, int C, const float* roww,
+                                                long roww_bs, float scale, int tpr, int rpp, int rpc, float* out,
+                                                long out_bs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y;
+  STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[1][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = 0.f;
+    if (active) {
+      for (long n = r_begin + tr; n < r_end; n += (long)rpp * UNR) {
+        float t[UNR][VE], rw[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long nn = n + (long)u * rpp;
+          if (nn < r_end) {
+            ldv<DT, VE>(x, (long)b * bs + nn * ld + vc * VE, t[u]);
+            rw[u] = roww ? roww[(long)b * roww_bs + nn] : 1.f;
+          } else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) t[u][e] = 0.f;
+            rw[u] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int e = 0; e < VE; ++e) acc[0][e] += rw[u] * t[u][e];
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[0][e] *= scale;
+    }
+    float* const dst[1] = {out + (long)b * out_bs};
+    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
+  }
+}
+
+void colsum_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const float* roww, long roww_bs,
+                    float scale, float* out, long out_bs) {
+  int ve = col_ve(ctx, C);
+  if (ld % ve != 0 || bs % ve != 0) ve = 1;
+  ColGeom g = col_geom(C, ve, N, B, 768);
+  COL_DISPATCH(ctx, ve, colsum_k, dim3(g.chunks, B), (size_t)C * sizeof(float), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr,
+               g.rpp, g.rpc, out, out_bs);
+}
+
+// ---- BatchNorm statistics ----------------------------------------------------------------------------
+// acc3[0..C) = shift (row 0), acc3[C..2C) += sum(x - shift), acc3[2C..3C) += sum((x - shift)^2)
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void bn_stats_k(const void* x, long rows, int C, int tpr, int rpp, int rpc, float* acc3) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[2][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+      float sft[VE];
+      ldv<DT, VE>(x, (long)vc * VE, sft);
+      if (blockIdx.x == 0 && tr == 0) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc3[vc * VE + e] = sft[e];
+      }
+      for (long r = r_begin + tr; r < r_end; r += (long)rpp * UNR) {
+        float t[UNR][VE];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long rr = r + (long)u * rpp;
+          if (rr < r_end) ldv<DT, VE>(x, rr * C + vc * VE, t[u]);
+          else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) t[u][e] = sft[e];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int e = 0; e < VE; ++e) { const float d = t[u][e] - sft[e]; acc[0][e] += d; acc[1][e] += d * d; }
+      }
+    }
+    float* const dst[2] = {acc3 + C, acc3 + 2 * C};
+    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst);
+  }
+}
+
+void bn_stats(const Ctx& ctx, const void* x, long rows, int C, float* acc) {
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(C, ve, rows, 1, 768);
+  COL_DISPATCH(ctx, ve, bn_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), x, rows, C, g.tpr, g.rpp, g.rpc, acc);
+}
+
+__global__ void bn_finalize_k(const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
+                              float* run_var, float momentum, float eps, int training, float* mean, float* rstd,
+                              float* sc, float* sh) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float m, v;
+  if (training) {
+    const float s1 = acc[C + c] / rows, s2 = acc[2 * C + c] / rows;
+    m = acc[c] + s1;
+    v = fmaxf(s2 - s1 * s1, 0.f);
+    const float unb = rows > 1 ? v * ((float)rows / (float)(rows - 1)) : v;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+  } else {
+    m = run_mean[c];
+    v = run_var[c];
+  }
+  const float rs = rsqrtf(v + eps);
+  mean[c] = m;
+  rstd[c] = rs;
+  const float s = w[c] * rs;
+  sc[c] = s;
+  sh[c] = b[c] - m * s;
+}
+
+void bn_finalize(const Ctx& ctx, const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
+                 float* run_var, float momentum, float eps, int training, float* mean, float* rstd, float* sc, float* sh) {
+  hipLaunchKernelGGL(bn_finalize_k, dim3((C + 255) / 256), dim3(256), 0, STREAM(ctx), acc, rows, C, w, b, run_mean, run_var,
+                     momentum, eps, training, mean, rstd, sc, sh);
+}
+
+// ---- per-channel affine (+relu) -----------------------------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long rows, int C, int tpr, int rpp, int rpc,
+                                                    const float* sc, const float* sh, int relu) {
+  STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    if (!(tr < rpp && vc < nvr)) continue;
+    float a[VE], bsh[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { a[e] = sc ? sc[vc * VE + e] : 1.f; bsh[e] = sc ? sh[vc * VE + e] : 0.f; }
+    for (long r = r_begin + tr; r < r_end; r += (long)rpp * UNR) {
+      float t[UNR][VE];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = r + (long)u * rpp;
+        if (rr < r_end) ldv<DT, VE>(x, rr * C + vc * VE, t[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = r + (long)u * rpp;
+        if (rr < r_end) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) { float v = t[u][e] * a[e] + bsh[e]; t[u][e] = relu ? fmaxf(v, 0.f) : v; }
+          stv<DT, VE>(y, rr * C + vc * VE, t[u]);
+        }
+      }
+    }
+  }
+}
+
+void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu) {
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(C, ve, rows, 1);
+  COL_DISPATCH(ctx, ve, affine_act_k, dim3(g.chunks), 0, x, y, rows, C, g.tpr, g.rpp, g.rpc, sc, sh, relu);
+}
+
+// ---- BatchNorm backward --------------------------------------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void* x, long rows, int C, const float* mean,
+                                                      const float* rstd, const float* sc, const float* sh, int relu,
+                                                      int tpr, int rpp, int rpc, float* sums) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[2][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+      float m[VE], rs[VE], a[VE], bsh[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { const int c = vc * VE + e; m[e] = mean[c]; rs[e] = rstd[c]; a[e] = sc[c]; bsh[e] = sh[c]; }
+      for (long r = r_begin + tr; r < r_end; r += (long)rpp * UNR) {
+        float g[UNR][VE], t[UNR][VE];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long rr = r + (long)u * rpp;
+          if (rr < r_end) { ldv<DT, VE>(dy, rr * C + vc * VE, g[u]); ldv<DT, VE>(x, rr * C + vc * VE, t[u]); }
+          else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { g[u][e] = 0.f; t[u][e] = 0.f; }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            float gg = g[u][e];
+            if (relu && !(t[u][e] * a[e] + bsh[e] > 0.f)) gg = 0.f;
+            acc[0][e] += gg;
+            acc[1][e] += gg * (t[u][e] - m[e]) * rs[e];
+          }
+      }
+    }
+    float* const dst[2] = {sums, sums + C};
+    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst);
+  }
+}
+
+void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
+                  const float* sc, const float* sh, int relu, float* sums) {
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(C, ve, rows, 1, 768);
+  COL_DISPATCH(ctx, ve, bn_bwd_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), dy, x, rows, C, mean, rstd, sc, sh, relu,
+               g.tpr, g.rpp, g.rpc, sums);
+}
+
+// dx = k1*gg - k2 - x*k3 with k1 = sc, k3 = sc*rstd*s1/R, k2 = sc*s0/R - mean*k3      (training)
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const void* dy, const void* x, void* dx, long rows, int C, int tpr,
+                                                      int rpp, int rpc, const float* mean, const float* rstd,
+                                                      const float* sc, const float* sh, const float* sums, int relu,
+                                                      int has_bn, int training) {
+  STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  const float inv = 1.f / (float)rows;
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    if (!(tr < rpp && vc < nvr)) continue;
+    float a[VE], bsh[VE], k1[VE], k2[VE], k3[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int c = vc * VE + e;
+      if (has_bn) {
+        a[e] = sc[c]; bsh[e] = sh[c]; k1[e] = sc[c];
+        if (training) { k3[e] = sc[c] * rstd[c] * sums[C + c] * inv; k2[e] = sc[c] * sums[c] * inv - mean[c] * k3[e]; }
+        else { k3[e] = 0.f; k2[e] = 0.f; }
+      } else { a[e] = 1.f; bsh[e] = 0.f; k1[e] = 1.f; k2[e] = 0.f; k3[e] = 0.f; }
+    }
+    for (long r = r_begin + tr; r < r_end; r += (long)rpp * UNR) {
+      float g[UNR][VE], t[UNR][VE];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = r + (long)u * rpp;
+        if (rr < r_end) { ldv<DT, VE>(dy, rr * C + vc * VE, g[u]); ldv<DT, VE>(x, rr * C + vc * VE, t[u]); }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = r + (long)u * rpp;
+        if (rr < r_end) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            float gg = g[u][e];
+            if (relu && !(t[u][e] * a[e] + bsh[e] > 0.f)) gg = 0.f;
+            g[u][e] = k1[e] * gg - k2[e] - t[u][e] * k3[e];
+          }
+          stv<DT, VE>(dx, rr * C + vc * VE, g[u]);
+        }
+      }
+    }
+  }
+}
+
+void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long rows, int C, const float* mean,
+                  const float* rstd, const float* sc, const float* sh, const float* sums, int relu, int has_bn, int training) {
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(C, ve, rows, 1);
+  COL_DISPATCH(ctx, ve, bn_bwd_apply_k, dim3(g.chunks), 0, dy, x, dx, rows, C, g.tpr, g.rpp, g.rpc, mean, rstd, sc, sh, sums,
+               relu, has_bn, training);
+}
+
+// ---- scale_cols: y = x * (add + colw[b][c]) -----------------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void scale_cols_k(const void* x, void* y, int N, int C, int tpr, int rpp, int rpc,
+                                                    const float* colw, float add) {
+  const int b = blockIdx.y;
+  STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    if (!(tr < rpp && vc < nvr)) continue;
+    float cw[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) cw[e] = add + colw[(long)b * C + vc * VE + e];
+    for (long n = r_begin + tr; n < r_end; n += (long)rpp * UNR) {
+      float t[UNR][VE];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long nn = n + (long)u * rpp;
+        if (nn < r_end) ldv<DT, VE>(x, ((long)b * N + nn) * C + vc * VE, t[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long nn = n + (long)u * rpp;
+        if (nn < r_end) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) t[u][e] *= cw[e];
+          stv<DT, VE>(y, ((long)b * N + nn) * C + vc * VE, t[u]);
+        }
+      }
+    }
+  }
+}
+void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* colw, float add) {
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(C, ve, N, B);
+  COL_DISPATCH(ctx, ve, scale_cols_k, dim3(g.chunks, B), 0, x, y, N, C, g.tpr, g.rpp, g.rpc, colw, add);
+}
+
+// ---- relu_bwd_scale: y = (x > 0) * roww[b][n] * colw[b][c] * colw2[c] * scale ----------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, int N, int C, int tpr, int rpp, int rpc,
+                                                        const float* roww, const void* colw, int cdt,
+                                                        const float* colw2, float scale) {
+  const int b = blockIdx.y;
+  STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    if (!(tr < rpp && vc < nvr)) continue;
+    float cw[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int c = vc * VE + e;
+      cw[e] = scale * lde_rt(colw, cdt, (long)b * C + c) * (colw2 ? colw2[c] : 1.f);
+    }
+    for (long n = r_begin + tr; n < r_end; n += (long)rpp * UNR) {
+      float t[UNR][VE], rw[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long nn = n + (long)u * rpp;
+        if (nn < r_end) {
+          ldv<DT, VE>(x, ((long)b * N + nn) * C + vc * VE, t[u]);
+          rw[u] = roww ? roww[(long)b * N + nn] : 1.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long nn = n + (long)u * rpp;
+        if (nn < r_end) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) t[u][e] = t[u][e] > 0.f ? rw[u] * cw[e] : 0.f;
+          stv<DT, VE>(y, ((long)b * N + nn) * C + vc * VE, t[u]);
+        }
+      }
+    }
+  }
+}
+void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
+                    const float* colw2, float scale) {
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(C, ve, N, B);
+  COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), 0, x, y, N, C, g.tpr, g.rpp, g.rpc, roww, colw, cdt, colw2, scale);
+}
+
+// ---- xc_bwd: dX1 += dXc*(1+ch); dch += sum_n dXc*X1 ------------------------------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void xc_bwd_k(const void* dXc, const void* X1, void* dX1, int N, int C, const float* ch,
+                                                int tpr, int rpp, int rpc, float* dch) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y;
+  STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[1][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = 0.f;
+    if (active) {
+      float cv[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) cv[e] = 1.f + ch[(long)b * C + vc * VE + e];
+      for (long n = r_begin + tr; n < r_end; n += (long)rpp * UNR) {
+        float g[UNR][VE], x[UNR][VE], d[UNR][VE];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long nn = n + (long)u * rpp;
+          if (nn < r_end) {
+            const long o = ((long)b * N + nn) * C + vc * VE;
+            ldv<DT, VE>(dXc, o, g[u]); ldv<DT, VE>(X1, o, x[u]); ldv<DT, VE>(dX1, o, d[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long nn = n + (long)u * rpp;
+          if (nn < r_end) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { acc[0][e] += g[u][e] * x[u][e]; d[u][e] += g[u][e] * cv[e]; }
+            stv<DT, VE>(dX1, ((long)b * N + nn) * C + vc * VE, d[u]);
+          }
+        }
+      }
+    }
+    float* const dst[1] = {dch + (long)b * C};
+    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
+  }
+}
+void xc_bwd(const Ctx& ctx, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch) {
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(C, ve, N, B, 768);
+  COL_DISPATCH(ctx, ve, xc_bwd_k, dim3(g.chunks, B), (size_t)C * sizeof(float), dXc, X1, dX1, N, C, ch, g.tpr, g.rpp, g.rpc, dch);
+}
+
+// ---- sum over the batch axis of small fp32 tensors: out[i] (+)= scale * sum_b in[b*bs + i] ---------------
+// grid (n/256, batch slices); every slice adds its partial with one atomic, so `out` must hold the value to
+// accumulate onto (zero for a plain sum: the callers' gradient buffer is pre-zeroed).
+__global__ __launch_bounds__(256) void sum_batch_k(const float* in, long bs, int B, long n, float* out, float scale, int bper) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int b0 = blockIdx.y * bper, b1 = imin_d(B, b0 + bper);
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) s += in[(long)b * bs + i];
+  unsafeAtomicAdd(out + i, s * scale);
+}
+void sum_batch(const Ctx& ctx, const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
+  if (!accumulate) (void)hipMemsetAsync(out, 0, (size_t)n * sizeof(float), STREAM(ctx));
+  const int bx = (int)cdiv(n, 256);
+  int slices = (int)cdiv(1024, bx);
+  if (slices > B) slices = B;
+  if (slices < 1) slices = 1;
+  const int bper = (int)cdiv(B, slices);
+  slices = (int)cdiv(B, bper);
+  hipLaunchKernelGGL(sum_batch_k, dim3(bx, slices), dim3(256), 0, STREAM(ctx), in, bs, B, n, out, scale, bper);
+}
+
+}  // namespace dgsct

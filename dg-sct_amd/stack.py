@@ -43,8 +43,10 @@ class AdapterStack(nn.Module):
     """4 x L adapters (audio/visual x p1/p2) in the reference's ModuleLists, plus the layer loop."""
 
     def __init__(self, stages: Sequence[Dict[str, int]], opt: Optional[SimpleNamespace] = None, flavour: str = "ave",
-                 compute_dtype: Optional[torch.dtype] = None, lib=None):
+                 compute_dtype: Optional[torch.dtype] = None, lib=None, concurrent: bool = True):
         super().__init__()
+        self.concurrent = concurrent
+        self._side_streams = {}
         self.opt = opt or default_opt()
         o = self.opt
         self.stages = [dict(s) for s in stages]
@@ -84,18 +86,39 @@ class AdapterStack(nn.Module):
         outs = []
         idx = 0
         maps = (None, None)
+        # The audio and the visual adapter of a position read the same pre-block maps and are independent
+        # (net_trans.py:891-892): run them on two HIP streams so the many small kernels of the late stages overlap.
+        # autograd replays each backward on the stream of its forward, so backward overlaps the same way.
+        dev = feats[0][0].device
+        side = None
+        if self.concurrent and dev.type == "cuda":
+            side = self._side_streams.get(dev.index)
+            if side is None:
+                side = self._side_streams[dev.index] = torch.cuda.Stream(device=dev)
+
+        def pair(audio_mod, vis_mod, f_a, f_v):
+            if side is None:
+                a = audio_mod(self._view(f_a), self._view(f_v))
+                v = vis_mod(self._view(f_v), self._view(f_a))
+                return a, v
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                a = audio_mod(self._view(f_a), self._view(f_v))
+            v = vis_mod(self._view(f_v), self._view(f_a))
+            main.wait_stream(side)
+            return a, v
+
         for s, (f_v, f_a) in zip(self.stages, feats):
             for _ in range(s["layers"]):
-                a_res, _ = self.audio_adapter_blocks_p1[idx](self._view(f_a), self._view(f_v))[:2]
-                v_res, _ = self.vis_adapter_blocks_p1[idx](self._view(f_v), self._view(f_a))[:2]
+                (a_res, _), (v_res, _) = [r[:2] for r in pair(self.audio_adapter_blocks_p1[idx], self.vis_adapter_blocks_p1[idx], f_a, f_v)]
                 if vis_block is not None:
                     f_v = f_v + vis_block(idx, 0, f_v)
                 f_v = f_v + v_res.squeeze(-1).permute(0, 2, 1)
                 if aud_block is not None:
                     f_a = aud_block(idx, f_a)
                 f_a = f_a + a_res.squeeze(-1).permute(0, 2, 1)
-                a_res, a_map = self.audio_adapter_blocks_p2[idx](self._view(f_a), self._view(f_v))[:2]
-                v_res, v_map = self.vis_adapter_blocks_p2[idx](self._view(f_v), self._view(f_a))[:2]
+                (a_res, a_map), (v_res, v_map) = [r[:2] for r in pair(self.audio_adapter_blocks_p2[idx], self.vis_adapter_blocks_p2[idx], f_a, f_v)]
                 if vis_block is not None:
                     f_v = f_v + vis_block(idx, 1, f_v)
                 f_v = f_v + v_res.squeeze(-1).permute(0, 2, 1)

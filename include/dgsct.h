@@ -142,6 +142,13 @@ typedef struct dgsct_gemm_args {
 } dgsct_gemm_args;
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream);
 
+/* ---- measurement hook (bench.py roofline leg) ---------------------------------------------------
+ * While enabled, every launch of the MFMA GEMM family issued from the calling thread is bracketed by
+ * HIP events on its own stream; collect() synchronises them and returns the number of launches, the sum
+ * of their durations and the sum of their useful FLOPs (2*M*N*K per batch), then clears the log. */
+int dgsct_prof_enable(int on);
+int dgsct_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,9 +10,22 @@ from dgsct_amd._lib import PARAM_NAMES, default_lib
 from oracle import dgsct_oracle as O
 
 
+def synth(N, C, No, Co, tk, BT, seed=3):
+    import dataclasses
+    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=tk, r=8, g=2)
+    p = O.random_params(cfg, "ave", seed=seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    r = lambda *s: torch.randn(*s, generator=gen).bfloat16().float()
+    return dict(cfg=dataclasses.asdict(cfg), state0=p, X=r(BT, N, C), Y=r(BT, No, Co), dOut=r(BT, N, C),
+                dMap=torch.randn(BT, N, generator=gen), dTmap=None)
+
+
 def main(name="ave_orderA", dtype=torch.float32):
     lib = default_lib()
-    fx = load_golden(name)
+    if name.startswith("synth:"):
+        fx = synth(*[int(x) for x in name[6:].split(",")])
+    else:
+        fx = load_golden(name)
     dev = torch.device("cuda:0")
     spec = spec_of(fx["cfg"])
     cfg = oracle_cfg(fx["cfg"])
