@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-optim", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no audio/visual adapter overlap)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,26 +162,74 @@ def main():
         import torch.distributed as dist
         for p in stack.parameters():
             dist.broadcast(p.data, 0)
-    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack)) if world > 1 else None
-    opt = None if args.no_optim else torch.optim.Adam(params, lr=1e-5)
+    # N > 1: gradients are reduced after backward (buckets launched back-to-back on a side stream, RCCL), outside the
+    # captured graph -- collectives are kept out of the capture on purpose.
+    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack), overlap=False) if world > 1 else None
+    use_graph = not args.no_graph
+    opt = None if args.no_optim else torch.optim.Adam(params, lr=1e-5, capturable=use_graph)
     feats, cots, mcots = make_inputs(stages, BT, dtype, device, seed=1 + rank)
 
-    def step():
+    def fwd_bwd():
         outs, maps = stack(feats)
         tensors = [t for pair in outs for t in pair] + [maps[0], maps[1]]
         grads = [g for pair in cots for g in pair] + [mcots[0], mcots[1]]
         torch.autograd.backward(tensors, grads)
-        if reducer is not None:
-            reducer.finish()
-        if opt is not None:
-            opt.step()
-            opt.zero_grad(set_to_none=True)
-        else:
-            for p in params:
-                p.grad = None
         for fv, fa in feats:
             fv.grad = None
             fa.grad = None
+
+    def update():
+        if opt is not None:
+            opt.step()
+            opt.zero_grad(set_to_none=world == 1)
+        elif world == 1:
+            for p in params:
+                p.grad = None
+        else:
+            for p in params:
+                if p.grad is not None:
+                    p.grad.zero_()
+
+    graphs = []
+
+    def capture(fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        graphs.append(g)
+        return g.replay
+
+    def eager_step():
+        fwd_bwd()
+        if reducer is not None:
+            reducer.finish()
+        update()
+
+    step = eager_step
+    if use_graph:
+        # One HIP graph per step: ~6000 kernel launches (48 adapters x ~125 kernels) replayed with a single
+        # hipGraphLaunch, so the host is out of the critical path (eager: ~100 ms of host enqueue per step).
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                eager_step()            # allocator + optimizer-state warm-up, as torch.cuda.graphs requires
+        torch.cuda.current_stream(device).wait_stream(s)
+        torch.cuda.synchronize()
+        if world == 1:
+            def whole():
+                fwd_bwd()
+                update()
+            step = capture(whole)
+        else:
+            for p in params:            # static .grad buffers: backward accumulates into them inside the graph
+                p.grad = torch.zeros_like(p) if p.grad is None else p.grad.zero_()
+            g_fb = capture(fwd_bwd)
+
+            def step():
+                g_fb()
+                reducer.finish()
+                update()                # zero_grad(set_to_none=False): keeps the captured buffers
 
     def barrier():
         if world > 1:
@@ -192,8 +241,11 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         step()
+        host_s += time.perf_counter() - h0
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -212,7 +264,7 @@ def main():
         lib.prof_enable(True)
         nprof = 2
         for _ in range(nprof):
-            step()
+            eager_step()                 # eager launches: the library brackets each GEMM launch with HIP events
         torch.cuda.synchronize()
         launches, gemm_ms, gemm_flops = lib.prof_collect()
         lib.prof_enable(False)
@@ -239,7 +291,8 @@ def main():
             config=dict(workload=f"AVE fine-tune adapter stack (BASELINE configs[1]): {args.backbone} + HTS-AT token/width "
                                  f"shapes, 48 DG-SCT adapters, B={args.batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on",
                         global_batch=args.batch * world, frames_per_clip=T, parallelism=f"dp{world}",
-                        step="fwd+bwd" + ("+allreduce" if world > 1 else "") + ("" if args.no_optim else "+adam")),
+                        step="fwd+bwd" + ("+allreduce" if world > 1 else "") + ("" if args.no_optim else "+adam"),
+                        streams=1 if args.serial else 2, hip_graph=use_graph, host_enqueue_ms_per_step=round(host_s / args.steps * 1e3, 2)),
             roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -194,8 +194,16 @@ void Plan::layout() {
     gr(DGSCT_P_WCATT, (int64_t)C * dd); gr(DGSCT_P_BCATT, C);
     gr(DGSCT_P_WD, (int64_t)ds * (C / g));
     gr(DGSCT_P_WU, (int64_t)C * (ds / g));
-    gr(DGSCT_P_BN1_W, ds, d.use_bn); gr(DGSCT_P_BN1_B, ds, d.use_bn);
-    gr(DGSCT_P_BN2_W, C, d.use_bn); gr(DGSCT_P_BN2_B, C, d.use_bn);
+    // BatchNorm gradients are laid out [d bias | d weight] back to back: that is exactly the [sum dy | sum dy*xhat]
+    // pair the BN-backward reductions accumulate, so the kernels write the parameter gradients in place.
+    auto gr_bn = [&](int idw, int idb, int64_t n) {
+      if (!d.use_bn) return;
+      grad_off[idb] = off; grad_numel[idb] = n;
+      grad_off[idw] = off + n; grad_numel[idw] = n;
+      off += rup(2 * n, 4);
+    };
+    gr_bn(DGSCT_P_BN1_W, DGSCT_P_BN1_B, ds);
+    gr_bn(DGSCT_P_BN2_W, DGSCT_P_BN2_B, C);
     gr(DGSCT_P_LNB_W, C, d.ln_before); gr(DGSCT_P_LNB_B, C, d.ln_before);
     gr(DGSCT_P_LNP_W, C, d.ln_post); gr(DGSCT_P_LNP_B, C, d.ln_post);
     gr(DGSCT_P_WT, C, d.temporal); gr(DGSCT_P_BT, 1, d.temporal);
@@ -241,24 +249,28 @@ struct Bound {
 int Plan::prepare(float* const* params, void* prep, void* stream) const {
   Ctx ctx{stream, E};
   char* p = (char*)prep;
+  CvtSeg segs[CVT_MAX_SEG];
+  int ns = 0;
   if (E == DT_BF16)
     for (int i = 0; i < DGSCT_P_COUNT; ++i)
       if (prep_w[i] >= 0) {
         if (!params[i]) { set_error("dgsct_prepare: parameter %d is NULL", i); return 2; }
-        cvt(ctx, params[i], p + prep_w[i], E, wnumel[i]);
+        segs[ns++] = CvtSeg{params[i], p + prep_w[i], (long)wnumel[i], E};
       }
   float* rowb = (float*)(p + prep_rowb);
   float* colb = (float*)(p + prep_colb);
   float* colb2 = (float*)(p + prep_colb2);
   if (d.remap == DGSCT_REMAP_CONV) {
     // Yp = Wn.Y.Wc^T + bn (x) rowsum(Wc) + 1 (x) bc                       (net_trans.py:553-554)
-    ew(ctx, EW_COPY, rowb, DT_F32, F32(params[DGSCT_P_BN]), NOARG, NOARG, N, 0.f, 1);
+    segs[ns++] = CvtSeg{params[DGSCT_P_BN], rowb, (long)N, DT_F32};
+    segs[ns++] = CvtSeg{params[DGSCT_P_BC], colb2, (long)C, DT_F32};
+    cvt_multi(ctx, segs, ns);
     rowsum_f32(ctx, params[DGSCT_P_WC], C, Co, colb);
-    ew(ctx, EW_COPY, colb2, DT_F32, F32(params[DGSCT_P_BC]), NOARG, NOARG, C, 0.f, 1);
   } else {
     // Yp = Wfix.(Y.Wc^T + bc) = Wfix.Y.Wc^T + rowsum(Wfix) (x) bc        (PVT_AVSModel.py:190-197)
+    segs[ns++] = CvtSeg{params[DGSCT_P_BC], colb, (long)C, DT_F32};
+    cvt_multi(ctx, segs, ns);
     rowsum_f32(ctx, params[DGSCT_P_WN], N, No, rowb);
-    ew(ctx, EW_COPY, colb, DT_F32, F32(params[DGSCT_P_BC]), NOARG, NOARG, C, 0.f, 1);
     zero(ctx, colb2, (size_t)C * 4);
   }
   return has_error() ? 1 : 0;
@@ -430,13 +442,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   tail_bwd(ctx, dOut, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr, bn2, bn2 + C,
            d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
            d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, b.S<float>(s.mu_p), b.S<float>(s.rstd_p), R, C,
-           dO, G(DGSCT_P_LNP_W), G(DGSCT_P_LNP_B), G(DGSCT_P_GATE), d.use_bn ? b.Wk<float>(wb.bnsums2) : nullptr);
+           dO, G(DGSCT_P_LNP_W), G(DGSCT_P_LNP_B), G(DGSCT_P_GATE), d.use_bn ? G(DGSCT_P_BN2_B) : nullptr);
   // B10 ---- BN2 backward, up projection
   if (d.use_bn) {
-    bn_bwd_apply(ctx, dO, b.S(s.Op), dO, R, C, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C, b.Wk<float>(wb.bnsums2), 0, 1,
-                 d.training);
-    ew(ctx, EW_COPY, G(DGSCT_P_BN2_B), DT_F32, F32(b.Wk<float>(wb.bnsums2)), NOARG, NOARG, C, 0.f, 1);
-    ew(ctx, EW_COPY, G(DGSCT_P_BN2_W), DT_F32, F32(b.Wk<float>(wb.bnsums2) + C), NOARG, NOARG, C, 0.f, 1);
+    bn_bwd_apply(ctx, dO, b.S(s.Op), dO, R, C, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C, G(DGSCT_P_BN2_B), 0, 1, d.training);
   }
   {
     Gemm g1 = mk(cg, dg, (int)R, g);                             // dWu = dOp^T (x)_g Z
@@ -454,11 +463,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B9 ---- relu, BN1 backward, down projection
   void* dZ = b.Wk(wb.dZ);
   if (d.use_bn) {
-    bn_bwd_stats(ctx, dZ, b.S(s.Zp), R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, 1, b.Wk<float>(wb.bnsums1));
-    bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, b.Wk<float>(wb.bnsums1), 1, 1,
-                 d.training);
-    ew(ctx, EW_COPY, G(DGSCT_P_BN1_B), DT_F32, F32(b.Wk<float>(wb.bnsums1)), NOARG, NOARG, ds, 0.f, 1);
-    ew(ctx, EW_COPY, G(DGSCT_P_BN1_W), DT_F32, F32(b.Wk<float>(wb.bnsums1) + ds), NOARG, NOARG, ds, 0.f, 1);
+    bn_bwd_stats(ctx, dZ, b.S(s.Zp), R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, 1, G(DGSCT_P_BN1_B));
+    bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, G(DGSCT_P_BN1_B), 1, 1, d.training);
   } else {
     bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0);
   }
@@ -489,7 +495,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     sum_batch(ctx, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 1);                 // dws
     ew(ctx, EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd);
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
-    relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f);
+    relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
+                   G(DGSCT_P_BV2));
     Gemm g1 = mk((int)R, C, dd);                                 // dXc = dvq2 . Wv2
     g1.A = km(b.S(s.vq2), dd);
     g1.B = mn(b.W(DGSCT_P_WV2), C);
@@ -501,7 +508,6 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g2, G(DGSCT_P_WV2), C);
     atomic_out(g2);
     gemm(ctx, g2);
-    colsum_batched(ctx, b.S(s.vq2), dd, 0, 1, (int)R, dd, nullptr, 0, 1.f, G(DGSCT_P_BV2), 0);
     xc_bwd(ctx, b.Wk(wb.dXc), b.S(s.X1), dX1, B, N, C, b.S<float>(s.ch), b.Wk<float>(wb.dch));
   }
   // B6 ---- channel-gate head
@@ -531,7 +537,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   }
   // B5 ---- video query 1
   {
-    relu_bwd_scale(ctx, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N);
+    relu_bwd_scale(ctx, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N,
+                   G(DGSCT_P_BV1));
     Gemm g1 = mk((int)R, C, C);                                  // dX1 += dvq1 . Wv1
     g1.A = km(b.S(s.vq1), C); g1.B = mn(b.W(DGSCT_P_WV1), C);
     resid(g1, dX1, E, C);
@@ -542,7 +549,6 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g2, G(DGSCT_P_WV1), C);
     atomic_out(g2);
     gemm(ctx, g2);
-    colsum_batched(ctx, b.S(s.vq1), C, 0, 1, (int)R, C, nullptr, 0, 1.f, G(DGSCT_P_BV1), 0);
   }
   // B4 ---- audio queries
   {
@@ -602,6 +608,13 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g4, b.Wk<float>(wb.dtokF), C, (long)tk * C);
     gemm(ctx, g4);
     cvt(ctx, b.Wk<float>(wb.dtokF), b.Wk(wb.dtokE), E, (long)B * tk * C);
+    if (d.remap == DGSCT_REMAP_CONV) {
+      // d fc.bias = sum_{b,n} dYp[b,n,:].  Softmax rows sum to 1 and dS1 rows sum to 0, so this equals
+      // sum_b (sum_t dtok[b,t,:] + da[b,:]) exactly -- computed from these two small fp32 tensors instead of
+      // re-reducing the big bf16-rounded dYp (a cancellation-heavy sum: 30 % relative error in bf16 otherwise).
+      sum_batch(ctx, b.Wk<float>(wb.dtokF), C, B * tk, C, G(DGSCT_P_BC), 1.f, 1);
+      sum_batch(ctx, b.Wk<float>(wb.da), C, B, C, G(DGSCT_P_BC), 1.f, 1);
+    }
   }
   // B2 ---- tokens <- remapped tokens attention
   void* dYp = b.Wk(wb.dYp);
@@ -638,7 +651,6 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   {
     const bool conv = d.remap == DGSCT_REMAP_CONV;
     if (conv) {
-      colsum_batched(ctx, dYp, C, 0, 1, (int)R, C, nullptr, 0, 1.f, G(DGSCT_P_BC), 0);                    // dbc
       rowdot_batched(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
       sum_batch(ctx, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                             // dbn
       colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);    // d rowsum(Wc)

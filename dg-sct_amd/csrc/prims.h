@@ -78,8 +78,9 @@ void sum_batch(const Ctx&, const float* in, long bs, int B, long n, float* out, 
 // y[b][n][c] = x[b][n][c] * (add + colw[b][c])         x,y are E (may alias)
 void scale_cols(const Ctx&, const void* x, void* y, int B, int N, int C, const float* colw, float add);
 // y[b][n][c] = (x[b][n][c] > 0) * (roww ? roww[b][n] : 1) * colw[b][c] * (colw2 ? colw2[c] : 1) * scale     x,y E (may alias)
+// If colsum_out: colsum_out[c] += sum_{b,n} y[b][n][c]  (the bias gradient of the layer whose pre-activation x masks).
 void relu_bwd_scale(const Ctx&, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
-                    const float* colw2, float scale);
+                    const float* colw2, float scale, float* colsum_out);
 // dX1[b][n][c] += dXc[b][n][c] * (1 + ch[b][c]);  dch[b][c] += sum_n dXc * X1        (all big tensors E, dch pre-initialised)
 void xc_bwd(const Ctx&, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch);
 
@@ -140,6 +141,10 @@ void ew(const Ctx&, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n,
 void temporal_fwd(const Ctx&, const float* a, const float* wt, const float* bt, int B, int C, float* tg);
 // out[i] = (E) in[i]   i < n, for weights: fp32 master -> E copy
 void cvt(const Ctx&, const float* in, void* out, int odt, long n);
+// Up to CVT_MAX_SEG independent fp32 -> odt[i] copies in ONE launch (all weight casts of dgsct_prepare).
+constexpr int CVT_MAX_SEG = 16;
+struct CvtSeg { const float* src; void* dst; long n; int odt; };
+void cvt_multi(const Ctx&, const CvtSeg* segs, int nseg);
 // out[r] = sum_c W[r][c]  (fp32 [R][C] -> fp32 [R])
 void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out);
 

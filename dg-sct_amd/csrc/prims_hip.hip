@@ -688,6 +688,30 @@ void cvt(const Ctx& ctx, const float* in, void* out, int odt, long n) {
   hipLaunchKernelGGL(cvt_k, dim3(flat_grid(n)), dim3(256), 0, STREAM(ctx), in, out, odt, n);
 }
 
+struct CvtTable { CvtSeg seg[CVT_MAX_SEG]; long first_block[CVT_MAX_SEG + 1]; int nseg; };
+__global__ __launch_bounds__(256) void cvt_multi_k(const CvtTable t) {
+  int s = 0;
+  while (s + 1 < t.nseg && (long)blockIdx.x >= t.first_block[s + 1]) ++s;
+  const CvtSeg sg = t.seg[s];
+  const long base = ((long)blockIdx.x - t.first_block[s]) * 2048;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long i = base + k * 256 + threadIdx.x;
+    if (i < sg.n) ste_rt(sg.dst, sg.odt, i, sg.src[i]);
+  }
+}
+void cvt_multi(const Ctx& ctx, const CvtSeg* segs, int nseg) {
+  if (nseg <= 0) return;
+  if (nseg > CVT_MAX_SEG) { set_error("cvt_multi: too many segments"); return; }
+  CvtTable t;
+  long blocks = 0;
+  t.nseg = nseg;
+  for (int s = 0; s < nseg; ++s) { t.seg[s] = segs[s]; t.first_block[s] = blocks; blocks += cdiv(segs[s].n, 2048); }
+  t.first_block[nseg] = blocks;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(cvt_multi_k, dim3((int)blocks), dim3(256), 0, STREAM(ctx), t);
+}
+
 __global__ __launch_bounds__(64) void rowsum_f32_k(const float* W, int C, float* out) {
   const int r = blockIdx.x;
   float s = 0.f;

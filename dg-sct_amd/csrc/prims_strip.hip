@@ -390,49 +390,64 @@ void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, con
   COL_DISPATCH(ctx, ve, scale_cols_k, dim3(g.chunks, B), 0, x, y, N, C, g.tpr, g.rpp, g.rpc, colw, add);
 }
 
-// ---- relu_bwd_scale: y = (x > 0) * roww[b][n] * colw[b][c] * colw2[c] * scale ----------------------------
+// ---- relu_bwd_scale: y = (x > 0) * roww[b][n] * colw[b][c] * colw2[c] * scale; optional colsum_out[c] += sum y ------
 template <int DT, int VE>
 __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, int N, int C, int tpr, int rpp, int rpc,
                                                         const float* roww, const void* colw, int cdt,
-                                                        const float* colw2, float scale) {
+                                                        const float* colw2, float scale, float* colsum_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y;
   STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
   for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
     const int vc = vc0 + tc;
-    if (!(tr < rpp && vc < nvr)) continue;
-    float cw[VE];
+    const bool active = tr < rpp && vc < nvr;
+    float acc[1][VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      const int c = vc * VE + e;
-      cw[e] = scale * lde_rt(colw, cdt, (long)b * C + c) * (colw2 ? colw2[c] : 1.f);
+    for (int e = 0; e < VE; ++e) acc[0][e] = 0.f;
+    if (active) {
+      float cw[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const int c = vc * VE + e;
+        cw[e] = scale * lde_rt(colw, cdt, (long)b * C + c) * (colw2 ? colw2[c] : 1.f);
+      }
+      for (long n = r_begin + tr; n < r_end; n += (long)rpp * UNR) {
+        float t[UNR][VE], rw[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long nn = n + (long)u * rpp;
+          if (nn < r_end) {
+            ldv<DT, VE>(x, ((long)b * N + nn) * C + vc * VE, t[u]);
+            rw[u] = roww ? roww[(long)b * N + nn] : 1.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long nn = n + (long)u * rpp;
+          if (nn < r_end) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) t[u][e] = t[u][e] > 0.f ? rw[u] * cw[e] : 0.f;
+            stv<DT, VE>(y, ((long)b * N + nn) * C + vc * VE, t[u]);
+            if (colsum_out) {      // sum what was STORED (the rounded values the weight-gradient GEMM will read)
+#pragma unroll
+              for (int e = 0; e < VE; ++e) acc[0][e] += DT == DT_BF16 ? bf2f(f2bf(t[u][e])) : t[u][e];
+            }
+          }
+        }
+      }
     }
-    for (long n = r_begin + tr; n < r_end; n += (long)rpp * UNR) {
-      float t[UNR][VE], rw[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const long nn = n + (long)u * rpp;
-        if (nn < r_end) {
-          ldv<DT, VE>(x, ((long)b * N + nn) * C + vc * VE, t[u]);
-          rw[u] = roww ? roww[(long)b * N + nn] : 1.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const long nn = n + (long)u * rpp;
-        if (nn < r_end) {
-#pragma unroll
-          for (int e = 0; e < VE; ++e) t[u][e] = t[u][e] > 0.f ? rw[u] * cw[e] : 0.f;
-          stv<DT, VE>(y, ((long)b * N + nn) * C + vc * VE, t[u]);
-        }
-      }
+    if (colsum_out) {
+      float* const dst[1] = {colsum_out};
+      flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
     }
   }
 }
 void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
-                    const float* colw2, float scale) {
+                    const float* colw2, float scale, float* colsum_out) {
   const int ve = col_ve(ctx, C);
-  ColGeom g = col_geom(C, ve, N, B);
-  COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), 0, x, y, N, C, g.tpr, g.rpp, g.rpc, roww, colw, cdt, colw2, scale);
+  ColGeom g = col_geom(C, ve, N, B, colsum_out ? 1024 : 4096);
+  COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), (size_t)C * sizeof(float), x, y, N, C, g.tpr, g.rpp, g.rpc, roww,
+               colw, cdt, colw2, scale, colsum_out);
 }
 
 // ---- xc_bwd: dX1 += dXc*(1+ch); dch += sum_n dXc*X1 ------------------------------------------------------

@@ -126,7 +126,7 @@ void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, con
 }
 
 void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
-                    const float* colw2, float scale) {
+                    const float* colw2, float scale, float* colsum_out) {
   for (int b = 0; b < B; ++b)
     for (int n = 0; n < N; ++n)
       for (int c = 0; c < C; ++c) {
@@ -135,6 +135,7 @@ void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C,
         if (ld(x, ctx.mode, o) > 0.f)
           v = (roww ? roww[(long)b * N + n] : 1.f) * scale * ld(colw, cdt, (long)b * C + c) * (colw2 ? colw2[c] : 1.f);
         st(y, ctx.mode, o, v);
+        if (colsum_out) colsum_out[c] += ld(y, ctx.mode, o);
       }
 }
 
@@ -380,6 +381,10 @@ void temporal_fwd(const Ctx&, const float* a, const float* wt, const float* bt, 
 }
 
 void cvt(const Ctx&, const float* in, void* out, int odt, long n) { for (long i = 0; i < n; ++i) st(out, odt, i, in[i]); }
+
+void cvt_multi(const Ctx&, const CvtSeg* segs, int nseg) {
+  for (int s = 0; s < nseg; ++s) for (long i = 0; i < segs[s].n; ++i) st(segs[s].dst, segs[s].odt, i, segs[s].src[i]);
+}
 
 void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out) {
   for (int r = 0; r < R; ++r) { double s = 0; for (int c = 0; c < C; ++c) s += W[(long)r * C + c]; out[r] = (float)s; }
