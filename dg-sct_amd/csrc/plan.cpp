@@ -54,7 +54,7 @@ bool Plan::validate() {
   if (C % 4 || C > 1536) return bad("C must be a multiple of 4 and <= 1536");
   if (dd % 4) return bad("C/2 must be a multiple of 4");
   if (tk > 64) return bad("tk must be <= 64");
-  if (d.T > 0 && B % d.T) return bad("BT must be a multiple of T");
+  if (d.temporal && d.T > 0 && B % d.T) return bad("BT must be a multiple of T (temporal gate)");
   if (E != DT_F32 && E != DT_BF16) return bad("dtype");
   if (d.remap != DGSCT_REMAP_CONV && d.remap != DGSCT_REMAP_FIXED) return bad("remap");
   return true;

@@ -243,6 +243,79 @@ def fd_check(ref, cfg, X, Y, dOut, dMap, dTmap):
     return err
 
 
+STACK_STAGES = [dict(layers=1, Nv=16, Cv=32, Na=36, Ca=16), dict(layers=2, Nv=9, Cv=48, Na=16, Ca=32)]
+
+
+def make_stack_fixture(seed=500):
+    """a-10: the AVE layer loop (net_trans.py:880-916) over reference adapters with identity backbone
+    blocks, two tiny stages.  Outputs, last spatial maps, input gradients and every parameter gradient."""
+    cls = load_reference_class("ave")
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=4)
+    torch.manual_seed(seed)
+    hidden, hidden_a, conv, conv_a = [], [], [], []
+    for st in STACK_STAGES:
+        for _ in range(st["layers"]):
+            hidden.append(st["Cv"]); hidden_a.append(st["Ca"]); conv.append(st["Nv"]); conv_a.append(st["Na"])
+
+    def audio(i):
+        return cls(input_dim=hidden_a[i], output_dim=hidden_a[i], adapter_kind="bottleneck", dim_list=hidden_a, layer_idx=i,
+                   reduction_factor=8, opt=opt, use_bn=True, use_gate=True, num_tk=4, conv_dim_in=conv[i],
+                   conv_dim_out=conv_a[i], linear_in=hidden[i], linear_out=hidden_a[i])
+
+    def visual(i):
+        return cls(input_dim=hidden[i], output_dim=hidden[i], adapter_kind="bottleneck", dim_list=hidden, layer_idx=i,
+                   reduction_factor=8, opt=opt, use_bn=True, use_gate=True, num_tk=4, conv_dim_in=conv_a[i],
+                   conv_dim_out=conv[i], linear_in=hidden_a[i], linear_out=hidden[i])
+
+    n = len(hidden)
+    net = nn.Module()
+    net.audio_adapter_blocks_p1 = nn.ModuleList([audio(i) for i in range(n)])
+    net.vis_adapter_blocks_p1 = nn.ModuleList([visual(i) for i in range(n)])
+    net.audio_adapter_blocks_p2 = nn.ModuleList([audio(i) for i in range(n)])
+    net.vis_adapter_blocks_p2 = nn.ModuleList([visual(i) for i in range(n)])
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, v in net.named_parameters():
+            if k.endswith(".gate"):
+                v.fill_(0.7)
+            elif k.endswith(".gate_av"):
+                v.fill_(0.3)
+    state0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    BT = 10
+    feats = [(torch.randn(BT, st["Nv"], st["Cv"], generator=gen), torch.randn(BT, st["Na"], st["Ca"], generator=gen))
+             for st in STACK_STAGES]
+    cots = [(torch.randn(BT, st["Nv"], st["Cv"], generator=gen), torch.randn(BT, st["Na"], st["Ca"], generator=gen))
+            for st in STACK_STAGES]
+    mcots = (torch.randn(BT, 1, STACK_STAGES[-1]["Nv"], generator=gen), torch.randn(BT, 1, STACK_STAGES[-1]["Na"], generator=gen))
+    nn.BatchNorm2d.forward = _bn_forward_workaround
+    net.train()
+    leaves = [(a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for a, b in feats]
+    view = lambda f: f.permute(0, 2, 1).unsqueeze(-1)
+    outs, idx = [], 0
+    for st, (f_v, f_a) in zip(STACK_STAGES, leaves):
+        for _ in range(st["layers"]):
+            a_res, _ = net.audio_adapter_blocks_p1[idx](view(f_a), view(f_v))
+            v_res, _ = net.vis_adapter_blocks_p1[idx](view(f_v), view(f_a))
+            f_v = f_v + v_res.squeeze(-1).permute(0, 2, 1)           # frozen Swin / HTS-AT half-blocks: identity stand-ins
+            f_a = f_a + a_res.squeeze(-1).permute(0, 2, 1)
+            a_res, a_map = net.audio_adapter_blocks_p2[idx](view(f_a), view(f_v))
+            v_res, v_map = net.vis_adapter_blocks_p2[idx](view(f_v), view(f_a))
+            f_v = f_v + v_res.squeeze(-1).permute(0, 2, 1)
+            f_a = f_a + a_res.squeeze(-1).permute(0, 2, 1)
+            idx += 1
+        outs.append((f_v, f_a))
+    tensors = [t for pr in outs for t in pr] + [v_map, a_map]
+    grads = [g for pr in cots for g in pr] + [mcots[0], mcots[1]]
+    torch.autograd.backward(tensors, grads)
+    nn.BatchNorm2d.forward = _BN_FORWARD
+    fx = dict(stages=STACK_STAGES, state0=state0, feats=feats, cots=cots, mcots=mcots,
+              outs=[(a.detach().clone(), b.detach().clone()) for a, b in outs],
+              maps=(v_map.detach().clone(), a_map.detach().clone()),
+              dfeats=[(a.grad.clone(), b.grad.clone()) for a, b in leaves],
+              grads={k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None})
+    return fx
+
+
 def dataclass_dict(cfg):
     import dataclasses
     return dataclasses.asdict(cfg)
@@ -261,6 +334,11 @@ def main():
                             bytes=os.path.getsize(path))
         print(f"{name:22s} worst |oracle-reference| = {worst:.2e} over {len(errs)} tensors; "
               f"no-grad params: {fx['none_grads']}; {os.path.getsize(path)} B")
+    fx = make_stack_fixture()
+    path = os.path.join(outdir, "stack_2stage.pt")
+    torch.save(fx, path)
+    report["stack_2stage"] = dict(bytes=os.path.getsize(path), n_param_grads=len(fx["grads"]))
+    print(f"stack_2stage           AVE layer loop over 12 reference adapters, identity backbone; {os.path.getsize(path)} B")
     json.dump(report, open(os.path.join(outdir, "VALIDATION.json"), "w"), indent=1)
 
 

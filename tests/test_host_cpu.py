@@ -1,0 +1,166 @@
+"""CPU-only: host logic around the C ABI -- exported symbols, the nn.Module drop-in surface (names, shapes, errors),
+the AVE layer-loop schedule against the reference-generated stack fixture (through the host-emulated primitives), and
+the data-parallel gradient all-reduce with world_size 2 over gloo."""
+import ctypes
+import os
+import re
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import GOLDEN, ROOT, load_golden, rel_err
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+from build_emu import build_emu  # noqa: E402
+
+import dgsct_amd  # noqa: E402
+from dgsct_amd import AdapterStack, GradAllReducer, VisualAdapter  # noqa: E402
+from dgsct_amd._lib import LIB_PATH, Lib  # noqa: E402
+from dgsct_amd.stack import default_opt  # noqa: E402
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "dgsct.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(dgsct_[a-z_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_are_exported():
+    syms = _declared_symbols()
+    assert {"dgsct_query", "dgsct_prepare", "dgsct_adapter_forward", "dgsct_adapter_backward"} <= set(syms)
+    if not os.path.exists(LIB_PATH):
+        pytest.skip("libdgsct.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(LIB_PATH)              # loads without a GPU; no compute call is made
+    for s in syms:
+        assert hasattr(lib, s), f"libdgsct.so does not export {s}"
+    lib.dgsct_arch.restype = ctypes.c_char_p
+    assert lib.dgsct_arch() == b"gfx950"
+
+
+def test_query_rejects_bad_descriptor():
+    emu = Lib(build_emu())
+    from dgsct_amd.ops import AdapterSpec
+    bad = AdapterSpec(N=16, C=30, No=36, Co=16, tk=4)          # C not a multiple of 4 / r
+    with pytest.raises(RuntimeError, match="bad descriptor"):
+        emu.query(bad.desc(10, torch.float32, True))
+
+
+FLAVOUR_OF = {"ave_orderA": "ave", "avvp": "avvp", "avs_s4": "avs_s4", "avs_ms3": "avs_ms3", "avqa": "avqa", "pretrain": "pretrain"}
+
+
+@pytest.mark.parametrize("name", sorted(FLAVOUR_OF))
+def test_module_state_dict_matches_reference(name):
+    """parameter / buffer names and shapes are the checkpoint format (reference main_trans.py:306 loads by name)"""
+    fx = load_golden(name)
+    c = fx["cfg"]
+    fl = FLAVOUR_OF[name]
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=c["g"], is_before_layernorm=int(c["ln_before"] or fl.startswith("avs")),
+                          is_post_layernorm=int(c["ln_post"]), num_tokens=c["tk"])
+    kw = dict(num_tk=c["tk"]) if fl in ("ave", "avvp", "pretrain") else {}
+    m = VisualAdapter(c["C"], c["C"], "bottleneck", reduction_factor=c["r"], opt=opt, use_bn=c["use_bn"], use_gate=c["use_gate"],
+                      conv_dim_in=c["No"], conv_dim_out=c["N"], linear_in=c["Co"], linear_out=c["C"], flavour=fl, **kw)
+    ours = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    ref = {k: tuple(v.shape) for k, v in fx["state0"].items()}
+    assert ours == ref
+    m.load_state_dict(fx["state0"])            # strict
+
+
+def test_unknown_adapter_kind_raises_like_the_reference():
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=4)
+    with pytest.raises(NotImplementedError):
+        VisualAdapter(32, 32, "lora", opt=opt, reduction_factor=8, conv_dim_in=36, conv_dim_out=16, linear_in=16, linear_out=32)
+
+
+def test_no_cpu_fallback():
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=4)
+    m = VisualAdapter(32, 32, "bottleneck", reduction_factor=8, opt=opt, num_tk=4, conv_dim_in=36, conv_dim_out=16,
+                      linear_in=16, linear_out=32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.randn(10, 32, 16, 1), torch.randn(10, 16, 36, 1))
+
+
+def _stack_from_fixture(fx, emu, **kw):
+    opt = default_opt(num_tokens=4)
+    st = AdapterStack(fx["stages"], opt=opt, lib=emu, concurrent=False, **kw)
+    st.load_state_dict(fx["state0"])
+    return st
+
+
+def test_stack_schedule_matches_reference_loop():
+    """a-10: 12 adapters in the reference's ModuleLists + the AVE layer loop, identity backbone, vs. the reference."""
+    emu = Lib(build_emu())
+    fx = load_golden("stack_2stage")
+    st = _stack_from_fixture(fx, emu).train()
+    feats = [(a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for a, b in fx["feats"]]
+    outs, maps = st(feats)
+    for (fv, fa), (rv, ra) in zip(outs, fx["outs"]):
+        assert rel_err(fv, rv) < 1e-4 and rel_err(fa, ra) < 1e-4
+    assert rel_err(maps[0], fx["maps"][0]) < 1e-4 and rel_err(maps[1], fx["maps"][1]) < 1e-4
+    tensors = [t for pr in outs for t in pr] + [maps[0], maps[1]]
+    grads = [g for pr in fx["cots"] for g in pr] + [fx["mcots"][0], fx["mcots"][1]]
+    torch.autograd.backward(tensors, grads)
+    for (fv, fa), (gv, ga) in zip(feats, fx["dfeats"]):
+        assert rel_err(fv.grad, gv) < 1e-4 and rel_err(fa.grad, ga) < 1e-4
+    got = {k: p.grad for k, p in st.named_parameters() if p.grad is not None}
+    assert set(got) == set(fx["grads"])
+    for k, g in fx["grads"].items():
+        assert rel_err(got[k], g) < 1e-4, k
+    assert all(int(m.bn1.num_batches_tracked) == 1 for m in st.vis_adapter_blocks_p1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, emu_path, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    emu = Lib(emu_path)
+    fx = load_golden("stack_2stage")
+    opt = default_opt(num_tokens=4, is_bn=0)                       # per-replica BN statistics differ by design
+    st = AdapterStack(fx["stages"], opt=opt, lib=emu, concurrent=False)
+    st.load_state_dict(fx["state0"], strict=False)
+    red = GradAllReducer(GradAllReducer.stage_buckets(st))
+    BT = fx["feats"][0][0].shape[0]
+    lo, hi = rank * BT // world, (rank + 1) * BT // world
+    feats = [(a[lo:hi].clone(), b[lo:hi].clone()) for a, b in fx["feats"]]
+    outs, maps = st(feats)
+    tensors = [t for pr in outs for t in pr]
+    grads = [g[lo:hi] for pr in fx["cots"] for g in pr]
+    torch.autograd.backward(tensors, grads)
+    red.finish()
+    if rank == 0:
+        q.put({k: p.grad.numpy().copy() for k, p in st.named_parameters() if p.grad is not None})   # by value
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_allreduce_gloo_world2():
+    """N > 1 path on CPU: clips sharded over 2 ranks, bucketed all-reduce (average) == single-rank gradient / 1
+    of the concatenated batch divided by world (sum-of-clips loss), BN off."""
+    emu_path = build_emu()
+    fx = load_golden("stack_2stage")
+    # single-process reference on the full batch
+    emu = Lib(emu_path)
+    opt = default_opt(num_tokens=4, is_bn=0)
+    st = AdapterStack(fx["stages"], opt=opt, lib=emu, concurrent=False)
+    st.load_state_dict(fx["state0"], strict=False)
+    outs, maps = st([(a.clone(), b.clone()) for a, b in fx["feats"]])
+    torch.autograd.backward([t for pr in outs for t in pr], [g for pr in fx["cots"] for g in pr])
+    full = {k: p.grad.clone() for k, p in st.named_parameters() if p.grad is not None}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, emu_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert set(got) == set(full)
+    for k in full:
+        assert rel_err(torch.from_numpy(got[k]), full[k] / 2) < 1e-4, k
