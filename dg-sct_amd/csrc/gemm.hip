@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <mutex>
 #include <vector>
@@ -33,7 +34,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 struct GemmK {
   int M, N, K, KB;
-  int tiles_m, tiles_n, kt_per_kb, kt_total, kt_per_split;
+  int tiles_m, tiles_n, kflat, kt_total, kt_per_split; unsigned kinv;
   const char* A; long lda, a_bs, a_kbs; int a_vec;
   const char* B; long ldb, b_bs, b_kbs; int b_vec;
   char* D; int ddt; long ldd, dbs;
@@ -57,7 +58,7 @@ __host__ __device__ constexpr int mn_pitch_bf16(int rows) {
 template <int MODE, bool KM, int ROWS>
 struct TileGeom {
   static constexpr int ES = MODE == DT_BF16 ? 2 : 4;
-  static constexpr int BKT = MODE == DT_BF16 ? 32 : 16;
+  static constexpr int BKT = MODE == DT_BF16 ? 64 : 16;
   static constexpr int VE = 16 / ES;                       // elements per 16-byte chunk
   static constexpr int NCHUNK = ROWS * BKT / VE;           // chunks per tile
   static constexpr int NLD = (NCHUNK + 255) / 256;         // chunks per thread
@@ -67,9 +68,16 @@ struct TileGeom {
 };
 
 // ---- global -> register staging of one operand tile --------------------------------------------
+// The contraction index is FLAT: kf in [0, Kflat), Kflat = KB*K; kf -> (kb, k) = (kf / K, kf % K) by a
+// multiply-high with kinv = ceil(2^32 / K) (exact for kf*K < 2^32), address += kb*kbs.  A k-tile may therefore
+// straddle two frames of a two-level contraction (no padding waste when K = 96 and the tile is 64 deep).
+__device__ __forceinline__ void split_k(int kf, int K, int Kflat, unsigned kinv, int& kb, int& k) {
+  if (Kflat == K) { kb = 0; k = kf; }
+  else { kb = kinv ? (int)__umulhi((unsigned)kf, kinv) : kf; k = kf - kb * K; }
+}
 template <int MODE, bool KM, int ROWS, int NLD_>
-__device__ __forceinline__ void stage_load(uint4 (&reg)[NLD_], const char* base, long ld,
-                                           int r0, int rows_total, int k0, int K, int vec, int tid) {
+__device__ __forceinline__ void stage_load(uint4 (&reg)[NLD_], const char* base, long ld, long kbs, int r0, int rows_total,
+                                           int kf0, int K, int Kflat, unsigned kinv, int vec, int tid) {
   using G = TileGeom<MODE, KM, ROWS>;
   constexpr int ES = G::ES, VE = G::VE;
 #pragma unroll
@@ -80,25 +88,29 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[NLD_], const char* base,
       int r, k;
       if (KM) { r = c / (G::BKT / VE); k = (c % (G::BKT / VE)) * VE; }
       else    { k = c / (ROWS / VE);   r = (c % (ROWS / VE)) * VE; }
-      int rg = r0 + r, kg = k0 + k;
-      if (KM) {
-        if (rg < rows_total && kg < K) {
-          const char* p = base + ((long)rg * ld + kg) * ES;
-          if (vec && kg + VE <= K) v = *reinterpret_cast<const uint4*>(p);
+      const int rg = r0 + r, kf = kf0 + k;
+      if (rg < rows_total && kf < Kflat) {
+        int kb, kk;
+        split_k(kf, K, Kflat, kinv, kb, kk);
+        const char* bp = base + (long)kb * kbs * ES;
+        if (KM) {
+          const char* p = bp + ((long)rg * ld + kk) * ES;
+          if (vec && kk + VE <= K) v = *reinterpret_cast<const uint4*>(p);
           else {
             unsigned w[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < VE; ++e)
-              if (kg + e < K) {
-                if (ES == 4) w[e] = reinterpret_cast<const unsigned*>(p)[e];
-                else w[e >> 1] |= (unsigned)reinterpret_cast<const unsigned short*>(p)[e] << ((e & 1) * 16);
+              if (kf + e < Kflat) {
+                int kbe, kke;
+                split_k(kf + e, K, Kflat, kinv, kbe, kke);
+                const char* q = base + ((long)kbe * kbs + (long)rg * ld + kke) * ES;
+                if (ES == 4) w[e] = *reinterpret_cast<const unsigned*>(q);
+                else w[e >> 1] |= (unsigned)*reinterpret_cast<const unsigned short*>(q) << ((e & 1) * 16);
               }
             v = make_uint4(w[0], w[1], w[2], w[3]);
           }
-        }
-      } else {
-        if (kg < K && rg < rows_total) {
-          const char* p = base + ((long)kg * ld + rg) * ES;
+        } else {
+          const char* p = bp + ((long)kk * ld + rg) * ES;
           if (vec && rg + VE <= rows_total) v = *reinterpret_cast<const uint4*>(p);
           else {
             unsigned w[4] = {0, 0, 0, 0};
@@ -173,7 +185,7 @@ __device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row0, int kk,
 }
 
 template <int MODE, bool AK, bool BK, int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
+__global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmK p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   using GA = TileGeom<MODE, AK, BM>;
   using GB = TileGeom<MODE, BK, BN>;
@@ -216,21 +228,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[GA::NLD], rb[GB::NLD];
-  auto prefetch = [&](int kt) {
-    const int kb = kt / p.kt_per_kb;
-    const int k0 = (kt - kb * p.kt_per_kb) * BKT;
-    stage_load<MODE, AK, BM>(ra, Ab + (long)kb * p.a_kbs * ES, p.lda, m0, p.M, k0, p.K, p.a_vec, tid);
-    stage_load<MODE, BK, BN>(rb, Bb + (long)kb * p.b_kbs * ES, p.ldb, n0, p.N, k0, p.K, p.b_vec, tid);
-  };
-
-  if (kt_begin < kt_end) prefetch(kt_begin);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    __syncthreads();                       // previous tile's fragment reads are done
-    stage_store<MODE, AK, BM>(ra, ldsA, tid);
-    stage_store<MODE, BK, BN>(rb, ldsB, tid);
-    __syncthreads();
-    if (kt + 1 < kt_end) prefetch(kt + 1);  // global loads fly under the MFMAs below
+  // Two register sets in flight: the loads of k-tiles t+1 and t+2 are outstanding while tile t is in the MFMAs, so a
+  // tile's global-memory latency is covered by two tiles of math (small GEMMs here are latency-, not throughput-bound).
+  uint4 ra0[GA::NLD], rb0[GB::NLD], ra1[GA::NLD], rb1[GB::NLD];
+  auto compute = [&]() {
     if (MODE == DT_BF16) {
 #pragma unroll
       for (int kk = 0; kk < BKT / 16; ++kk) {
@@ -264,7 +265,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
     }
+  };
+#define DGSCT_PREFETCH(RA, RB, KT)                                                                                     \
+  do {                                                                                                                 \
+    stage_load<MODE, AK, BM>(RA, Ab, p.lda, p.a_kbs, m0, p.M, (KT) * BKT, p.K, p.kflat, p.kinv, p.a_vec, tid);           \
+    stage_load<MODE, BK, BN>(RB, Bb, p.ldb, p.b_kbs, n0, p.N, (KT) * BKT, p.K, p.kflat, p.kinv, p.b_vec, tid);           \
+  } while (0)
+  if (kt_begin < kt_end) DGSCT_PREFETCH(ra0, rb0, kt_begin);
+  if (kt_begin + 1 < kt_end) DGSCT_PREFETCH(ra1, rb1, kt_begin + 1);
+  for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    __syncthreads();                       // previous tile's fragment reads are done
+    stage_store<MODE, AK, BM>(ra0, ldsA, tid);
+    stage_store<MODE, BK, BN>(rb0, ldsB, tid);
+    __syncthreads();
+    if (kt + 2 < kt_end) DGSCT_PREFETCH(ra0, rb0, kt + 2);
+    compute();
+    if (kt + 1 < kt_end) {
+      __syncthreads();
+      stage_store<MODE, AK, BM>(ra1, ldsA, tid);
+      stage_store<MODE, BK, BN>(rb1, ldsB, tid);
+      __syncthreads();
+      if (kt + 3 < kt_end) DGSCT_PREFETCH(ra1, rb1, kt + 3);
+      compute();
+    }
   }
+#undef DGSCT_PREFETCH
 
   // ---- epilogue: accumulator element r of tile (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
   const float alpha = p.alpha * (p.alpha_ptr ? *p.alpha_ptr : 1.f);
@@ -385,15 +410,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
 // ------------------------------------------------------------------------------------------------
 // Optional per-launch timing of the GEMM family (bench.py's roofline leg): HIP events recorded on the
 // launch stream around every gemm_kernel launch of this thread while enabled.  Off by default.
-struct ProfRec { hipEvent_t e0, e1; double flops; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int M, N, K, KB, batch, splitk, cfg, ak, bk, atomic, wide; double bytes; };
 // (process-wide: autograd runs backward on its own thread)
 static std::atomic<bool> g_prof_on{false};
 static std::mutex g_prof_mu;
 static std::deque<ProfRec>* g_prof = nullptr;
 
-static ProfRec* prof_begin(hipStream_t s, double flops) {
+static ProfRec* prof_begin(hipStream_t s, double flops, const ProfRec& shape) {
   if (!g_prof_on.load(std::memory_order_relaxed)) return nullptr;
-  ProfRec r;
+  ProfRec r = shape;
   r.flops = flops;
   (void)hipEventCreate(&r.e0);
   (void)hipEventCreate(&r.e1);
@@ -411,16 +436,22 @@ void gemm_prof_enable(int on) { g_prof_on.store(on != 0); }
 void gemm_prof_collect(long* launches, double* total_ms, double* total_flops) {
   long n = 0; double ms = 0, fl = 0;
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  FILE* dump = nullptr;
+  if (const char* path = getenv("DGSCT_PROF_DUMP")) dump = fopen(path, "w");
+  if (dump) fprintf(dump, "M,N,K,KB,batch,splitk,cfg,ak,bk,atomic,wide,flops,bytes,ms\n");
   if (g_prof) {
     for (auto& r : *g_prof) {
       (void)hipEventSynchronize(r.e1);
       float t = 0.f;
       if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms += t; fl += r.flops; ++n; }
+      if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.0f,%.0f,%.5f\n", r.M, r.N, r.K, r.KB, r.batch, r.splitk, r.cfg,
+                        r.ak, r.bk, r.atomic, r.wide, r.flops, r.bytes, t);
       (void)hipEventDestroy(r.e0);
       (void)hipEventDestroy(r.e1);
     }
     g_prof->clear();
   }
+  if (dump) fclose(dump);
   if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
@@ -440,7 +471,7 @@ template <int MODE>
 static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   constexpr int ES = MODE == DT_BF16 ? 2 : 4;
   constexpr int VE = 16 / ES;
-  constexpr int BKT = MODE == DT_BF16 ? 32 : 16;
+  constexpr int BKT = MODE == DT_BF16 ? 64 : 16;
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
   GemmK k;
   k.M = g.M; k.N = g.N; k.K = g.K; k.KB = g.KB;
@@ -461,17 +492,33 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     if (g.R) w = w && aligned16(g.R) && g.ldr % rv == 0 && g.rbs % rv == 0;
     k.wide = w;
   }
-  k.kt_per_kb = (g.K + BKT - 1) / BKT;
-  k.kt_total = k.kt_per_kb * g.KB;
+  k.kflat = g.K * g.KB;
+  k.kinv = g.K > 1 ? (unsigned)((0x100000000ULL + (unsigned long long)g.K - 1) / (unsigned long long)g.K) : 0u;
+  k.kt_total = (k.kflat + BKT - 1) / BKT;
 
-  // tile configuration
+  // tile configuration (measured on MI355X with tools/gemm_bench.py over the shapes of the adapter stack):
+  //  * deep contractions (K >= 1024: the remap GEMMs) want the big tiles: 128x96 when N is a multiple of 96 (the
+  //    remap widths), else 128x128;
+  //  * shallow ones (most of this workload: K = 32..768) are bound by per-workgroup latency and by wave
+  //    quantisation over the 256 CUs x 3 resident 128x128 workgroups: 64x64 tiles (6 resident) win unless the 128x128
+  //    grid fills its last round well and K is not tiny.
   int cfg;
+  const long kflat = (long)g.K * g.KB;
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.batch; };
   if (g.N <= 32) cfg = 2;                                       // 128 x 32
   else if (g.M <= 32) cfg = 3;                                  // 32 x 128
-  else if (g.N % 128 != 0 && g.N % 96 == 0 && g.M >= 96) cfg = 1;   // 128 x 96 (remap widths are multiples of 96)
-  else if (g.M >= 128 && g.N >= 128 && tiles(128, 128) >= 192) cfg = 0;   // 128 x 128
-  else cfg = 4;                                                 // 64 x 64
+  else if (kflat >= 1024 && !g.atomic) {
+    if (g.N % 128 != 0 && g.N % 96 == 0 && g.M >= 96) cfg = 1; // 128 x 96
+    else if (g.M >= 96 && g.N >= 96) cfg = 0;                   // 128 x 128
+    else cfg = 4;
+  } else if (g.atomic && g.M >= 1024 && g.N >= 1024) cfg = 0;   // dWn: a plain big GEMM
+  else {
+    const long w0 = tiles(128, 128);
+    const long last = w0 % 768;
+    const bool fills = w0 >= 192 && (last == 0 || last >= 576 || w0 >= 6144);
+    cfg = (kflat > 256 && g.M >= 128 && g.N >= 128 && fills && !g.atomic) ? 0 : 4;
+  }
+  if (const char* e = getenv("DGSCT_GEMM_CFG")) { const int c = atoi(e); if (c >= 0 && c <= 4) cfg = c; }   // tuning hook
   static const int BMs[5] = {128, 128, 128, 32, 64}, BNs[5] = {128, 96, 32, 128, 64};
   k.tiles_m = (g.M + BMs[cfg] - 1) / BMs[cfg];
   k.tiles_n = (g.N + BNs[cfg] - 1) / BNs[cfg];
@@ -489,7 +536,12 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   dim3 grid(k.tiles_m * k.tiles_n, g.batch, splitk);
   hipStream_t s = (hipStream_t)ctx.stream;
   const int ak = g.A.kmajor, bk = g.B.kmajor;
-  ProfRec* rec = prof_begin(s, 2.0 * g.M * g.N * (double)g.K * g.KB * g.batch);
+  ProfRec shp{};
+  shp.M = g.M; shp.N = g.N; shp.K = g.K; shp.KB = g.KB; shp.batch = g.batch; shp.splitk = splitk; shp.cfg = cfg;
+  shp.ak = ak; shp.bk = bk; shp.atomic = g.atomic; shp.wide = k.wide;
+  shp.bytes = ((double)g.M * g.K * g.KB * (g.A.bs ? g.batch : 1) + (double)g.N * g.K * g.KB * (g.B.bs ? g.batch : 1)) * ES +
+              (double)g.M * g.N * g.batch * (g.ddt == DT_F32 ? 4 : 2) * (g.R ? 2 : 1);
+  ProfRec* rec = prof_begin(s, 2.0 * g.M * g.N * (double)g.K * g.KB * g.batch, shp);
   switch (cfg) {
     case 0: launch_cfg<MODE, 2, 2, 2, 2>(k, ak, bk, grid, s); break;
     case 1: launch_cfg<MODE, 4, 1, 1, 3>(k, ak, bk, grid, s); break;

@@ -166,7 +166,7 @@ void Plan::layout() {
     wb.dP1 = a.take("dP1", (int64_t)B * tk * Np * 4);
     wb.dS1 = a.take("dS1", (int64_t)B * tk * Np * es);
     wb.dYp = a.take("dYp", R * C * es);
-    wb.dT = a.take("dT", orderA ? R * Co * es : (int64_t)B * C * Nop * es);
+    wb.dT = a.take("dT", orderA ? R * Co * es : (int64_t)B * No * C * es);
     wb.rowtmp = a.take("rowtmp", R * 4);
     ws_bwd_bytes = a.off;
   }
@@ -682,10 +682,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         gemm(ctx, g4);
       }
     } else {
-      Gemm g1 = mk(C, No, N, B);                                 // dT2t[b] = dYp[b]^T . Wn     [C][No]
-      g1.A = mn(dYp, C, (long)N * C);
-      g1.B = mn(b.W(DGSCT_P_WN), No);
-      outE(g1, b.Wk(wb.dT), E, Nop, (long)C * Nop);
+      Gemm g1 = mk(No, C, N, B);                                 // dT2[b] = Wn^T . dYp[b]     [No][C] token-major
+      g1.A = mn(b.W(DGSCT_P_WN), No);                            //   (M = No, N = C: the 128x96 remap tile; the transposed
+      g1.B = mn(dYp, C, (long)N * C);                            //    form M = C = 96 runs at half the rate)
+      outE(g1, b.Wk(wb.dT), E, C, (long)No * C);
       gemm(ctx, g1);
       if (conv) {
         Gemm g2 = mk(N, No, C);                                  // dWn = sum_b dYp[b] . T2[b]^T
@@ -697,13 +697,13 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         gemm(ctx, g2);
       }
       Gemm g3 = mk(No, Co, C, B);                                // dY[b] = dT2[b] . Wc
-      g3.A = mn(b.Wk(wb.dT), Nop, (long)C * Nop);
+      g3.A = km(b.Wk(wb.dT), C, (long)No * C);
       g3.B = mn(b.W(DGSCT_P_WC), Co);
       outE(g3, dY, E, Co, (long)No * Co);
       gemm(ctx, g3);
-      Gemm g4 = mk(C, Co, No);                                   // dWc = sum_b dT2t[b] . Y[b]
+      Gemm g4 = mk(C, Co, No);                                   // dWc = sum_b dT2[b]^T . Y[b]
       g4.KB = B;
-      g4.A = km(b.Wk(wb.dT), Nop, 0, (long)C * Nop);
+      g4.A = mn(b.Wk(wb.dT), C, 0, (long)No * C);
       g4.B = mn(Y, Co, 0, (long)No * Co);
       outF(g4, G(DGSCT_P_WC), Co);
       atomic_out(g4);
