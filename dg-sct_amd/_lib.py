@@ -56,7 +56,7 @@ class GemmArgs(C.Structure):
 
 
 EXPORTS = ["dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
-           "dgsct_adapter_backward", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect"]
+           "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect"]
 
 _PP = C.POINTER(C.c_void_p)
 
@@ -84,6 +84,7 @@ class Lib:
         c.dgsct_adapter_backward.argtypes = [C.POINTER(AdapterDesc), _PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p]
+        c.dgsct_adapter_backward_ex.argtypes = c.dgsct_adapter_backward.argtypes + [C.c_void_p]
         c.dgsct_saved_region.argtypes = [C.POINTER(AdapterDesc), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]
         c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
@@ -114,9 +115,9 @@ class Lib:
         self._check(self.c.dgsct_adapter_forward(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, out, amap, tmap, saved, ws,
                                                  stream), "dgsct_adapter_forward")
 
-    def backward(self, desc, ptrs, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream):
-        self._check(self.c.dgsct_adapter_backward(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, saved, dOut, dMap, dTmap,
-                                                  dX, dY, grads, ws, stream), "dgsct_adapter_backward")
+    def backward(self, desc, ptrs, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream=None):
+        self._check(self.c.dgsct_adapter_backward_ex(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, saved, dOut, dMap, dTmap,
+                                                     dX, dY, grads, ws, stream, aux_stream), "dgsct_adapter_backward")
 
     def saved_regions(self, desc):
         out = {}

@@ -54,6 +54,12 @@ int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, 
 int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
                            const void* Y, const void* saved, const void* dOut, const float* dMap, const float* dTmap,
                            void* dX, void* dY, float* grads, void* ws, void* stream) {
+  return dgsct_adapter_backward_ex(desc, params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, nullptr);
+}
+
+int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
+                              const void* Y, const void* saved, const void* dOut, const float* dMap, const float* dTmap,
+                              void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream) {
   clear_error();
   if (!desc || !params || !prep || !X || !Y || !saved || !dOut || !dX || !dY || !grads || !ws) {
     set_error("dgsct_adapter_backward: NULL argument");
@@ -61,7 +67,7 @@ int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params,
   }
   Plan p(*desc);
   if (!p.ok) return 2;
-  return p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream);
+  return p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream);
 }
 
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes) {

@@ -426,9 +426,16 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
 // ------------------------------------------------------------------------------------------------
 int Plan::backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved_c,
                    const void* dOut, const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws,
-                   void* stream) const {
+                   void* stream, void* aux_stream) const {
   Bound b(*this, params, prep, const_cast<void*>(saved_c), ws, stream);
+  b.ctx.aux = aux_stream;
   const Ctx& ctx = b.ctx;
+  // Weight / bias gradients feed nothing downstream: they go to the aux stream (when given) and overlap the data-gradient
+  // chain.  side_begin() makes aux wait for everything enqueued so far (the operands); the final join orders it all
+  // before the caller's next use of `grads` / `ws`.
+  Ctx side = ctx;
+  if (aux_stream) { side.stream = aux_stream; side.aux = nullptr; }
+  auto side_begin = [&]() { stream_fork(ctx); };
   auto G = [&](int id) -> float* { return grad_off[id] >= 0 ? grads + grad_off[id] : nullptr; };
   zero(ctx, b.Wk(0), (size_t)wb.zero_end);
   zero(ctx, grads, (size_t)grad_floats * 4);
@@ -453,7 +460,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g1.B = mn(b.S(s.Z), ds, dg);
     outF(g1, G(DGSCT_P_WU), dg, (long)cg * dg);
     atomic_out(g1);
-    gemm(ctx, g1);
+    side_begin();
+    gemm(side, g1);
     Gemm g2 = mk((int)R, dg, cg, g);                             // dZ = dOp (x)_g Wu
     g2.A = km(dO, C, cg);
     g2.B = mn(b.W(DGSCT_P_WU), dg, (long)cg * dg);
@@ -474,7 +482,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g1.B = mn(b.S(s.X3), C, cg);
     outF(g1, G(DGSCT_P_WD), cg, (long)dg * cg);
     atomic_out(g1);
-    gemm(ctx, g1);
+    side_begin();
+    gemm(side, g1);
     Gemm g2 = mk((int)R, cg, dg, g);                             // dX3 = dZp (x)_g Wd
     g2.A = km(dZ, ds, dg);
     g2.B = mn(b.W(DGSCT_P_WD), cg, (long)dg * cg);
@@ -507,7 +516,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g2.B = mn(b.S(s.Xc), C);
     outF(g2, G(DGSCT_P_WV2), C);
     atomic_out(g2);
-    gemm(ctx, g2);
+    side_begin();
+    gemm(side, g2);
     xc_bwd(ctx, b.Wk(wb.dXc), b.S(s.X1), dX1, B, N, C, b.S<float>(s.ch), b.Wk<float>(wb.dch));
   }
   // B6 ---- channel-gate head
@@ -516,7 +526,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g1 = mk(C, dd, B);                                      // dWcatt = dpre^T . q
     g1.A = mn(b.Wk(wb.dpre_c), C); g1.B = mn(b.S(s.q), dd);
     outF(g1, G(DGSCT_P_WCATT), dd);
-    gemm(ctx, g1);
+    side_begin();
+    gemm(side, g1);
     colsum_batched(ctx, b.Wk(wb.dpre_c), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BCATT), 0);
     Gemm g2 = mk(B, dd, C);                                      // dq = (dpre . Wcatt) * (q > 0)
     g2.A = km(b.Wk(wb.dpre_c), C); g2.B = mn(b.W(DGSCT_P_WCATT), dd);
@@ -526,7 +537,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g3 = mk(dd, C, B);                                      // dWb = dq^T . m1
     g3.A = mn(b.Wk(wb.dq), dd); g3.B = mn(b.S(s.m1), C);
     outF(g3, G(DGSCT_P_WB), C);
-    gemm(ctx, g3);
+    side_begin();
+    gemm(side, g3);
     colsum_batched(ctx, b.Wk(wb.dq), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BB), 0);
     Gemm g4 = mk(B, C, dd);                                      // dm1 = dq . Wb
     g4.A = km(b.Wk(wb.dq), dd); g4.B = mn(b.W(DGSCT_P_WB), C);
@@ -548,19 +560,22 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g2.A = mn(b.S(s.vq1), C); g2.B = mn(b.S(s.X1), C);
     outF(g2, G(DGSCT_P_WV1), C);
     atomic_out(g2);
-    gemm(ctx, g2);
+    side_begin();
+    gemm(side, g2);
   }
   // B4 ---- audio queries
   {
     Gemm g1 = mk(C, C, B);                                       // dWa1 = dpa1^T . a
     g1.A = mn(b.Wk(wb.dpa1), C); g1.B = mn(b.S(s.aE), C);
     outF(g1, G(DGSCT_P_WA1), C);
-    gemm(ctx, g1);
+    side_begin();
+    gemm(side, g1);
     colsum_batched(ctx, b.Wk(wb.dpa1), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BA1), 0);
     Gemm g2 = mk(dd, C, B);                                      // dWa2 = dpa2^T . a
     g2.A = mn(b.Wk(wb.dpa2), dd); g2.B = mn(b.S(s.aE), C);
     outF(g2, G(DGSCT_P_WA2), C);
-    gemm(ctx, g2);
+    side_begin();
+    gemm(side, g2);
     colsum_batched(ctx, b.Wk(wb.dpa2), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BA2), 0);
     Gemm g3 = mk(B, C, C);                                       // da = dpa1 . Wa1 + dpa2 . Wa2
     g3.A = km(b.Wk(wb.dpa1), C); g3.B = mn(b.W(DGSCT_P_WA1), C);
@@ -666,7 +681,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       g2.A = mn(dYp, C); g2.B = mn(b.S(s.T), Co);
       outF(g2, G(DGSCT_P_WC), Co);
       atomic_out(g2);
-      gemm(ctx, g2);
+      side_begin();
+      gemm(side, g2);
       Gemm g3 = mk(No, Co, N, B);                                // dY[b] = Wn^T . dT1[b]
       g3.A = mn(b.W(DGSCT_P_WN), No);
       g3.B = mn(b.Wk(wb.dT), Co, (long)N * Co);
@@ -679,7 +695,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         g4.B = km(Y, Co, 0, (long)No * Co);
         outF(g4, G(DGSCT_P_WN), No);
         atomic_out(g4);
-        gemm(ctx, g4);
+        side_begin();
+        gemm(side, g4);
       }
     } else {
       Gemm g1 = mk(No, C, N, B);                                 // dT2[b] = Wn^T . dYp[b]     [No][C] token-major
@@ -694,7 +711,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         g2.B = mn(b.S(s.T), Nop, 0, (long)C * Nop);
         outF(g2, G(DGSCT_P_WN), No);
         atomic_out(g2);
-        gemm(ctx, g2);
+        side_begin();
+        gemm(side, g2);
       }
       Gemm g3 = mk(No, Co, C, B);                                // dY[b] = dT2[b] . Wc
       g3.A = km(b.Wk(wb.dT), C, (long)No * C);
@@ -707,11 +725,13 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       g4.B = mn(Y, Co, 0, (long)No * Co);
       outF(g4, G(DGSCT_P_WC), Co);
       atomic_out(g4);
-      gemm(ctx, g4);
+      side_begin();
+      gemm(side, g4);
     }
     if (conv)   // + d rowsum(Wc)[c] broadcast over co
-      ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
+      ew(side, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
   }
+  stream_join(ctx);
   return has_error() ? 1 : 0;
 }
 

@@ -43,7 +43,8 @@ struct Plan {
   int forward(float* const* params, const void* prep, const void* X, const void* Y, void* out, float* map, float* tmap,
               void* saved, void* ws, void* stream) const;
   int backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved, const void* dOut,
-               const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws, void* stream) const;
+               const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws, void* stream,
+               void* aux_stream = nullptr) const;
 
  private:
   bool validate();

@@ -21,7 +21,12 @@ inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 struct Ctx {
   void* stream;   // hipStream_t
   int mode;       // DType of E
+  void* aux = nullptr;   // optional second hipStream_t for work off the critical path (weight gradients)
 };
+// aux waits for everything enqueued on stream so far / stream waits for everything enqueued on aux so far.
+// No-ops when ctx.aux is null.
+void stream_fork(const Ctx&);
+void stream_join(const Ctx&);
 
 // One GEMM operand X[r][k] (r = M- or N-index, k = contraction index), element type E.
 //   kmajor = 1 : &X[r][k] = p + r*ld + k     (k contiguous)

@@ -22,6 +22,29 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// Cross-stream ordering with a small thread-local ring of timing-less events (re-recording an event whose earlier
+// wait is still pending is well defined: a wait captures the record that preceded it).
+static hipEvent_t next_event() {
+  static thread_local hipEvent_t ring[32];
+  static thread_local int n = 0, made = 0;
+  if (made < 32) { (void)hipEventCreateWithFlags(&ring[made], hipEventDisableTiming); return ring[made++]; }
+  hipEvent_t e = ring[n];
+  n = (n + 1) & 31;
+  return e;
+}
+void stream_fork(const Ctx& ctx) {
+  if (!ctx.aux) return;
+  hipEvent_t e = next_event();
+  (void)hipEventRecord(e, (hipStream_t)ctx.stream);
+  (void)hipStreamWaitEvent((hipStream_t)ctx.aux, e, 0);
+}
+void stream_join(const Ctx& ctx) {
+  if (!ctx.aux) return;
+  hipEvent_t e = next_event();
+  (void)hipEventRecord(e, (hipStream_t)ctx.aux);
+  (void)hipStreamWaitEvent((hipStream_t)ctx.stream, e, 0);
+}
+
 void zero(const Ctx& ctx, void* p, size_t bytes) {
   if (bytes) (void)hipMemsetAsync(p, 0, bytes, STREAM(ctx));
 }

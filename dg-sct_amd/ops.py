@@ -58,6 +58,22 @@ def _stream_of(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
 
+_AUX: Dict[Tuple, "torch.cuda.Stream"] = {}
+USE_AUX_STREAM = True
+
+
+def _aux_stream(t: torch.Tensor, stream: int) -> Optional[int]:
+    """one side stream per (device, caller stream): weight gradients overlap the data-gradient chain on it"""
+    if not (USE_AUX_STREAM and t.is_cuda):
+        return None
+    key = (t.device.index, stream)
+    with _WS_LOCK:
+        s = _AUX.get(key)
+        if s is None:
+            s = _AUX[key] = torch.cuda.Stream(device=t.device)
+    return s.cuda_stream
+
+
 def _workspace(device: torch.device, stream: int, nbytes: int) -> torch.Tensor:
     key = (device.type, device.index, stream)
     with _WS_LOCK:
@@ -127,7 +143,7 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     ws = _workspace(dev, stream, int(sz.ws_bwd_bytes))
     lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
                  dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
-                 dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream)
+                 dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(X, stream))
     per_param: List[Optional[torch.Tensor]] = []
     for i in range(P_COUNT):
         off, n = int(sz.grad_offset[i]), int(sz.grad_numel[i])

@@ -122,6 +122,14 @@ int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params,
                            const void* dOut, const float* dMap, const float* dTmap,
                            void* dX, void* dY, float* grads, void* ws, void* stream);
 
+/* Same, with an optional second stream: weight / bias gradients (which feed nothing downstream) are issued on
+ * `aux_stream` and overlap the data-gradient chain; the call forks from and joins back into `stream`, so the caller sees
+ * ordinary single-stream semantics.  aux_stream == NULL is dgsct_adapter_backward. */
+int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep,
+                              const void* X, const void* Y, const void* saved,
+                              const void* dOut, const float* dMap, const float* dTmap,
+                              void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream);
+
 /* ---- introspection / test hooks (used by tests/ only) ------------------------------------------ */
 /* i-th named region of the `saved` buffer; returns 0 and fills name/offset/bytes, or 1 past the end. */
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes);
