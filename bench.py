@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-optim", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no audio/visual adapter overlap)")
+    ap.add_argument("--no-aux", action="store_true", help="no aux stream for weight gradients")
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of eager launches "
                     "(ROCm 7.2: replaying ~6000 nodes costs as much host time as launching them, so this is off by default)")
     args = ap.parse_args()
@@ -167,7 +168,15 @@ def main():
     # captured graph -- collectives are kept out of the capture on purpose.
     reducer = GradAllReducer(GradAllReducer.stage_buckets(stack), overlap=False) if world > 1 else None
     use_graph = args.graph
-    opt = None if args.no_optim else torch.optim.Adam(params, lr=1e-5, capturable=use_graph)
+    if use_graph or args.no_aux:
+        from dgsct_amd import ops as _ops
+        _ops.USE_AUX_STREAM = False        # event fork/join from inside the library is not capture-safe on ROCm 7.2
+    opt = None
+    if not args.no_optim:
+        try:        # one fused multi-tensor Adam launch per dtype/device group instead of ~10 foreach launches
+            opt = torch.optim.Adam(params, lr=1e-5, fused=True, capturable=use_graph)
+        except Exception:
+            opt = torch.optim.Adam(params, lr=1e-5, capturable=use_graph)
     feats, cots, mcots = make_inputs(stages, BT, dtype, device, seed=1 + rank)
 
     def fwd_bwd():

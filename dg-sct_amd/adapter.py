@@ -125,23 +125,44 @@ class VisualAdapter(nn.Module):
 
     # ------------------------------------------------------------------
     def _param_list(self) -> List[Optional[torch.Tensor]]:
-        sd = dict(self.named_parameters())
-        sd.update(dict(self.named_buffers()))
+        """parameter table in C-ABI order; the name -> tensor resolution is done once (Parameters keep their identity
+        across .to()/.load_state_dict(); the 2-D views of the conv weights are re-made when their storage moves)."""
+        cache = self.__dict__.get("_ptab")
+        if cache is None:
+            sd = dict(self.named_parameters())
+            sd.update(dict(self.named_buffers()))
+            cache = []
+            for name in PARAM_NAMES:
+                t = sd.get(name)
+                view = None
+                if name == "conv_adapter.weight":
+                    if self.spec.remap == "bicubic":
+                        t = self._remap_op
+                    else:
+                        view = (self.spec.N, self.spec.No)
+                elif name == "conv_adapter.bias" and self.spec.remap == "bicubic":
+                    t = None
+                elif name in ("down_sampler.weight", "up_sampler.weight"):
+                    view = (t.shape[0], t.shape[1])
+                elif name.startswith("temporal_gated") and not self.spec.temporal:
+                    t = None
+                elif name.startswith("ln_before") and not self.spec.ln_before:
+                    t = None
+                cache.append([t, view, None, 0])
+            self.__dict__["_ptab"] = cache
         out: List[Optional[torch.Tensor]] = []
-        for name in PARAM_NAMES:
-            t = sd.get(name)
-            if name == "conv_adapter.weight":
-                t = self._remap_op if self.spec.remap == "bicubic" else t.view(self.spec.N, self.spec.No)
-            elif name == "conv_adapter.bias" and self.spec.remap == "bicubic":
-                t = None
-            elif name in ("down_sampler.weight", "up_sampler.weight"):
-                t = t.view(t.shape[0], t.shape[1])
-            elif name.startswith("temporal_gated") and not self.spec.temporal:
-                t = None
-            elif name.startswith("ln_before") and not self.spec.ln_before:
-                t = None
+        for ent in cache:
+            t, view = ent[0], ent[1]
+            if t is not None and view is not None:
+                if ent[2] is None or ent[3] != t.data_ptr():
+                    ent[2], ent[3] = t.view(*view), t.data_ptr()
+                t = ent[2]
             out.append(t)
         return out
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop("_ptab", None)        # .to()/.cuda()/.float(): buffers may be replaced
+        return super()._apply(fn, *a, **k)
 
     def _prepared(self, lib, params, dtype, device):
         key = (dtype, device, tuple((p.data_ptr(), p._version) for p in params if p is not None))

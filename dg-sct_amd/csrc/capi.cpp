@@ -73,7 +73,7 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes) {
   clear_error();
   if (!desc) return 2;
-  Plan p(*desc);
+  Plan p(*desc, true);
   if (!p.ok) return 2;
   if (i < 0 || i >= (int)p.saved_regions.size()) return 1;
   const Region& r = p.saved_regions[i];

@@ -32,7 +32,7 @@ struct Arena {
 };
 
 // ------------------------------------------------------------------------------------------------
-Plan::Plan(const dgsct_adapter_desc& d_) : d(d_) {
+Plan::Plan(const dgsct_adapter_desc& d_, bool record_regions) : record_regions_(record_regions), d(d_) {
   B = d.BT; N = d.N; C = d.C; No = d.No; Co = d.Co; tk = d.tk; g = d.g;
   dd = C / 2; ds = d.r > 0 ? C / d.r : 0;
   E = d.dtype; es = (int64_t)dt_size(E);
@@ -87,7 +87,7 @@ void Plan::layout() {
   }
   // ---- saved
   {
-    Arena a; a.regs = &saved_regions;
+    Arena a; a.regs = record_regions_ ? &saved_regions : nullptr;
     // zero block first (atomically accumulated in forward)
     s.a = a.take("a", (int64_t)B * C * 4);
     s.mvq1 = a.take("mvq1", (int64_t)B * C * 4);

@@ -11,7 +11,8 @@ namespace dgsct {
 struct Region { std::string name; int64_t offset, bytes; };
 
 struct Plan {
-  explicit Plan(const dgsct_adapter_desc& d);
+  explicit Plan(const dgsct_adapter_desc& d, bool record_regions = false);
+  bool record_regions_ = false;
   bool ok = false;
   dgsct_adapter_desc d;
   int B, N, C, No, Co, tk, g, dd, ds, E, Np, Nop, tkp;

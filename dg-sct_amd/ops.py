@@ -38,6 +38,14 @@ class AdapterSpec:
     bn_momentum: float = 0.1
 
     def desc(self, BT: int, dtype: torch.dtype, training: bool) -> AdapterDesc:
+        key = (self, BT, dtype, bool(training))
+        d = _DESC_CACHE.get(key)
+        if d is not None:
+            return d
+        d = _DESC_CACHE[key] = self._make_desc(BT, dtype, training)
+        return d
+
+    def _make_desc(self, BT: int, dtype: torch.dtype, training: bool) -> AdapterDesc:
         d = AdapterDesc()
         d.BT, d.T, d.N, d.C, d.No, d.Co, d.tk, d.r, d.g = BT, self.T, self.N, self.C, self.No, self.Co, self.tk, self.r, self.g
         d.dtype = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
@@ -46,6 +54,19 @@ class AdapterSpec:
         d.gate_before_ln_post, d.temporal, d.training = int(self.gate_before_ln_post), int(self.temporal), int(training)
         d.alpha, d.beta, d.gamma, d.eps, d.bn_momentum = self.alpha, self.beta, self.gamma, self.eps, self.bn_momentum
         return d
+
+
+_DESC_CACHE: Dict[Tuple, AdapterDesc] = {}
+_SIZE_CACHE: Dict[Tuple, object] = {}
+
+
+def _sizes(lib: Lib, d: AdapterDesc):
+    """dgsct_query results are pure functions of the descriptor: ask once per (library, descriptor)."""
+    key = (id(lib), id(d))
+    s = _SIZE_CACHE.get(key)
+    if s is None:
+        s = _SIZE_CACHE[key] = lib.query(d)
+    return s
 
 
 # ---------------------------------------------------------------------------------------------
@@ -104,7 +125,7 @@ def check_param(name: str, p: Optional[torch.Tensor], device) -> Optional[torch.
 def prepare(lib: Lib, spec: AdapterSpec, params: List[Optional[torch.Tensor]], dtype: torch.dtype, device) -> torch.Tensor:
     """fp32 master parameters -> MFMA-operand copies + derived bias vectors (dgsct_prepare)."""
     d = spec.desc(spec.T, dtype, False)
-    sz = lib.query(d)
+    sz = _sizes(lib, d)
     prep = torch.empty(max(int(sz.prep_bytes), 256), dtype=torch.uint8, device=device)
     some = next(p for p in params if p is not None)
     lib.prepare(d, _ptrs(params), prep.data_ptr(), _stream_of(some))
@@ -120,7 +141,7 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
     if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("dg-sct_amd: X and Y must both be float32 or both bfloat16")
     d = spec.desc(BT, X.dtype, training)
-    sz = lib.query(d)
+    sz = _sizes(lib, d)
     dev = X.device
     out = torch.empty_like(X)
     amap = torch.empty(BT, spec.N, dtype=torch.float32, device=dev)
@@ -134,7 +155,7 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
 
 
 def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y, saved, dOut, dMap, dTmap):
-    sz = lib.query(d)
+    sz = _sizes(lib, d)
     dev = X.device
     dX = torch.empty_like(X)
     dY = torch.empty_like(Y)
@@ -144,11 +165,14 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
                  dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
                  dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(X, stream))
-    per_param: List[Optional[torch.Tensor]] = []
-    for i in range(P_COUNT):
-        off, n = int(sz.grad_offset[i]), int(sz.grad_numel[i])
-        per_param.append(grads[off:off + n] if off >= 0 else None)
+    lay = _GRAD_LAYOUT.get(id(sz))
+    if lay is None:
+        lay = _GRAD_LAYOUT[id(sz)] = [(int(sz.grad_offset[i]), int(sz.grad_numel[i])) for i in range(P_COUNT)]
+    per_param: List[Optional[torch.Tensor]] = [grads[off:off + n] if off >= 0 else None for off, n in lay]
     return dX, dY, per_param
+
+
+_GRAD_LAYOUT: Dict[int, list] = {}
 
 
 class _AdapterFn(torch.autograd.Function):
