@@ -271,6 +271,11 @@ def main():
         # dominant kernel family = the MFMA GEMM engine (gemm_kernel<...>): time every launch of two extra steps
         # with HIP events on the launch stream (the library records them itself: dgsct_prof_enable).
         lib = default_lib()
+        from dgsct_amd import ops as _ops
+        conc, aux = stack.concurrent, _ops.USE_AUX_STREAM
+        stack.concurrent, _ops.USE_AUX_STREAM = False, False      # one stream: a kernel's events then bracket that kernel alone
+        eager_step()
+        torch.cuda.synchronize()
         lib.prof_enable(True)
         nprof = 2
         for _ in range(nprof):
@@ -278,6 +283,7 @@ def main():
         torch.cuda.synchronize()
         launches, gemm_ms, gemm_flops = lib.prof_collect()
         lib.prof_enable(False)
+        stack.concurrent, _ops.USE_AUX_STREAM = conc, aux
         alg = 3.0 * alg_flops_per_frame(stages) * BT                 # fwd + bwd, per step
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = alg * nprof / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0

@@ -92,6 +92,29 @@ __device__ __forceinline__ void stv(void* p, long i, const float (&v)[VE]) {
     }
   }
 }
+// raw (still packed) VE-element vector in a uint4 -- lets a kernel issue next-row loads early at 4 registers apiece
+template <int DT, int VE>
+__device__ __forceinline__ uint4 ldraw(const void* p, long i) {
+  constexpr int BYTES = VE * El<DT>::ES;
+  const char* q = reinterpret_cast<const char*>(p) + i * El<DT>::ES;
+  if (BYTES == 16) return *reinterpret_cast<const uint4*>(q);
+  if (BYTES == 8) { const uint2 t = *reinterpret_cast<const uint2*>(q); return make_uint4(t.x, t.y, 0, 0); }
+  uint4 r = make_uint4(0, 0, 0, 0);
+  if (BYTES == 4) r.x = *reinterpret_cast<const unsigned*>(q);
+  else r.x = *reinterpret_cast<const unsigned short*>(q);
+  return r;
+}
+template <int DT, int VE>
+__device__ __forceinline__ void unpack(const uint4& r, float (&v)[VE]) {
+  const unsigned w[4] = {r.x, r.y, r.z, r.w};
+  if (DT == DT_F32) {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = __uint_as_float(w[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+  }
+}
 // VE consecutive fp32 values
 template <int VE>
 __device__ __forceinline__ void ldf(const float* p, long i, float (&v)[VE]) {

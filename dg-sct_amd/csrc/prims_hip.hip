@@ -216,6 +216,15 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
     }
   }
   float tsum = 0.f;
+  uint4 pg[MAXNV], px[MAXNV];
+  auto fetch = [&](long row) {
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) { pg[v] = ldraw<DT, VE>(dX3, row * C + col); px[v] = ldraw<DT, VE>(X1, row * C + col); }
+    }
+  };
+  if (blockIdx.x * rpc + sub < n_end) fetch((long)b * N + blockIdx.x * rpc + sub);
   for (int n = blockIdx.x * rpc + sub; n < n_end; n += rpp) {
     const long row = (long)b * N + n;
     const float sgv = beta * sg[row];
@@ -226,8 +235,8 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
       if (v < nv && col < C) {
-        ldv<DT, VE>(dX3, row * C + col, g[v]);
-        ldv<DT, VE>(X1, row * C + col, x1[v]);
+        unpack<DT, VE>(pg[v], g[v]);
+        unpack<DT, VE>(px[v], x1[v]);
         if (lnw) {
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
@@ -241,6 +250,7 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
         }
       }
     }
+    if (n + rpp < n_end) fetch(row + rpp);
     if (lnw) {
       s1 = group_sum(s1, gs) / C;
       s2 = group_sum(s2, gs) / C;
@@ -366,7 +376,7 @@ void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2
 }
 
 template <int DT, int VE, int MAXNV>
-__global__ __launch_bounds__(256) void tail_bwd_k(const void* dOut, const void* Op, const float* sc2, const float* sh2,
+__global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void* dOut, const void* Op, const float* sc2, const float* sh2,
                                                   const float* mean2, const float* rstd2, const float* lnw,
                                                   const float* lnb, const float* gate, int gate_first, const float* mu,
                                                   const float* rstd, long rows, int C, int gs, int nv, int rpc, void* dO,
@@ -375,29 +385,43 @@ __global__ __launch_bounds__(256) void tail_bwd_k(const void* dOut, const void* 
   const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
   const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
   const float gv = gate ? *gate : 1.f;
-  float sc[MAXNV][VE], sh[MAXNV][VE], w[MAXNV][VE], bb[MAXNV][VE], m2[MAXNV][VE], r2[MAXNV][VE];
-  float acc[4][MAXNV][VE];   // 0: dlnw 1: dlnb 2: sum dO 3: sum dO*xh2
+  float sc[MAXNV][VE], sh[MAXNV][VE], w[MAXNV][VE], bb[MAXNV][VE];
+  float acc[4][MAXNV][VE];   // 0: dlnw 1: dlnb 2: sum dO 3: sum dO*Op (turned into sum dO*xh2 at the end)
 #pragma unroll
   for (int v = 0; v < MAXNV; ++v) {
     const int col = (v * gs + gl) * VE;
 #pragma unroll
     for (int e = 0; e < VE; ++e) { acc[0][v][e] = acc[1][v][e] = acc[2][v][e] = acc[3][v][e] = 0.f; }
     if (v < nv && col < C) {
-      if (sc2) { ldf<VE>(sc2, col, sc[v]); ldf<VE>(sh2, col, sh[v]); ldf<VE>(mean2, col, m2[v]); ldf<VE>(rstd2, col, r2[v]); }
+      if (sc2) { ldf<VE>(sc2, col, sc[v]); ldf<VE>(sh2, col, sh[v]); }
       if (lnw) { ldf<VE>(lnw, col, w[v]); ldf<VE>(lnb, col, bb[v]); }
     }
   }
   float gsum = 0.f;
+  // software pipeline: the next row's two 16-byte loads are in flight while this row is reduced and stored
+  uint4 pg[MAXNV], pop[MAXNV];
+  auto fetch = [&](long row) {
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) { pg[v] = ldraw<DT, VE>(dOut, row * C + col); pop[v] = ldraw<DT, VE>(Op, row * C + col); }
+    }
+  };
+  if ((long)blockIdx.x * rpc + sub < r_end) fetch((long)blockIdx.x * rpc + sub);
   for (long row = (long)blockIdx.x * rpc + sub; row < r_end; row += rpp) {
     float g[MAXNV][VE], o[MAXNV][VE], xh[MAXNV][VE], op[MAXNV][VE];
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) { unpack<DT, VE>(pg[v], g[v]); unpack<DT, VE>(pop[v], op[v]); }
+    }
+    if (row + rpp < r_end) fetch(row + rpp);
     const float mean = lnw ? mu[row] : 0.f, rs = lnw ? rstd[row] : 1.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
       if (v < nv && col < C) {
-        ldv<DT, VE>(dOut, row * C + col, g[v]);
-        ldv<DT, VE>(Op, row * C + col, op[v]);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
           o[v][e] = sc2 ? op[v][e] * sc[v][e] + sh[v][e] : op[v][e];
@@ -445,10 +469,22 @@ __global__ __launch_bounds__(256) void tail_bwd_k(const void* dOut, const void* 
           d[e] = t;
           if (sc2) {
             acc[2][v][e] += t;
-            acc[3][v][e] += t * (op[v][e] - m2[v][e]) * r2[v][e];
+            acc[3][v][e] += t * op[v][e];
           }
         }
         stv<DT, VE>(dO, row * C + col, d);
+      }
+    }
+  }
+  if (sc2) {       // sum dO*xh2 = rstd2 * (sum dO*Op - mean2 * sum dO): keeps mean2/rstd2 out of the row loop's registers
+#pragma unroll
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
+        float m2[VE], r2[VE];
+        ldf<VE>(mean2, col, m2); ldf<VE>(rstd2, col, r2);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[3][v][e] = r2[e] * (acc[3][v][e] - m2[e] * acc[2][v][e]);
       }
     }
   }
