@@ -43,6 +43,17 @@ def alg_flops_per_frame(stages, tk=32, r=8, g=2):
     return tot
 
 
+def alg_bytes_per_step(stages, BT, es=2):
+    """per adapter per frame fwd es*(2NC + NoCo + N), bwd es*(3NC + 2NoCo); + 3 x 4 B per parameter per step."""
+    tot = 0.0
+    for s in stages:
+        for (N, C, No, Co) in ((s["Nv"], s["Cv"], s["Na"], s["Ca"]), (s["Na"], s["Ca"], s["Nv"], s["Cv"])):
+            tot += (es * (2 * N * C + No * Co + N) + es * (3 * N * C + 2 * No * Co)) * 2 * s["layers"] * BT
+            nparam = N * No + C * Co + 2 * C * C + 3 * (C // 2) * C + C * (C // 2) + 2 * C * (C // 8) // 2 + 32 * C
+            tot += 3 * 4 * nparam * 2 * s["layers"]
+    return tot
+
+
 def build_stack(backbone, dtype, device, concurrent=True):
     torch.manual_seed(0)
     stages = ave_stage_shapes(backbone)
@@ -287,8 +298,15 @@ def main():
         alg = 3.0 * alg_flops_per_frame(stages) * BT                 # fwd + bwd, per step
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = alg * nprof / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.backbone == "swinv2_base" and args.batch == 16 and args.dtype == "bf16":
+            # bytes per GEMM launch through the L2's memory-side port (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc passes of
+            # tools/pmc_stack.sh over the 8 adapter shapes of this exact workload, scaled by the schedule)
+            traffic = round(json.load(open(tpath))["gemm_kernel<*>"]["bytes_per_launch"])
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                        traffic=None, kernel="dgsct::gemm_kernel<*> (all MFMA GEMM launches of a step)",
+                        traffic=traffic, traffic_unit="bytes/launch (PMC, profiles/r01_pmc_traffic.json)",
+                        alg_bytes_per_launch=round(alg_bytes_per_step(stages, BT) / max(launches // nprof, 1)), kernel="dgsct::gemm_kernel<*> (all MFMA GEMM launches of a step)",
                         launches_per_step=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
                         gemm_ms_per_step=round(gemm_ms / nprof, 3),

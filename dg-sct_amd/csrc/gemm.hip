@@ -511,7 +511,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     if (g.N % 128 != 0 && g.N % 96 == 0 && g.M >= 96) cfg = 1; // 128 x 96
     else if (g.M >= 96 && g.N >= 96) cfg = 0;                   // 128 x 128
     else cfg = 4;
-  } else if (g.atomic && g.M >= 1024 && g.N >= 1024) cfg = 0;   // dWn: a plain big GEMM
+  } else if (g.atomic && g.M >= 1024 && g.N >= 1024 && kflat >= 8192) cfg = 0;   // dWn: a plain big GEMM
   else {
     const long w0 = tiles(128, 128);
     const long last = w0 % 768;

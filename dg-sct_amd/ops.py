@@ -187,7 +187,7 @@ class _AdapterFn(torch.autograd.Function):
         ctx.save_for_backward(X, Y, *[p for p in plist if p is not None])
         ctx.present = [p is not None for p in plist]
         ctx.shapes = [tuple(p.shape) if p is not None else None for p in plist]
-        ctx.mark_non_differentiable()
+        ctx.set_materialize_grads(False)      # unused outputs (map of all but the last layer, tmap) arrive as None, not zeros
         if tmap is None:
             tmap = torch.empty(0, device=X.device)
         return out, amap, tmap
@@ -202,6 +202,8 @@ class _AdapterFn(torch.autograd.Function):
         it = iter(tensors[2:])
         plist = [next(it) if pres else None for pres in ctx.present]
         spec = ctx.spec
+        if dOut is None:
+            dOut = torch.zeros_like(X)
         dOut = dOut.contiguous()
         if dOut.dtype != X.dtype:
             dOut = dOut.to(X.dtype)

@@ -133,6 +133,45 @@ def test_real_shapes_bf16(shape):
             assert _l2(g, go.reshape(-1)) < 0.15, (k, _l2(g, go.reshape(-1)))
 
 
+STAGE01 = [(2304, 128, 4096, 96), (4096, 96, 2304, 128), (576, 256, 1024, 192), (1024, 192, 576, 256)]
+
+
+@pytest.mark.parametrize("shape", STAGE01)
+def test_real_shapes_stage01_fp32(shape):
+    """the large-token stages (N up to 4096, the remap GEMMs with K = 4096 / 2304) against the oracle, one clip"""
+    r = _real_case(*shape, BT=10, dtype=torch.float32)
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(*r[k]) < TOL_F32, k
+    for k, (g, go) in r["grads"].items():
+        assert rel_err(g, go.reshape(-1)) < TOL_F32, k
+
+
+@pytest.mark.parametrize("shape", [STAGE01[0], STAGE01[1]])
+def test_full_size_frames_are_independent(shape):
+    """BASELINE size (B=16 x T=10 = 160 frames, stage 0): with BatchNorm in eval mode no operation couples frames, so
+    the first clip of the 160-frame call must equal a 10-frame call on the same data (size-independent property;
+    exercises the full grids, the large-offset addressing and the XCD tile remap at the benchmark's shapes)."""
+    N, C, No, Co = shape
+    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
+    p = O.random_params(cfg, "ave", seed=5, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        params = param_table(p, spec, DEV)
+        gen = torch.Generator().manual_seed(7)
+        X = torch.randn(160, N, C, generator=gen).to(DEV, dtype)
+        Y = torch.randn(160, No, Co, generator=gen).to(DEV, dtype)
+        prep = ops.prepare(lib, spec, params, dtype, DEV)
+        big = ops.raw_forward(lib, spec, params, prep, X, Y, False)
+        small = ops.raw_forward(lib, spec, params, prep, X[:10].contiguous(), Y[:10].contiguous(), False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(big[0].float()).all()
+        assert nrm_err(big[0][:10], small[0].float().cpu()) < tol
+        assert nrm_err(big[1][:10], small[1].float().cpu()) < tol
+        assert nrm_err(big[0][150:], ops.raw_forward(lib, spec, params, prep, X[150:].contiguous(), Y[150:].contiguous(),
+                                                     False)[0].float().cpu()) < tol
+
+
 def test_module_dropin_matches_oracle():
     """nn.Module boundary: reference call convention ([BT,C,N,1] views), state_dict names, autograd."""
     from types import SimpleNamespace

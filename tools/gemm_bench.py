@@ -9,23 +9,18 @@ from dgsct_amd._lib import GemmArgs, default_lib
 DEV = "cuda:0"
 # (M, N, K, KB, batch, ak, bk, a_shared, atomic, out_bf16, residual)
 SHAPES = [
-    (2304, 96, 4096, 1, 160, 1, 0, 1, 0, 1, 0),     # T1 = Wn.Y
-    (4096, 96, 2304, 1, 160, 1, 1, 1, 0, 1, 0),     # Yp = Wn.T2
-    (96, 2304, 4096, 1, 160, 0, 0, 0, 0, 1, 0),     # dT2t
-    (2304, 4096, 96, 160, 1, 1, 1, 0, 1, 0, 0),     # dWn
-    (40960, 384, 384, 1, 1, 1, 1, 0, 0, 1, 0),      # vq1 stage 2
-    (23040, 512, 512, 1, 1, 1, 0, 0, 0, 1, 1),      # dX1 += dvq1.Wv1 stage 2
-    (368640, 128, 128, 1, 1, 1, 1, 0, 0, 1, 0),     # vq1 stage 0
-    (2304, 128, 32, 1, 160, 1, 0, 0, 0, 1, 1),      # X1 = X + P2.tok stage 0
-    (144, 512, 32, 1, 160, 1, 0, 0, 0, 1, 1),       # X1 stage 2
-    (144, 512, 384, 1, 160, 0, 0, 0, 0, 1, 0),      # dY stage2?
-    (512, 512, 23040, 1, 1, 0, 0, 0, 1, 0, 0),      # dWv1 stage 2
-    (384, 384, 40960, 1, 1, 0, 0, 0, 1, 0, 0),      # dWv1 stage 2 audio
-    (160, 192, 384, 1, 1, 1, 1, 0, 0, 1, 0),        # tiny gate GEMM
-    (368640, 8, 64, 1, 2, 1, 1, 0, 0, 1, 0),        # Zp grouped stage 0
-    (368640, 64, 8, 1, 2, 1, 1, 0, 0, 1, 0),        # Op grouped stage 0
-    (32, 2304, 128, 1, 160, 1, 1, 1, 0, 0, 0),      # S1 stage 0
-    (32, 128, 2304, 1, 160, 1, 0, 0, 0, 1, 1),      # tok stage 0
+    (128, 128, 368640, 1, 1, 0, 0, 0, 1, 0, 0),      # dWv1 stage 0 (TN, split-K atomics)
+    (64, 128, 368640, 1, 1, 0, 0, 0, 1, 0, 0),       # dWv2 stage 0
+    (128, 96, 368640, 1, 1, 0, 0, 0, 1, 0, 0),       # dWc stage 0
+    (256, 256, 92160, 1, 1, 0, 0, 0, 1, 0, 0),       # dWv1 stage 1
+    (512, 512, 23040, 1, 1, 0, 0, 0, 1, 0, 0),       # dWv1 stage 2
+    (1024, 1024, 5760, 1, 1, 0, 0, 0, 1, 0, 0),      # dWv1 stage 3
+    (64, 8, 368640, 1, 2, 0, 0, 0, 1, 0, 0),         # dWu stage 0 (grouped)
+    (8, 64, 368640, 1, 2, 0, 0, 0, 1, 0, 0),         # dWd stage 0
+    (368640, 128, 128, 1, 1, 1, 0, 0, 0, 1, 1),      # dX1 += dvq1.Wv1 stage 0
+    (368640, 128, 64, 1, 1, 1, 0, 0, 0, 1, 0),       # dXc = dvq2.Wv2
+    (368640, 96, 128, 1, 1, 1, 0, 0, 0, 1, 0),       # dT1 = dYp.Wc
+    (368640, 128, 96, 1, 1, 1, 1, 0, 0, 1, 0),       # Yp = T1.Wc^T
 ]
 
 def run(shape, iters=20):
@@ -64,7 +59,7 @@ if __name__ == "__main__":
         print("RESULT " + json.dumps(out))
         sys.exit(0)
     table = {}
-    for cfg in ["auto", 0, 1, 4, 5, 6, 7, 2, 3]:
+    for cfg in ["auto", 0, 1, 4, 2, 3]:
         env = dict(os.environ)
         if cfg != "auto":
             env["DGSCT_GEMM_CFG"] = str(cfg)
