@@ -58,6 +58,7 @@ def build_stack(backbone, dtype, device, concurrent=True):
     torch.manual_seed(0)
     stages = ave_stage_shapes(backbone)
     stack = AdapterStack(stages, compute_dtype=dtype, concurrent=concurrent).to(device)
+    stack.flatten_parameters()         # one flat fp32 parameter (and one flat gradient) per adapter: 48 tensors, not ~1900
     with torch.no_grad():
         for n, p in stack.named_parameters():
             if n.endswith("gate") or n.endswith("gate_av"):
@@ -150,6 +151,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no audio/visual adapter overlap)")
     ap.add_argument("--no-aux", action="store_true", help="no aux stream for weight gradients")
+    ap.add_argument("--force-dp", action="store_true", help="run the RCCL gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of eager launches "
                     "(ROCm 7.2: replaying ~6000 nodes costs as much host time as launching them, so this is off by default)")
     args = ap.parse_args()
@@ -161,8 +163,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    dp = world > 1 or args.force_dp
+    if dp:
         import torch.distributed as dist
+        if "RANK" not in os.environ:       # --force-dp without a launcher
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
         dist.init_process_group("nccl", device_id=device)       # "nccl" is RCCL on ROCm
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     T = 10
@@ -171,13 +176,13 @@ def main():
     stages, stack = build_stack(args.backbone, dtype, device, concurrent=not args.serial)
     stack.train()
     params = [p for p in stack.parameters() if p.requires_grad]
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         for p in stack.parameters():
             dist.broadcast(p.data, 0)
     # N > 1: gradients are reduced after backward (buckets launched back-to-back on a side stream, RCCL), outside the
     # captured graph -- collectives are kept out of the capture on purpose.
-    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack), overlap=False) if world > 1 else None
+    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack), overlap=False, force=args.force_dp) if dp else None
     use_graph = args.graph
     if use_graph or args.no_aux:
         from dgsct_amd import ops as _ops
@@ -202,8 +207,8 @@ def main():
     def update():
         if opt is not None:
             opt.step()
-            opt.zero_grad(set_to_none=world == 1)
-        elif world == 1:
+            opt.zero_grad(set_to_none=not (use_graph and dp))
+        elif not (use_graph and dp):
             for p in params:
                 p.grad = None
         else:
@@ -237,7 +242,7 @@ def main():
                 eager_step()            # allocator + optimizer-state warm-up, as torch.cuda.graphs requires
         torch.cuda.current_stream(device).wait_stream(s)
         torch.cuda.synchronize()
-        if world == 1:
+        if not dp:
             def whole():
                 fwd_bwd()
                 update()
@@ -253,7 +258,7 @@ def main():
                 update()                # zero_grad(set_to_none=False): keeps the captured buffers
 
     def barrier():
-        if world > 1:
+        if dp:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -269,7 +274,7 @@ def main():
         host_s += time.perf_counter() - h0
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -311,7 +316,7 @@ def main():
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
                         gemm_ms_per_step=round(gemm_ms / nprof, 3),
                         step_frac_of_mfma_peak=round(alg / (ms_per_step * 1e-3) / 1e12 / peak, 4))
-    if world > 1:
+    if dp:
         barrier()
 
     if rank == 0:
@@ -325,11 +330,11 @@ def main():
             config=dict(workload=f"AVE fine-tune adapter stack (BASELINE configs[1]): {args.backbone} + HTS-AT token/width "
                                  f"shapes, 48 DG-SCT adapters, B={args.batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on",
                         global_batch=args.batch * world, frames_per_clip=T, parallelism=f"dp{world}",
-                        step="fwd+bwd" + ("+allreduce" if world > 1 else "") + ("" if args.no_optim else "+adam"),
+                        step="fwd+bwd" + ("+allreduce" if dp else "") + ("" if args.no_optim else "+adam"),
                         streams=1 if args.serial else 2, hip_graph=use_graph, host_enqueue_ms_per_step=round(host_s / args.steps * 1e3, 2)),
             roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -131,6 +131,7 @@ class VisualAdapter(nn.Module):
         if cache is None:
             sd = dict(self.named_parameters())
             sd.update(dict(self.named_buffers()))
+            sd.update(self.__dict__.get("_flat_views", {}))
             cache = []
             for name in PARAM_NAMES:
                 t = sd.get(name)
@@ -162,7 +163,75 @@ class VisualAdapter(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self.__dict__.pop("_ptab", None)        # .to()/.cuda()/.float(): buffers may be replaced
-        return super()._apply(fn, *a, **k)
+        r = super()._apply(fn, *a, **k)
+        if "_flat_views" in self.__dict__:
+            self._rebuild_flat_views()
+        return r
+
+    # ------------------------------------------------------------------ flat parameters (opt-in)
+    def flatten_parameters(self):
+        """Move every trainable tensor of this adapter into ONE flat fp32 ``nn.Parameter`` (``flat_param``) laid out like
+        the library's gradient buffer.  ``state_dict()`` / ``load_state_dict()`` keep the reference's names (hooks below);
+        ``named_parameters()`` then lists ``flat_param`` instead of the ~30 individual tensors (its name still contains
+        ``adapter_blocks`` inside the task models, so the reference's freeze-by-name rule is unaffected)."""
+        if "_flat_views" in self.__dict__:
+            return self
+        lib = self._lib or _lib.default_lib()
+        d = self.spec.desc(self.spec.T, torch.float32, True)
+        lay = ops.grad_layout(lib, d)
+        total = int(ops._sizes(lib, d).grad_floats)
+        named = dict(self.named_parameters())
+        dev = next(iter(named.values())).device
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._flat_layout = {}
+        for i, name in enumerate(PARAM_NAMES):
+            off, n = lay[i]
+            if off < 0 or name not in named:
+                continue
+            p = named[name]
+            flat[off:off + n].copy_(p.detach().reshape(-1))
+            self._flat_layout[name] = (off, n, tuple(p.shape))
+            owner, leaf = self, name
+            if "." in name:
+                path, leaf = name.rsplit(".", 1)
+                owner = self.get_submodule(path)
+            del owner._parameters[leaf]                   # the name stays reachable as a plain tensor view (set below)
+        self.flat_param = nn.Parameter(flat)
+        self.__dict__["_flat_views"] = {}
+        self._rebuild_flat_views()
+        self._register_state_dict_hook(VisualAdapter._flat_state_dict_hook)
+        self._register_load_state_dict_pre_hook(self._flat_load_pre_hook)
+        return self
+
+    def _rebuild_flat_views(self):
+        views = {}
+        for name, (off, n, shape) in self._flat_layout.items():
+            v = self.flat_param.data[off:off + n].view(shape)
+            views[name] = v
+            owner, leaf = self, name
+            if "." in name:
+                path, leaf = name.rsplit(".", 1)
+                owner = self.get_submodule(path)
+            object.__setattr__(owner, leaf, v)
+        self.__dict__["_flat_views"] = views
+        self.__dict__.pop("_ptab", None)
+
+    @staticmethod
+    def _flat_state_dict_hook(module, state_dict, prefix, local_metadata):
+        state_dict.pop(prefix + "flat_param", None)
+        for name, v in module.__dict__["_flat_views"].items():
+            state_dict[prefix + name] = v.detach()
+        return state_dict
+
+    def _flat_load_pre_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name, v in self.__dict__["_flat_views"].items():
+            key = prefix + name
+            if key in state_dict:
+                with torch.no_grad():
+                    v.copy_(state_dict.pop(key).reshape(v.shape))
+            elif strict:
+                missing_keys.append(key)
+        state_dict[prefix + "flat_param"] = self.flat_param.detach()
 
     def _prepared(self, lib, params, dtype, device):
         key = (dtype, device, tuple((p.data_ptr(), p._version) for p in params if p is not None))
@@ -188,7 +257,8 @@ class VisualAdapter(nn.Module):
         params = [ops.check_param(n, p, X.device) for n, p in zip(PARAM_NAMES, self._param_list())]
         prep = self._prepared(lib, params, cd, X.device)
         training = self.training
-        out, amap, tmap = ops.adapter_apply(lib, self.spec, training, prep, X, Y, params)
+        flat = self.flat_param if "_flat_views" in self.__dict__ else None
+        out, amap, tmap = ops.adapter_apply(lib, self.spec, training, prep, X, Y, params, flat)
         if training and self.use_bn:
             self.bn1.num_batches_tracked += 1
             self.bn2.num_batches_tracked += 1

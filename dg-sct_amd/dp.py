@@ -3,13 +3,20 @@
 The reference has no multi-process training at all (single GPU, or single-process nn.DataParallel:
 avs_s4/train.py:139, main_avst.py:236; SURVEY.md header).  Clips are independent through the whole
 adapter path, so DP shards clips across ranks and the only collective is the all-reduce of the
-adapter gradients (188.5 M params = 754 MB fp32 for AVE/Swin-L).
+adapter gradients (143 M params = 572 MB fp32 for AVE/Swin-B, 754 MB for Swin-L).
 
-Design for xGMI (point-to-point links, no switch): few large buckets (one per backbone stage, filled
-in reverse order because backward reaches stage 3 first), each launched as soon as its last
-gradient is produced, on a side stream so that the stage-0/1 backward (most of the FLOPs) hides
-the stage-3/2 traffic.  Gradients are averaged (sum / world).  Parameters that never receive a
-gradient (``gate_tk`` ...) are reduced as zeros so every rank issues identical collectives.
+Zero-copy design: ``dgsct_adapter_backward`` writes ALL parameter gradients of one adapter call into one
+flat fp32 buffer.  With flattened adapters (``VisualAdapter.flatten_parameters``) that buffer IS the gradient
+of the adapter's single parameter, so the natural communication unit is that buffer: 48 all-reduces of
+3-45 MB per step, issued in place (no flatten / unflatten kernels; the first version copied ~1900 tensors
+in and out and cost 38 ms per step).  xGMI is point-to-point
+(no switch): messages of tens of MB keep every link busy without the per-bucket latency dominating.
+Buckets (one per backbone stage, backward order) only decide WHEN buffers are launched: with
+``overlap=True`` a stage's buffers go to a side stream as soon as its last gradient has been produced,
+so the stage-0/1 backward hides the stage-3/2 traffic.  Gradients are averaged (sum / world).
+Un-flattened modules (the ~1900 individual tensors of the reference layout) fall back to one
+flattened (torch.cat) all-reduce per bucket plus a copy back.  Parameters without a gradient do
+not communicate (every rank runs the same graph, so every rank skips the same ones).
 """
 from __future__ import annotations
 
@@ -21,88 +28,88 @@ import torch.distributed as dist
 
 class GradAllReducer:
     def __init__(self, buckets: Sequence[Sequence[torch.nn.Parameter]], process_group=None, overlap: bool = True,
-                 comm_dtype: Optional[torch.dtype] = None):
+                 comm_dtype: Optional[torch.dtype] = None, force: bool = False):
         """buckets: parameter groups in the order backward finishes them (stage 3 first)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()        # run the collectives even with one rank (self-test)
+        self.active = self.world > 1 or self.force
         self.overlap = overlap
         self.comm_dtype = comm_dtype
         self.buckets: List[List[torch.nn.Parameter]] = [[p for p in b if p.requires_grad] for b in buckets]
         self.buckets = [b for b in self.buckets if b]
-        self.flat: List[torch.Tensor] = []
-        self.views: List[List[torch.Tensor]] = []
-        self._bucket_of: Dict[int, int] = {}
-        for bi, b in enumerate(self.buckets):
-            n = sum(p.numel() for p in b)
-            dev = b[0].device
-            flat = torch.zeros(n, dtype=comm_dtype or torch.float32, device=dev)
-            self.flat.append(flat)
-            vs, off = [], 0
-            for p in b:
-                vs.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-                self._bucket_of[id(p)] = bi
-            self.views.append(vs)
         self._pending = [0] * len(self.buckets)
-        self._ready: List[List[bool]] = [[False] * len(b) for b in self.buckets]
-        self._work: List[Optional[object]] = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._work: List[object] = []
+        self._reduced: List[torch.Tensor] = []          # tensors to scale by 1/world after the wait
+        self._copy_back: List[tuple] = []               # (flat, params) of the fallback path
         self._stream = None
         self._hooks = []
-        if self.world > 1 and overlap:
+        if self.active and overlap:
             for bi, b in enumerate(self.buckets):
-                for pi, p in enumerate(b):
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, pi)))
+                for p in b:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
     # ------------------------------------------------------------------
-    def _make_hook(self, bi: int, pi: int):
+    def _make_hook(self, bi: int):
         def hook(param):
-            self._ready[bi][pi] = True
             self._pending[bi] += 1
             if self._pending[bi] == len(self.buckets[bi]):
                 self._launch(bi)
         return hook
 
+    def _all_reduce(self, t: torch.Tensor):
+        if t.is_cuda and self.overlap:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=t.device)
+            self._stream.wait_stream(torch.cuda.current_stream(t.device))
+            with torch.cuda.stream(self._stream):
+                self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._reduced.append(t)
+
     def _launch(self, bi: int):
         if self._launched[bi]:
             return
         self._launched[bi] = True
-        flat = self.flat[bi]
-        for p, v in zip(self.buckets[bi], self.views[bi]):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        if flat.is_cuda and self.overlap:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=flat.device)
-            self._stream.wait_stream(torch.cuda.current_stream(flat.device))
-            with torch.cuda.stream(self._stream):
-                self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        grads = [p for p in self.buckets[bi] if p.grad is not None]
+        big = [p for p in grads if p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.numel() >= 4096
+               and self.comm_dtype in (None, torch.float32)]
+        if len(big) <= 64:
+            # flattened adapters (VisualAdapter.flatten_parameters): the gradient of an adapter IS the library's flat
+            # buffer -> reduce it in place, no staging copies
+            for p in big:
+                self._all_reduce(p.grad)
+            loose = [p for p in grads if all(p is not q for q in big)]
         else:
-            self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            loose = grads
+        if loose:                                       # everything else: one flattened message per bucket
+            flat = torch.cat([p.grad.reshape(-1).to(self.comm_dtype or torch.float32) for p in loose])
+            self._all_reduce(flat)
+            self._copy_back.append((flat, loose))
 
     def finish(self):
-        """Call after loss.backward(): launches what the hooks did not, waits, writes averaged grads back."""
-        if self.world <= 1:
+        """Call after loss.backward(): launches what the hooks did not, waits, averages."""
+        if not self.active:
             return
         for bi in range(len(self.buckets)):
             self._launch(bi)
-        for bi, w in enumerate(self._work):
-            if w is not None:
-                w.wait()
-        if self._stream is not None:
-            torch.cuda.current_stream(self.flat[0].device).wait_stream(self._stream)
-        inv = 1.0 / self.world
-        for bi, b in enumerate(self.buckets):
-            for p, v in zip(b, self.views[bi]):
-                if p.grad is None:
-                    continue        # stays None on every rank (same graph on every rank)
-                p.grad.copy_(v).mul_(inv) if p.grad.dtype == v.dtype else p.grad.copy_(v.to(p.grad.dtype)).mul_(inv)
+        for w in self._work:
+            w.wait()
+        if self._stream is not None and self._reduced:
+            torch.cuda.current_stream(self._reduced[0].device).wait_stream(self._stream)
+        if self._reduced:
+            torch._foreach_mul_(self._reduced, 1.0 / self.world)
+        for flat, params in self._copy_back:
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
         self._pending = [0] * len(self.buckets)
-        self._ready = [[False] * len(b) for b in self.buckets]
-        self._work = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._work, self._reduced, self._copy_back = [], [], []
 
     @staticmethod
     def stage_buckets(stack) -> List[List[torch.nn.Parameter]]:

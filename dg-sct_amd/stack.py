@@ -74,6 +74,14 @@ class AdapterStack(nn.Module):
         self.audio_adapter_blocks_p2 = nn.ModuleList([audio(i) for i in range(n)])
         self.vis_adapter_blocks_p2 = nn.ModuleList([visual(i) for i in range(n)])
 
+    def flatten_parameters(self):
+        """one flat fp32 parameter per adapter (see VisualAdapter.flatten_parameters); 48 tensors for the AVE stack"""
+        for ml in (self.audio_adapter_blocks_p1, self.vis_adapter_blocks_p1, self.audio_adapter_blocks_p2,
+                   self.vis_adapter_blocks_p2):
+            for m in ml:
+                m.flatten_parameters()
+        return self
+
     @staticmethod
     def _view(f: torch.Tensor) -> torch.Tensor:
         return f.permute(0, 2, 1).unsqueeze(-1)          # the reference's [BT,C,N,1] view of a token-major map
