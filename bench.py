@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no audio/visual adapter overlap)")
     ap.add_argument("--no-aux", action="store_true", help="no aux stream for weight gradients")
     ap.add_argument("--force-dp", action="store_true", help="run the RCCL gradient all-reduce path even with one rank (self-test)")
+    ap.add_argument("--overlap", action="store_true", help="DP: launch each stage's all-reduce from autograd hooks while the "
+                    "earlier stages' backward still runs (default: one grouped all-reduce after backward; see DESIGN.md section 5)")
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of eager launches "
                     "(ROCm 7.2: replaying ~6000 nodes costs as much host time as launching them, so this is off by default)")
     args = ap.parse_args()
@@ -168,7 +170,8 @@ def main():
         import torch.distributed as dist
         if "RANK" not in os.environ:       # --force-dp without a launcher
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
-        dist.init_process_group("nccl", device_id=device)       # "nccl" is RCCL on ROCm
+        from dgsct_amd import init_process_group
+        init_process_group(device)       # "nccl" IS RCCL on ROCm; collective stream in the high-priority queue pool
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     T = 10
     BT = args.batch * T
@@ -180,9 +183,10 @@ def main():
         import torch.distributed as dist
         for p in stack.parameters():
             dist.broadcast(p.data, 0)
-    # N > 1: gradients are reduced after backward (buckets launched back-to-back on a side stream, RCCL), outside the
-    # captured graph -- collectives are kept out of the capture on purpose.
-    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack), overlap=False, force=args.force_dp) if dp else None
+    # N > 1: the 48 flat gradient buffers are all-reduced in place (RCCL, ncclAvg) as ONE grouped call after backward.
+    # --overlap launches per-stage groups from autograd hooks instead; on ROCm 7.2 its extra cross-stream events can
+    # stall the HIP launch path depending on stream->hardware-queue placement, so it is opt-in.
+    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack), overlap=args.overlap and not args.graph, force=args.force_dp) if dp else None
     use_graph = args.graph
     if use_graph or args.no_aux:
         from dgsct_amd import ops as _ops
@@ -225,11 +229,20 @@ def main():
         graphs.append(g)
         return g.replay
 
+    host_parts = [0.0, 0.0, 0.0]           # host seconds spent enqueueing fwd+bwd / all-reduce / optimizer
+
     def eager_step():
+        t0 = time.perf_counter()
         fwd_bwd()
+        t1 = time.perf_counter()
         if reducer is not None:
             reducer.finish()
+        t2 = time.perf_counter()
         update()
+        t3 = time.perf_counter()
+        host_parts[0] += t1 - t0
+        host_parts[1] += t2 - t1
+        host_parts[2] += t3 - t2
 
     step = eager_step
     if use_graph:
@@ -266,6 +279,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    host_parts[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     host_s = 0.0
     for _ in range(args.steps):
@@ -280,6 +294,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
+    host_ms = [round(x / args.steps * 1e3, 2) for x in host_parts]
     clips_per_s = args.batch * world / (elapsed / args.steps)
 
     roofline = None
@@ -331,7 +346,8 @@ def main():
                                  f"shapes, 48 DG-SCT adapters, B={args.batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on",
                         global_batch=args.batch * world, frames_per_clip=T, parallelism=f"dp{world}",
                         step="fwd+bwd" + ("+allreduce" if dp else "") + ("" if args.no_optim else "+adam"),
-                        streams=1 if args.serial else 2, hip_graph=use_graph, host_enqueue_ms_per_step=round(host_s / args.steps * 1e3, 2)),
+                        streams=1 if args.serial else 2, hip_graph=use_graph, host_enqueue_ms_per_step=round(host_s / args.steps * 1e3, 2),
+                        host_ms_fwdbwd_allreduce_optim=host_ms),
             roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if dp:

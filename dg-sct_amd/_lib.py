@@ -56,7 +56,8 @@ class GemmArgs(C.Structure):
 
 
 EXPORTS = ["dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
-           "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect"]
+           "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect",
+           "dgsct_stream_create", "dgsct_stream_destroy"]
 
 _PP = C.POINTER(C.c_void_p)
 
@@ -88,6 +89,8 @@ class Lib:
         c.dgsct_saved_region.argtypes = [C.POINTER(AdapterDesc), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]
         c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        c.dgsct_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        c.dgsct_stream_destroy.argtypes = [C.c_void_p]
         if c.dgsct_version() != 100:
             raise RuntimeError("dg-sct_amd: libdgsct version mismatch")
 
@@ -128,6 +131,12 @@ class Lib:
             out[name.value.decode()] = (off.value, nb.value)
             i += 1
         return out
+
+    def stream_create(self, priority_class: int) -> int:
+        """raw hipStream_t in its own priority class (-1 high, 0 normal, +1 low) = its own hardware-queue pool"""
+        out = C.c_void_p()
+        self._check(self.c.dgsct_stream_create(int(priority_class), C.byref(out)), "dgsct_stream_create")
+        return int(out.value or 0)
 
     def prof_enable(self, on: bool):
         self.c.dgsct_prof_enable(int(on))

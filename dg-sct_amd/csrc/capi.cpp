@@ -83,6 +83,19 @@ int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int na
   return 0;
 }
 
+int dgsct_stream_create(int priority_class, void** stream) {
+  clear_error();
+  if (!stream) return 2;
+  *stream = stream_create(priority_class);
+  return has_error() ? 1 : 0;
+}
+
+int dgsct_stream_destroy(void* stream) {
+  clear_error();
+  stream_destroy(stream);
+  return has_error() ? 1 : 0;
+}
+
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
   clear_error();
   if (!a) return 2;

@@ -25,6 +25,10 @@ struct Ctx {
 };
 // aux waits for everything enqueued on stream so far / stream waits for everything enqueued on aux so far.
 // No-ops when ctx.aux is null.
+// a stream of its own priority class (-1 high, 0 normal, +1 low): the HIP runtime keeps one hardware-queue pool per
+// priority, so streams of different classes never share (and serialise on) a hardware queue
+void* stream_create(int priority_class);
+void stream_destroy(void* stream);
 void stream_fork(const Ctx&);
 void stream_join(const Ctx&);
 

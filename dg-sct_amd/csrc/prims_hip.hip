@@ -32,6 +32,21 @@ static hipEvent_t next_event() {
   n = (n + 1) & 31;
   return e;
 }
+void* stream_create(int priority_class) {
+  int least = 0, greatest = 0;                       // numerically: the greatest priority is the SMALLER number
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) { set_error("hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e)); return nullptr; }
+  int prio = priority_class < 0 ? greatest : (priority_class > 0 ? least : (least + greatest) / 2);
+  hipStream_t s = nullptr;
+  e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
+  if (e != hipSuccess) { set_error("hipStreamCreateWithPriority(%d): %s", prio, hipGetErrorString(e)); return nullptr; }
+  return s;
+}
+
+void stream_destroy(void* stream) {
+  if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+}
+
 void stream_fork(const Ctx& ctx) {
   if (!ctx.aux) return;
   hipEvent_t e = next_event();

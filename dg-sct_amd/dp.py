@@ -22,8 +22,25 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def init_process_group(device: torch.device, backend: str = "nccl", **kw):
+    """``dist.init_process_group`` for one-process-per-GPU data parallelism over RCCL ("nccl" IS RCCL on ROCm).
+
+    The collective kernels run on ProcessGroupNCCL's internal stream.  Taken from torch's normal-priority pool that
+    stream may share a hardware queue with the compute stream (the HIP runtime multiplexes all streams of a priority
+    class onto 4 queues); its event waits then stall the compute stream and serialise the audio/visual adapter streams
+    (measured: 94 -> 148 ms per step on one MI355X).  The high-priority pool holds only this stream and the stack's
+    second adapter stream, which land on different queues."""
+    if backend == "nccl":
+        hi = os.environ.get("DGSCT_NCCL_HIGH_PRIORITY", "0") == "1"
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=hi)
+        return dist.init_process_group(backend, device_id=device, pg_options=opts, **kw)
+    return dist.init_process_group(backend, **kw)
 
 
 class GradAllReducer:
@@ -44,6 +61,7 @@ class GradAllReducer:
         self._reduced: List[torch.Tensor] = []          # tensors to scale by 1/world after the wait
         self._copy_back: List[tuple] = []               # (flat, params) of the fallback path
         self._stream = None
+        self._avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._hooks = []
         if self.active and overlap:
             for bi, b in enumerate(self.buckets):
@@ -53,21 +71,49 @@ class GradAllReducer:
     # ------------------------------------------------------------------
     def _make_hook(self, bi: int):
         def hook(param):
+            if param.grad is not None and param.grad.is_cuda:
+                # the gradient was produced on whatever stream this adapter's backward ran on (main or the audio-side
+                # stream of AdapterStack): the communication stream must order after every producer of the bucket
+                self._comm_stream(param.grad.device).wait_stream(torch.cuda.current_stream(param.grad.device))
             self._pending[bi] += 1
             if self._pending[bi] == len(self.buckets[bi]):
                 self._launch(bi)
         return hook
 
-    def _all_reduce(self, t: torch.Tensor):
-        if t.is_cuda and self.overlap:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=t.device)
-            self._stream.wait_stream(torch.cuda.current_stream(t.device))
-            with torch.cuda.stream(self._stream):
-                self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+    def _comm_stream(self, device):
+        if self._stream is None:
+            # Only event waits/records live on this stream (the collective kernels run on ProcessGroupNCCL's own stream).
+            # Low priority class = a hardware queue shared with no compute stream (caller: normal, adapter side streams:
+            # high): a barrier packet waiting for the slower adapter stream must not sit in the other one's queue.
+            from . import _lib, ops
+            self._stream = ops.priority_stream(_lib.default_lib(), device, +1)
+        return self._stream
+
+    def _all_reduce(self, tensors: List[torch.Tensor]):
+        """one grouped, in-place all-reduce of `tensors` (ncclGroupStart/End: ONE work object and ONE pair of stream
+        events for the whole group -- per-tensor calls cost 48 event pairs per step, which stalls the HIP launch path)"""
+        # RCCL averages in the collective itself (ncclAvg); gloo (CPU tests) sums and finish() scales
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+
+        def issue():
+            if len(tensors) == 1 or not self._avg_in_collective:
+                for t in tensors:
+                    self._work.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+            else:
+                with dist._coalescing_manager(self.group, async_ops=True) as cm:
+                    for t in tensors:
+                        dist.all_reduce(t, op=op, group=self.group)
+                self._work.append(cm)
+
+        if tensors[0].is_cuda and self.overlap:
+            st = self._comm_stream(tensors[0].device)
+            st.wait_stream(torch.cuda.current_stream(tensors[0].device))
+            with torch.cuda.stream(st):
+                issue()
         else:
-            self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self._reduced.append(t)
+            issue()
+        if not self._avg_in_collective:
+            self._reduced.extend(tensors)
 
     def _launch(self, bi: int):
         if self._launched[bi]:
@@ -79,14 +125,14 @@ class GradAllReducer:
         if len(big) <= 64:
             # flattened adapters (VisualAdapter.flatten_parameters): the gradient of an adapter IS the library's flat
             # buffer -> reduce it in place, no staging copies
-            for p in big:
-                self._all_reduce(p.grad)
+            if big:
+                self._all_reduce([p.grad for p in big])
             loose = [p for p in grads if all(p is not q for q in big)]
         else:
             loose = grads
         if loose:                                       # everything else: one flattened message per bucket
             flat = torch.cat([p.grad.reshape(-1).to(self.comm_dtype or torch.float32) for p in loose])
-            self._all_reduce(flat)
+            self._all_reduce([flat])
             self._copy_back.append((flat, loose))
 
     def finish(self):
@@ -97,8 +143,8 @@ class GradAllReducer:
             self._launch(bi)
         for w in self._work:
             w.wait()
-        if self._stream is not None and self._reduced:
-            torch.cuda.current_stream(self._reduced[0].device).wait_stream(self._stream)
+        if self._stream is not None:
+            torch.cuda.current_stream(self._stream.device).wait_stream(self._stream)
         if self._reduced:
             torch._foreach_mul_(self._reduced, 1.0 / self.world)
         for flat, params in self._copy_back:

@@ -4,6 +4,7 @@ stream selection, and the autograd.Function that replaces the reference's ~45-op
 from __future__ import annotations
 
 import dataclasses
+import os
 import threading
 from typing import Dict, List, Optional, Tuple
 
@@ -80,18 +81,30 @@ def _stream_of(t: torch.Tensor) -> int:
 
 
 _AUX: Dict[Tuple, "torch.cuda.Stream"] = {}
-USE_AUX_STREAM = True
+USE_AUX_STREAM = os.environ.get("DGSCT_NO_AUX", "0") != "1"
 
 
-def _aux_stream(t: torch.Tensor, stream: int) -> Optional[int]:
-    """one side stream per (device, caller stream): weight gradients overlap the data-gradient chain on it"""
+COMPUTE_PRIORITY_CLASS = int(os.environ.get("DGSCT_COMPUTE_PRIORITY", "-1"))
+
+
+def priority_stream(lib: Lib, device: torch.device, priority_class: int) -> "torch.cuda.Stream":
+    """A torch handle on a library-created HIP stream of the given priority class (-1 high / 0 / +1 low).  Streams of
+    different classes never share a hardware queue (include/dgsct.h, dgsct_stream_create), whatever else (RCCL, torch's
+    stream pool) has created streams before."""
+    with torch.cuda.device(device):
+        raw = lib.stream_create(priority_class)
+    return torch.cuda.ExternalStream(raw, device=device)
+
+
+def _aux_stream(lib: Lib, t: torch.Tensor, stream: int) -> Optional[int]:
+    """one low-priority side stream per (device, caller stream): weight gradients overlap the data-gradient chain on it"""
     if not (USE_AUX_STREAM and t.is_cuda):
         return None
     key = (t.device.index, stream)
     with _WS_LOCK:
         s = _AUX.get(key)
         if s is None:
-            s = _AUX[key] = torch.cuda.Stream(device=t.device)
+            s = _AUX[key] = priority_stream(lib, t.device, COMPUTE_PRIORITY_CLASS)
     return s.cuda_stream
 
 
@@ -164,7 +177,7 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     ws = _workspace(dev, stream, int(sz.ws_bwd_bytes))
     lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
                  dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
-                 dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(X, stream))
+                 dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(lib, X, stream))
     if flat_out:
         return dX, dY, grads
     lay = grad_layout(lib, d)

@@ -102,7 +102,9 @@ class AdapterStack(nn.Module):
         if self.concurrent and dev.type == "cuda":
             side = self._side_streams.get(dev.index)
             if side is None:
-                side = self._side_streams[dev.index] = torch.cuda.Stream(device=dev)
+                from . import _lib, ops
+                lib = self.audio_adapter_blocks_p1[0]._lib or _lib.default_lib()
+                side = self._side_streams[dev.index] = ops.priority_stream(lib, dev, ops.COMPUTE_PRIORITY_CLASS)
 
         def pair(audio_mod, vis_mod, f_a, f_v):
             if side is None:

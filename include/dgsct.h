@@ -103,6 +103,15 @@ const char* dgsct_last_error(void);      /* thread-local, valid until the next f
 
 int dgsct_query(const dgsct_adapter_desc* desc, dgsct_sizes* out);
 
+/* A HIP stream in its own priority class (-1 high, 0 normal, +1 low).  The HIP runtime multiplexes all streams of one
+ * priority onto a small pool of hardware queues (4 by default), and which streams end up sharing a queue depends on
+ * creation order (e.g. whether RCCL was initialised first): two "concurrent" streams on one queue serialise.  Queue
+ * pools are per priority, so the caller stream (normal), the second adapter stream (high) and the weight-gradient
+ * stream (low, off the critical path) are guaranteed distinct queues.  No reference counterpart (the reference runs
+ * everything on torch's current stream). */
+int dgsct_stream_create(int priority_class, void** stream);
+int dgsct_stream_destroy(void* stream);
+
 /* params[DGSCT_P_COUNT]: fp32 device pointers.  Writes `prep` (prep_bytes).  Must be re-run whenever a
  * parameter changed (after every optimizer step); cheap (one pass over the weights). */
 int dgsct_prepare(const dgsct_adapter_desc* desc, float* const* params, void* prep, void* stream);

@@ -28,6 +28,8 @@ static inline float sigm(float x) { return 1.f / (1.f + std::exp(-x)); }
 void gemm_prof_enable(int) {}
 void gemm_prof_collect(long* n, double* ms, double* fl) { if (n) *n = 0; if (ms) *ms = 0; if (fl) *fl = 0; }
 
+void* stream_create(int) { return nullptr; }
+void stream_destroy(void*) {}
 void stream_fork(const Ctx&) {}
 void stream_join(const Ctx&) {}
 
