@@ -56,7 +56,7 @@ class GemmArgs(C.Structure):
 
 
 EXPORTS = ["dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
-           "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect",
+           "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect",
            "dgsct_stream_create", "dgsct_stream_destroy"]
 
 _PP = C.POINTER(C.c_void_p)
@@ -85,7 +85,9 @@ class Lib:
         c.dgsct_adapter_backward.argtypes = [C.POINTER(AdapterDesc), _PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p]
-        c.dgsct_adapter_backward_ex.argtypes = c.dgsct_adapter_backward.argtypes + [C.c_void_p]
+        c.dgsct_adapter_backward_ex.argtypes = c.dgsct_adapter_backward.argtypes + [C.c_void_p, C.c_int]
+        fa = list(c.dgsct_adapter_forward.argtypes)
+        c.dgsct_adapter_forward_ex.argtypes = fa[:5] + [C.c_void_p] + fa[5:]
         c.dgsct_saved_region.argtypes = [C.POINTER(AdapterDesc), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]
         c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
@@ -114,13 +116,15 @@ class Lib:
     def prepare(self, desc, ptrs, prep: int, stream: int):
         self._check(self.c.dgsct_prepare(C.byref(desc), C.cast(ptrs, _PP), prep, stream), "dgsct_prepare")
 
-    def forward(self, desc, ptrs, prep, X, Y, out, amap, tmap, saved, ws, stream):
-        self._check(self.c.dgsct_adapter_forward(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, out, amap, tmap, saved, ws,
-                                                 stream), "dgsct_adapter_forward")
+    def forward(self, desc, ptrs, prep, X, Y, out, amap, tmap, saved, ws, stream, residual=None):
+        self._check(self.c.dgsct_adapter_forward_ex(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, residual, out, amap, tmap,
+                                                    saved, ws, stream), "dgsct_adapter_forward")
 
-    def backward(self, desc, ptrs, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream=None):
+    def backward(self, desc, ptrs, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream=None,
+                 skip_into_dx=False):
         self._check(self.c.dgsct_adapter_backward_ex(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, saved, dOut, dMap, dTmap,
-                                                     dX, dY, grads, ws, stream, aux_stream), "dgsct_adapter_backward")
+                                                     dX, dY, grads, ws, stream, aux_stream, int(bool(skip_into_dx))),
+                    "dgsct_adapter_backward")
 
     def saved_regions(self, desc):
         out = {}

@@ -239,9 +239,13 @@ class VisualAdapter(nn.Module):
             self._prep_cache = (key, ops.prepare(lib, self.spec, params, dtype, device))
         return self._prep_cache[1]
 
-    def forward(self, x, vis_token=None, caption=None, is_temporal=False):
+    def forward(self, x, vis_token=None, caption=None, is_temporal=False, residual=None, skip=False):
         """x [BT,C,N,1], vis_token [BT,Co,No,1] (views of token-major maps) ->
-        (output [BT,C,N,1], spatial_att_maps [BT,1,N][, temporal_att_maps [BT/T,T,1,1]])."""
+        (output [BT,C,N,1], spatial_att_maps [BT,1,N][, temporal_att_maps [BT/T,T,1,1]]).
+
+        Extensions of the reference signature (the callers' `f = f + adapter(...)[0]` at
+        net_trans.py:894-906): ``residual`` ([BT,C,N,1] view like x) -> output = residual + adapter(x, vis_token);
+        ``skip=True`` -> output = x + adapter(x, vis_token) with the skip's share of d/dx fused into backward."""
         if caption is not None:
             raise NotImplementedError("caption prompts (AVVP mgn.py:306-308) are never passed by any reference launcher")
         if not x.is_cuda and self._lib is None:      # (tests inject the host-emulated library to check this plumbing)
@@ -258,7 +262,10 @@ class VisualAdapter(nn.Module):
         prep = self._prepared(lib, params, cd, X.device)
         training = self.training
         flat = self.flat_param if "_flat_views" in self.__dict__ else None
-        out, amap, tmap = ops.adapter_apply(lib, self.spec, training, prep, X, Y, params, flat)
+        res = None
+        if residual is not None:
+            res = residual.squeeze(-1).permute(0, 2, 1).to(cd).contiguous()
+        out, amap, tmap = ops.adapter_apply(lib, self.spec, training, prep, X, Y, params, flat, residual=res, skip=skip)
         if training and self.use_bn:
             self.bn1.num_batches_tracked += 1
             self.bn2.num_batches_tracked += 1

@@ -51,15 +51,33 @@ int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, 
   return p.forward(params, prep, X, Y, out, map, tmap, saved, ws, stream);
 }
 
+int dgsct_adapter_forward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
+                             const void* Y, const void* residual, void* out, float* map, float* tmap, void* saved, void* ws,
+                             void* stream) {
+  clear_error();
+  if (!desc || !params || !prep || !X || !Y || !out || !map || !saved || !ws) {
+    set_error("dgsct_adapter_forward_ex: NULL argument");
+    return 2;
+  }
+  if (residual && out == residual) {        // rows are read and written by the same lanes, but keep the contract simple
+    set_error("dgsct_adapter_forward_ex: out must not alias residual");
+    return 2;
+  }
+  Plan p(*desc);
+  if (!p.ok) return 2;
+  return p.forward(params, prep, X, Y, out, map, tmap, saved, ws, stream, residual);
+}
+
 int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
                            const void* Y, const void* saved, const void* dOut, const float* dMap, const float* dTmap,
                            void* dX, void* dY, float* grads, void* ws, void* stream) {
-  return dgsct_adapter_backward_ex(desc, params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, nullptr);
+  return dgsct_adapter_backward_ex(desc, params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, nullptr, 0);
 }
 
 int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
                               const void* Y, const void* saved, const void* dOut, const float* dMap, const float* dTmap,
-                              void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream) {
+                              void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream,
+                              int skip_into_dx) {
   clear_error();
   if (!desc || !params || !prep || !X || !Y || !saved || !dOut || !dX || !dY || !grads || !ws) {
     set_error("dgsct_adapter_backward: NULL argument");
@@ -67,7 +85,7 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
   }
   Plan p(*desc);
   if (!p.ok) return 2;
-  return p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream);
+  return p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream, skip_into_dx != 0);
 }
 
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes) {

@@ -6,6 +6,24 @@
 
 namespace dgsct {
 
+// Resident-workgroup capacity of the device for one kernel instantiation (256-thread workgroups): occupancy x CUs.
+// Reduction kernels size their grid to ONE full round of resident workgroups: 800 workgroups on 768 slots take two
+// rounds (the second one 4 % full), and every extra workgroup costs an LDS combine + one global atomic per channel.
+inline int wg_capacity(const void* fn, size_t shmem) {
+  struct Key { const void* f; size_t s; };
+  static thread_local Key keys[64];
+  static thread_local int vals[64];
+  static thread_local int n = 0;
+  for (int i = 0; i < n; ++i)
+    if (keys[i].f == fn && keys[i].s == shmem) return vals[i];
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, shmem) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int cap = per_cu * cus;
+  if (n < 64) { keys[n] = Key{fn, shmem}; vals[n] = cap; ++n; }
+  return cap;
+}
+
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 // round-to-nearest-even, NaN preserved (same rounding as torch.Tensor.to(torch.bfloat16))
 __device__ __forceinline__ unsigned short f2bf(float f) {

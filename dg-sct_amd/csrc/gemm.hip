@@ -43,6 +43,7 @@ struct GemmK {
   const float* r1_m; const float* r1_n;
   int act;
   const char* R; int rdt; long ldr, rbs; float beta;
+  const char* R2;
   const char* mask; long ldmask, maskbs;
   int atomic;
   int wide;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmK p) {
   const float alpha = p.alpha * (p.alpha_ptr ? *p.alpha_ptr : 1.f);
   char* Db = p.D + (long)b * p.dbs * (p.ddt == DT_F32 ? 4 : 2);
   const char* Rb = p.R ? p.R + (long)b * p.rbs * (p.rdt == DT_F32 ? 4 : 2) : nullptr;
+  const char* R2b = p.R2 ? p.R2 + (long)b * p.rbs * (p.rdt == DT_F32 ? 4 : 2) : nullptr;
   const char* Mb = p.mask ? p.mask + (long)b * p.maskbs * ES : nullptr;
   const float* bias_n = p.bias_n ? p.bias_n + (long)b * p.bias_n_bs : nullptr;
   if (p.wide) {
@@ -353,6 +355,12 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmK p) {
             else ldv<DT_BF16, 8>(Rb, orr, rv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += p.beta * rv[e];
+            if (R2b) {
+              if (p.rdt == DT_F32) ldv<DT_F32, 4>(R2b, orr, *reinterpret_cast<float(*)[4]>(rv)), ldv<DT_F32, 4>(R2b, orr + 4, *reinterpret_cast<float(*)[4]>(rv + 4));
+              else ldv<DT_BF16, 8>(R2b, orr, rv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
           }
           if (p.ddt == DT_F32) { stv<DT_F32, 4>(Db, od, *reinterpret_cast<const float(*)[4]>(v)); stv<DT_F32, 4>(Db, od + 4, *reinterpret_cast<const float(*)[4]>(v + 4)); }
           else stv<DT_BF16, 8>(Db, od, v);
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmK p) {
           for (int e = 0; e < 8 && n + e < p.N; ++e) {
             float x = v[e];
             if (Rb) x += p.beta * lde_rt(Rb, p.rdt, (long)m * p.ldr + n + e);
+            if (R2b) x += lde_rt(R2b, p.rdt, (long)m * p.ldr + n + e);
             ste_rt(Db, p.ddt, od + e, x);
           }
         }
@@ -397,6 +406,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmK p) {
           const long o = (long)m * p.ldr + n;
           v += p.beta * (p.rdt == DT_F32 ? reinterpret_cast<const float*>(Rb)[o]
                                          : bf2f(reinterpret_cast<const unsigned short*>(Rb)[o]));
+          if (R2b) v += lde_rt(R2b, p.rdt, o);
         }
         const long o = (long)m * p.ldd + n;
         if (p.atomic) unsafeAtomicAdd(reinterpret_cast<float*>(Db) + o, v);
@@ -484,12 +494,13 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   k.bias_m = g.bias_m; k.bias_n = g.bias_n; k.bias_n_bs = g.bias_n_bs; k.m_mod = g.m_mod;
   k.r1_m = g.r1_m; k.r1_n = g.r1_n; k.act = g.act;
   k.R = (const char*)g.R; k.rdt = g.rdt; k.ldr = g.ldr; k.rbs = g.rbs; k.beta = g.beta;
+  k.R2 = g.R ? (const char*)g.R2 : nullptr;
   k.mask = (const char*)g.mask; k.ldmask = g.ldmask; k.maskbs = g.maskbs;
   k.atomic = g.atomic;
   {
     const int dv = g.ddt == DT_F32 ? 4 : 8, rv = g.rdt == DT_F32 ? 4 : 8;
     bool w = !g.atomic && !g.mask && aligned16(g.D) && g.ldd % dv == 0 && g.dbs % dv == 0 && g.N >= 8;
-    if (g.R) w = w && aligned16(g.R) && g.ldr % rv == 0 && g.rbs % rv == 0;
+    if (g.R) w = w && aligned16(g.R) && g.ldr % rv == 0 && g.rbs % rv == 0 && (!g.R2 || aligned16(g.R2));
     k.wide = w;
   }
   k.kflat = g.K * g.KB;

@@ -278,7 +278,7 @@ int Plan::prepare(float* const* params, void* prep, void* stream) const {
 
 // ------------------------------------------------------------------------------------------------
 int Plan::forward(float* const* params, const void* prep, const void* X, const void* Y, void* out, float* map,
-                  float* tmap, void* saved, void* ws, void* stream) const {
+                  float* tmap, void* saved, void* ws, void* stream, const void* residual) const {
   Bound b(*this, params, prep, saved, ws, stream);
   const Ctx& ctx = b.ctx;
   const float invN = 1.f / (float)N;
@@ -419,14 +419,14 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   tail_fwd(ctx, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr,
            d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
            d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, d.eps, R, C, out, b.S<float>(s.mu_p),
-           b.S<float>(s.rstd_p));
+           b.S<float>(s.rstd_p), residual);        // f2: out = residual + adapter(X, Y)
   return has_error() ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 int Plan::backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved_c,
                    const void* dOut, const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws,
-                   void* stream, void* aux_stream) const {
+                   void* stream, void* aux_stream, bool skip_into_dx) const {
   Bound b(*this, params, prep, const_cast<void*>(saved_c), ws, stream);
   b.ctx.aux = aux_stream;
   const Ctx& ctx = b.ctx;
@@ -608,6 +608,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g2.A = km(b.Wk(wb.dS2), tkp, (long)N * tkp);
     g2.B = mn(b.S(s.tok), C, (long)tk * C);
     resid(g2, dX1, E, C, (long)N * C);
+    if (skip_into_dx) g2.R2 = dOut;                              // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
     outE(g2, dX, E, C, (long)N * C);
     gemm(ctx, g2);
     Gemm g3 = mk(tk, C, N, B);                                   // dtok = gate_av * P2^T . dX1

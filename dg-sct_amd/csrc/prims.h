@@ -60,6 +60,7 @@ struct Gemm {
   const float* r1_m = nullptr; const float* r1_n = nullptr;
   int act = ACT_NONE;
   const void* R = nullptr; int rdt = DT_F32; long ldr = 0, rbs = 0; float beta = 1.f;
+  const void* R2 = nullptr;                                  // second residual, same dtype / ld / batch stride as R, weight 1
   const void* mask = nullptr; long ldmask = 0, maskbs = 0;   // dtype E
 };
 
@@ -126,7 +127,8 @@ void bn_bwd_apply(const Ctx&, const void* dy, const void* x, void* dx, long rows
 // O = Op*sc2 + sh2 (sc2 null -> Op).  gate_first: G = gate*O, out = lnw ? LN(G) : G.
 // else: L = lnw ? LN(O) : O, out = gate ? gate*L : L.  mu/rstd [B*N] written when lnw.
 void tail_fwd(const Ctx&, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
-              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd);
+              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd,
+              const void* residual = nullptr);     // out += residual (E [rows][C]) when given
 // backward of tail_fwd: writes dO (E); accumulates dlnw, dlnb [C], *dgate, and (if bnsums) bnsums[0][c] += sum dO,
 // bnsums[1][c] += sum dO * (Op - mean2)*rstd2.
 void tail_bwd(const Ctx&, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,

@@ -9,6 +9,7 @@
 //  * "column-strip" kernels (per-channel affine / reductions over tokens): a thread owns VE consecutive
 //    channels and walks rows; loads are 16 B per lane and coalesced along the channel axis.
 // All of them are HBM-bound; they read and write each big tensor exactly once.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "prims.h"
 #include "device_util.h"
@@ -68,15 +69,22 @@ void zero(const Ctx& ctx, void* p, size_t bytes) {
 // row-kernel geometry
 // ================================================================================================
 struct RowGeom { int gs, nv, rpp, rpc, chunks; };
-static RowGeom row_geom(int C, int VE, int N, int B, long target_wgs = 2048) {
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+// min_iters: a workgroup keeps per-channel constants in registers and (reduction kernels) flushes per-channel sums with
+// one LDS pass + one atomic per channel; it must stream enough rows to amortise that (late stages: 36-144 rows per frame).
+// floor_to_cap: target_wgs is the resident capacity (wg_capacity) -> never exceed one round
+static RowGeom row_geom(int C, int VE, int N, int B, long target_wgs = 2048, int min_iters = 1, bool floor_to_cap = false) {
   RowGeom g;
   int nvec = C / VE;
   g.gs = 1;
   while (g.gs < nvec && g.gs < 64) g.gs <<= 1;
   g.nv = (nvec + g.gs - 1) / g.gs;
   g.rpp = 256 / g.gs;
-  long want = cdiv(target_wgs, B);                // workgroups; reductions (bwd kernels) use fewer, fatter ones
-  long maxc = cdiv(N, g.rpp);
+  long want = floor_to_cap ? target_wgs / B : cdiv(target_wgs, B);
+  long maxc = cdiv(N, (long)g.rpp * min_iters);
   long chunks = want < 1 ? 1 : (want > maxc ? maxc : want);
   g.rpc = (int)(cdiv(cdiv(N, chunks), g.rpp) * g.rpp);
   g.chunks = (int)cdiv(N, g.rpc);
@@ -104,6 +112,21 @@ static RowGeom row_geom(int C, int VE, int N, int B, long target_wgs = 2048) {
     }                                                                                                       \
   } while (0)
 #define ROW_DISPATCH(ctx, C, NV, KERNEL, GRID, ...) ROW_DISPATCH_SH(ctx, C, NV, KERNEL, GRID, 0, __VA_ARGS__)
+// resident capacity of the instantiation ROW_DISPATCH_SH would launch
+#define ROW_FN_(KERNEL, DT_, VE_, NV_) reinterpret_cast<const void*>(&KERNEL<DT_, VE_, NV_>)
+#define ROW_CAPACITY(OUT, ctx, C, NV, KERNEL, SHMEM)                                                        \
+  do {                                                                                                      \
+    const void* fn_;                                                                                        \
+    if ((ctx).mode == DT_BF16) {                                                                            \
+      if ((C) % 8 == 0) fn_ = (NV) <= 1 ? ROW_FN_(KERNEL, DT_BF16, 8, 1) : ((NV) <= 2 ? ROW_FN_(KERNEL, DT_BF16, 8, 2) \
+                                                                                     : ROW_FN_(KERNEL, DT_BF16, 8, 3)); \
+      else fn_ = ROW_FN_(KERNEL, DT_BF16, 4, 6);                                                            \
+    } else {                                                                                                \
+      fn_ = (NV) <= 1 ? ROW_FN_(KERNEL, DT_F32, 4, 1) : ((NV) <= 2 ? ROW_FN_(KERNEL, DT_F32, 4, 2)          \
+                      : ((NV) <= 3 ? ROW_FN_(KERNEL, DT_F32, 4, 3) : ROW_FN_(KERNEL, DT_F32, 4, 6)));       \
+    }                                                                                                       \
+    OUT = wg_capacity(fn_, SHMEM);                                                                          \
+  } while (0)
 static inline int row_ve(const Ctx& ctx, int C) { return ctx.mode == DT_BF16 ? (C % 8 == 0 ? 8 : 4) : 4; }
 
 // flush per-lane channel accumulators: LDS combine across the row-groups of the workgroup, then one
@@ -305,8 +328,15 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
 void modln_bwd(const Ctx& ctx, const void* dX3, const void* X1, const float* ch, const float* sg, const float* tg,
                float alpha, float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N,
                int C, void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg) {
-  RowGeom g = row_geom(C, row_ve(ctx, C), N, B, 1024);
+  static const int mi = env_int("DGSCT_ROW_MIN_ITERS", 8);
+  static const int use_cap = env_int("DGSCT_ROW_CAP", 1);
   const size_t sh = (size_t)3 * C * sizeof(float);
+  RowGeom g = row_geom(C, row_ve(ctx, C), N, B, 1024, mi);
+  if (use_cap) {
+    int cap = 1024;
+    ROW_CAPACITY(cap, ctx, C, g.nv, modln_bwd_k, sh);
+    g = row_geom(C, row_ve(ctx, C), N, B, cap, mi, true);
+  }
   ROW_DISPATCH_SH(ctx, C, g.nv, modln_bwd_k, dim3(g.chunks, B), sh, dX3, X1, ch, sg, tg, alpha, beta, gamma, lnw, mu, rstd, N, C,
                   g.gs, g.nv, g.rpc, dX1, dlnw, dlnb, dch, dsg, tg ? dtg : nullptr);
 }
@@ -318,7 +348,7 @@ template <int DT, int VE, int MAXNV>
 __global__ __launch_bounds__(256) void tail_fwd_k(const void* Op, const float* sc2, const float* sh2, const float* lnw,
                                                   const float* lnb, const float* gate, int gate_first, float eps,
                                                   long rows, int C, int gs, int nv, int rpc, void* out, float* mu,
-                                                  float* rstd) {
+                                                  float* rstd, const void* res) {
   const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
   const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
   const float gv = gate ? *gate : 1.f;
@@ -377,6 +407,12 @@ __global__ __launch_bounds__(256) void tail_fwd_k(const void* Op, const float* s
 #pragma unroll
           for (int e = 0; e < VE; ++e) x[v][e] *= gv;
         }
+        if (res) {
+          float rr[VE];
+          ldv<DT, VE>(res, row * C + col, rr);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) x[v][e] += rr[e];
+        }
         stv<DT, VE>(out, row * C + col, x[v]);
       }
     }
@@ -384,10 +420,11 @@ __global__ __launch_bounds__(256) void tail_fwd_k(const void* Op, const float* s
 }
 
 void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
-              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd) {
+              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd,
+              const void* residual) {
   RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1);
   ROW_DISPATCH(ctx, C, g.nv, tail_fwd_k, dim3(g.chunks), Op, sc2, sh2, lnw, lnb, gate, gate_first, eps, rows, C, g.gs, g.nv, g.rpc,
-               out, mu, rstd);
+               out, mu, rstd, residual);
 }
 
 template <int DT, int VE, int MAXNV>
@@ -514,8 +551,15 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
 void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
               const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums) {
-  RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1, 1024);
+  static const int mi = env_int("DGSCT_ROW_MIN_ITERS", 8);
+  static const int use_cap = env_int("DGSCT_ROW_CAP", 1);
   const size_t sh = (size_t)4 * C * sizeof(float);
+  RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1, 1024, mi);
+  if (use_cap) {
+    int cap = 1024;
+    ROW_CAPACITY(cap, ctx, C, g.nv, tail_bwd_k, sh);
+    g = row_geom(C, row_ve(ctx, C), (int)rows, 1, cap, mi, true);
+  }
   ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu,
                   rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums);
 }

@@ -8,6 +8,7 @@
 // flight -- these kernels are pure HBM streams and latency hiding is the whole game.  Reductions are
 // combined across the row-slots of the workgroup in LDS (ds_add_f32) and leave as one fp32 atomic per
 // channel per workgroup.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "prims.h"
 #include "device_util.h"
@@ -25,12 +26,12 @@ struct ColGeom { int nvr, tpr, rpp, rpc, chunks; };
 // target_wgs: ~4096 for pure streams; ~768 (3 per CU) for reductions, whose per-workgroup LDS combine + one global
 // atomic per channel must be amortised over many rows (3840 workgroups x 128 channels of atomics on 128 addresses
 // cost more than the 94 MB stream itself).
-static ColGeom col_geom(int C, int VE, long rows, int B, long target_wgs = 4096) {
+static ColGeom col_geom(int C, int VE, long rows, int B, long target_wgs = 4096, bool floor_to_cap = false) {
   ColGeom g;
   g.nvr = C / VE;
   g.tpr = imin(g.nvr, 256);
   g.rpp = 256 / g.tpr;
-  long want = cdiv(target_wgs, B);
+  long want = floor_to_cap ? target_wgs / B : cdiv(target_wgs, B);
   long maxc = cdiv(rows, (long)g.rpp * UNR);
   long chunks = want < 1 ? 1 : (want > maxc ? maxc : want);
   if (chunks < 1) chunks = 1;
@@ -42,6 +43,17 @@ static inline int col_ve(const Ctx& ctx, int C) {
   const int vmax = ctx.mode == DT_BF16 ? 8 : 4;
   return C % vmax == 0 ? vmax : 1;
 }
+// resident capacity (occupancy x CUs) of the instantiation COL_DISPATCH would launch; reductions use one full round
+#define COL_CAPACITY(OUT, ctx, VE_, KERNEL, SHMEM)                                                         \
+  do {                                                                                                      \
+    const void* fn_;                                                                                        \
+    if ((ctx).mode == DT_BF16) fn_ = (VE_) == 8 ? reinterpret_cast<const void*>(&KERNEL<DT_BF16, 8>)         \
+                                                : reinterpret_cast<const void*>(&KERNEL<DT_BF16, 1>);        \
+    else fn_ = (VE_) == 4 ? reinterpret_cast<const void*>(&KERNEL<DT_F32, 4>)                                \
+                          : reinterpret_cast<const void*>(&KERNEL<DT_F32, 1>);                               \
+    OUT = wg_capacity(fn_, SHMEM);                                                                          \
+    if (const char* e_ = getenv("DGSCT_COL_CAP")) { if (atoi(e_) > 0) OUT = atoi(e_); }                       \
+  } while (0)
 #define COL_DISPATCH(ctx, VE_, KERNEL, GRID, SHMEM, ...)                                                   \
   do {                                                                                                      \
     if ((ctx).mode == DT_BF16) {                                                                            \
@@ -128,7 +140,10 @@ void colsum_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int 
                     float scale, float* out, long out_bs) {
   int ve = col_ve(ctx, C);
   if (ld % ve != 0 || bs % ve != 0) ve = 1;
-  ColGeom g = col_geom(C, ve, N, B, 768);
+  int cap = 768;
+  COL_CAPACITY(cap, ctx, ve, colsum_k, (size_t)C * sizeof(float));
+  if (cap > 800) cap = 800;            // light kernel (5 resident/CU): beyond ~3 per CU the extra atomics cost more than they hide
+  ColGeom g = col_geom(C, ve, N, B, cap, true);
   COL_DISPATCH(ctx, ve, colsum_k, dim3(g.chunks, B), (size_t)C * sizeof(float), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr,
                g.rpp, g.rpc, out, out_bs);
 }
@@ -445,7 +460,9 @@ __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, 
 void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
                     const float* colw2, float scale, float* colsum_out) {
   const int ve = col_ve(ctx, C);
-  ColGeom g = col_geom(C, ve, N, B, colsum_out ? 1024 : 4096);
+  int cap = 4096;
+  if (colsum_out) COL_CAPACITY(cap, ctx, ve, relu_bwd_scale_k, (size_t)C * sizeof(float));
+  ColGeom g = col_geom(C, ve, N, B, cap, colsum_out != nullptr);
   COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), (size_t)C * sizeof(float), x, y, N, C, g.tpr, g.rpp, g.rpc, roww,
                colw, cdt, colw2, scale, colsum_out);
 }
@@ -494,7 +511,9 @@ __global__ __launch_bounds__(256) void xc_bwd_k(const void* dXc, const void* X1,
 }
 void xc_bwd(const Ctx& ctx, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch) {
   const int ve = col_ve(ctx, C);
-  ColGeom g = col_geom(C, ve, N, B, 768);
+  int cap = 768;
+  COL_CAPACITY(cap, ctx, ve, xc_bwd_k, (size_t)C * sizeof(float));
+  ColGeom g = col_geom(C, ve, N, B, cap, true);
   COL_DISPATCH(ctx, ve, xc_bwd_k, dim3(g.chunks, B), (size_t)C * sizeof(float), dXc, X1, dX1, N, C, ch, g.tpr, g.rpp, g.rpc, dch);
 }
 

@@ -145,14 +145,18 @@ def prepare(lib: Lib, spec: AdapterSpec, params: List[Optional[torch.Tensor]], d
     return prep
 
 
-def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: torch.Tensor, training: bool):
-    """X [BT,N,C], Y [BT,No,Co] contiguous, same dtype (fp32|bf16).  Returns (out, map, tmap, saved, desc)."""
+def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: torch.Tensor, training: bool,
+                residual: Optional[torch.Tensor] = None):
+    """X [BT,N,C], Y [BT,No,Co] contiguous, same dtype (fp32|bf16).  Returns (out, map, tmap, saved, desc).
+    residual [BT,N,C] (may be X itself): out = residual + adapter(X, Y), the add fused into the last kernel."""
     BT = X.shape[0]
     if X.shape != (BT, spec.N, spec.C) or Y.shape != (BT, spec.No, spec.Co):
         raise RuntimeError(f"dg-sct_amd: expected X [BT,{spec.N},{spec.C}] and Y [BT,{spec.No},{spec.Co}], got "
                            f"{tuple(X.shape)} and {tuple(Y.shape)}")
     if X.dtype != Y.dtype or X.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("dg-sct_amd: X and Y must both be float32 or both bfloat16")
+    if residual is not None and (residual.shape != X.shape or residual.dtype != X.dtype or not residual.is_contiguous()):
+        raise RuntimeError("dg-sct_amd: residual must be a contiguous tensor of X's shape and dtype")
     d = spec.desc(BT, X.dtype, training)
     sz = _sizes(lib, d)
     dev = X.device
@@ -163,11 +167,13 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
     stream = _stream_of(X)
     ws = _workspace(dev, stream, int(sz.ws_fwd_bytes))
     lib.forward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), out.data_ptr(), amap.data_ptr(),
-                tmap.data_ptr() if tmap is not None else None, saved.data_ptr(), ws.data_ptr(), stream)
+                tmap.data_ptr() if tmap is not None else None, saved.data_ptr(), ws.data_ptr(), stream,
+                residual.data_ptr() if residual is not None else None)
     return out, amap, tmap, saved, d
 
 
-def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y, saved, dOut, dMap, dTmap, flat_out=False):
+def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y, saved, dOut, dMap, dTmap, flat_out=False,
+                 skip_into_dx=False):
     sz = _sizes(lib, d)
     dev = X.device
     dX = torch.empty_like(X)
@@ -177,7 +183,8 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     ws = _workspace(dev, stream, int(sz.ws_bwd_bytes))
     lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
                  dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
-                 dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(lib, X, stream))
+                 dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(lib, X, stream),
+                 skip_into_dx)
     if flat_out:
         return dX, dY, grads
     lay = grad_layout(lib, d)
@@ -202,10 +209,11 @@ class _AdapterFn(torch.autograd.Function):
     """forward(X, Y, *params) -> (out, map[, tmap]); one library call each way."""
 
     @staticmethod
-    def forward(ctx, lib, spec, training, prep, X, Y, *params):
+    def forward(ctx, lib, spec, training, prep, skip, res, X, Y, *params):
         plist = list(params)
-        out, amap, tmap, saved, d = raw_forward(lib, spec, plist, prep, X, Y, training)
+        out, amap, tmap, saved, d = raw_forward(lib, spec, plist, prep, X, Y, training, X if skip else res)
         ctx.lib, ctx.spec, ctx.desc, ctx.prep = lib, spec, d, prep
+        ctx.skip, ctx.has_res = bool(skip), res is not None
         ctx.saved_buf = saved
         ctx.save_for_backward(X, Y, *[p for p in plist if p is not None])
         ctx.present = [p is not None for p in plist]
@@ -232,7 +240,8 @@ class _AdapterFn(torch.autograd.Function):
             dOut = dOut.to(X.dtype)
         dMap = dMap.contiguous().float() if dMap is not None else None
         dTm = dTmap.contiguous().float() if (spec.temporal and dTmap is not None and dTmap.numel()) else None
-        dX, dY, grads = raw_backward(ctx.lib, spec, ctx.desc, plist, ctx.prep, X, Y, ctx.saved_buf, dOut, dMap, dTm)
+        dX, dY, grads = raw_backward(ctx.lib, spec, ctx.desc, plist, ctx.prep, X, Y, ctx.saved_buf, dOut, dMap, dTm,
+                                     skip_into_dx=ctx.skip)
         ctx.saved_buf = None
         pg = []
         for i, g in enumerate(grads):
@@ -242,7 +251,7 @@ class _AdapterFn(torch.autograd.Function):
                 pg.append(None)
             else:
                 pg.append(g.view(ctx.shapes[i]))
-        return (None, None, None, None, dX, dY, *pg)
+        return (None, None, None, None, None, dOut if ctx.has_res else None, dX, dY, *pg)
 
 
 class _AdapterFlatFn(torch.autograd.Function):
@@ -252,9 +261,10 @@ class _AdapterFlatFn(torch.autograd.Function):
     tensors instead of ~1900, and data-parallel all-reduce runs on it in place."""
 
     @staticmethod
-    def forward(ctx, lib, spec, training, prep, plist, X, Y, flat):
-        out, amap, tmap, saved, d = raw_forward(lib, spec, plist, prep, X, Y, training)
+    def forward(ctx, lib, spec, training, prep, plist, skip, res, X, Y, flat):
+        out, amap, tmap, saved, d = raw_forward(lib, spec, plist, prep, X, Y, training, X if skip else res)
         ctx.lib, ctx.spec, ctx.desc, ctx.prep, ctx.plist = lib, spec, d, prep, plist
+        ctx.skip, ctx.has_res = bool(skip), res is not None
         ctx.saved_buf = saved
         ctx.save_for_backward(X, Y)
         ctx.set_materialize_grads(False)
@@ -277,15 +287,20 @@ class _AdapterFlatFn(torch.autograd.Function):
         dMap = dMap.contiguous().float() if dMap is not None else None
         dTm = dTmap.contiguous().float() if (spec.temporal and dTmap is not None and dTmap.numel()) else None
         dX, dY, gflat = raw_backward(ctx.lib, spec, ctx.desc, ctx.plist, ctx.prep, X, Y, ctx.saved_buf, dOut, dMap, dTm,
-                                     flat_out=True)
+                                     flat_out=True, skip_into_dx=ctx.skip)
         ctx.saved_buf = None
-        return None, None, None, None, None, dX, dY, gflat
+        return None, None, None, None, None, None, dOut if ctx.has_res else None, dX, dY, gflat
 
 
 def adapter_apply(lib: Lib, spec: AdapterSpec, training: bool, prep: torch.Tensor, X: torch.Tensor, Y: torch.Tensor,
-                  params: List[Optional[torch.Tensor]], flat: Optional[torch.Tensor] = None):
+                  params: List[Optional[torch.Tensor]], flat: Optional[torch.Tensor] = None,
+                  residual: Optional[torch.Tensor] = None, skip: bool = False):
+    """residual: out = residual + adapter(X, Y) (any tensor of X's shape; its gradient is dOut).
+    skip: out = X + adapter(X, Y) with the matching `dX += dOut` fused into backward."""
+    if skip and residual is not None:
+        raise RuntimeError("dg-sct_amd: pass either residual= or skip=True, not both")
     if flat is not None:
-        out, amap, tmap = _AdapterFlatFn.apply(lib, spec, training, prep, params, X, Y, flat)
+        out, amap, tmap = _AdapterFlatFn.apply(lib, spec, training, prep, params, skip, residual, X, Y, flat)
     else:
-        out, amap, tmap = _AdapterFn.apply(lib, spec, training, prep, X, Y, *params)
+        out, amap, tmap = _AdapterFn.apply(lib, spec, training, prep, skip, residual, X, Y, *params)
     return out, amap, (tmap if spec.temporal else None)

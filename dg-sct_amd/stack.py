@@ -43,9 +43,10 @@ class AdapterStack(nn.Module):
     """4 x L adapters (audio/visual x p1/p2) in the reference's ModuleLists, plus the layer loop."""
 
     def __init__(self, stages: Sequence[Dict[str, int]], opt: Optional[SimpleNamespace] = None, flavour: str = "ave",
-                 compute_dtype: Optional[torch.dtype] = None, lib=None, concurrent: bool = True):
+                 compute_dtype: Optional[torch.dtype] = None, lib=None, concurrent: bool = True, fuse_residual: bool = True):
         super().__init__()
         self.concurrent = concurrent
+        self.fuse_residual = fuse_residual        # `f = f + adapter(...)` inside the adapter's last kernel (8f row f2)
         self._side_streams = {}
         self.opt = opt or default_opt()
         o = self.opt
@@ -106,33 +107,44 @@ class AdapterStack(nn.Module):
                 lib = self.audio_adapter_blocks_p1[0]._lib or _lib.default_lib()
                 side = self._side_streams[dev.index] = ops.priority_stream(lib, dev, ops.COMPUTE_PRIORITY_CLASS)
 
-        def pair(audio_mod, vis_mod, f_a, f_v):
+        fuse = self.fuse_residual
+
+        def call(mod, f_own, f_other, f_res):
+            """adapter on the pre-block maps; with fuse: returns f_res + adapter(...) token-major (f_res is f_own when no
+            frozen block sits in between -> the fully fused skip), else the reference's [BT,C,N,1] result."""
+            if not fuse:
+                return mod(self._view(f_own), self._view(f_other))
+            if f_res is f_own:
+                r = mod(self._view(f_own), self._view(f_other), skip=True)
+            else:
+                r = mod(self._view(f_own), self._view(f_other), residual=self._view(f_res))
+            return (r[0].squeeze(-1).permute(0, 2, 1),) + tuple(r[1:])
+
+        def pair(audio_mod, vis_mod, f_a, f_v, r_a, r_v):
             if side is None:
-                a = audio_mod(self._view(f_a), self._view(f_v))
-                v = vis_mod(self._view(f_v), self._view(f_a))
-                return a, v
+                return call(audio_mod, f_a, f_v, r_a), call(vis_mod, f_v, f_a, r_v)
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                a = audio_mod(self._view(f_a), self._view(f_v))
-            v = vis_mod(self._view(f_v), self._view(f_a))
+                a = call(audio_mod, f_a, f_v, r_a)
+            v = call(vis_mod, f_v, f_a, r_v)
             main.wait_stream(side)
             return a, v
 
+        def step(p_audio, p_vis, f_a, f_v, idx, half, with_aud_block):
+            # frozen blocks first (they only read the pre-block maps), so their output can be the fused residual
+            r_v = f_v if vis_block is None else f_v + vis_block(idx, half, f_v)
+            r_a = f_a if (aud_block is None or not with_aud_block) else aud_block(idx, f_a)
+            a, v = pair(p_audio, p_vis, f_a, f_v, r_a, r_v)
+            if fuse:
+                return a[0], v[0], a[1], v[1]
+            return (r_a + a[0].squeeze(-1).permute(0, 2, 1), r_v + v[0].squeeze(-1).permute(0, 2, 1), a[1], v[1])
+
         for s, (f_v, f_a) in zip(self.stages, feats):
             for _ in range(s["layers"]):
-                (a_res, _), (v_res, _) = [r[:2] for r in pair(self.audio_adapter_blocks_p1[idx], self.vis_adapter_blocks_p1[idx], f_a, f_v)]
-                if vis_block is not None:
-                    f_v = f_v + vis_block(idx, 0, f_v)
-                f_v = f_v + v_res.squeeze(-1).permute(0, 2, 1)
-                if aud_block is not None:
-                    f_a = aud_block(idx, f_a)
-                f_a = f_a + a_res.squeeze(-1).permute(0, 2, 1)
-                (a_res, a_map), (v_res, v_map) = [r[:2] for r in pair(self.audio_adapter_blocks_p2[idx], self.vis_adapter_blocks_p2[idx], f_a, f_v)]
-                if vis_block is not None:
-                    f_v = f_v + vis_block(idx, 1, f_v)
-                f_v = f_v + v_res.squeeze(-1).permute(0, 2, 1)
-                f_a = f_a + a_res.squeeze(-1).permute(0, 2, 1)
+                f_a, f_v, _, _ = step(self.audio_adapter_blocks_p1[idx], self.vis_adapter_blocks_p1[idx], f_a, f_v, idx, 0, True)
+                f_a, f_v, a_map, v_map = step(self.audio_adapter_blocks_p2[idx], self.vis_adapter_blocks_p2[idx], f_a, f_v, idx, 1,
+                                              False)
                 maps = (v_map, a_map)
                 idx += 1
             outs.append((f_v, f_a))

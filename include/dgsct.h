@@ -123,6 +123,14 @@ int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, 
                           const void* X, const void* Y, void* out, float* map, float* tmap,
                           void* saved, void* ws, void* stream);
 
+/* Same, with the caller's residual add fused into the last kernel (reference call sites
+ * net_trans.py:894-898,903-906: `f = f + adapter(...)[0].squeeze(-1).permute(0,2,1)`):
+ *   out = residual + adapter(X, Y)        residual [BT][N][C] (dtype), may alias X (identity / pre-block skip).
+ * residual == NULL is dgsct_adapter_forward. */
+int dgsct_adapter_forward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep,
+                             const void* X, const void* Y, const void* residual, void* out, float* map, float* tmap,
+                             void* saved, void* ws, void* stream);
+
 /* dOut [BT][N][C] (dtype); dMap [BT][N] fp32 or NULL; dTmap [BT] fp32 or NULL.
  * Writes dX [BT][N][C], dY [BT][No][Co] (dtype) and the flat fp32 gradient buffer `grads`
  * (grad_floats; overwritten, not accumulated). */
@@ -133,11 +141,14 @@ int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params,
 
 /* Same, with an optional second stream: weight / bias gradients (which feed nothing downstream) are issued on
  * `aux_stream` and overlap the data-gradient chain; the call forks from and joins back into `stream`, so the caller sees
- * ordinary single-stream semantics.  aux_stream == NULL is dgsct_adapter_backward. */
+ * ordinary single-stream semantics.  aux_stream == NULL is dgsct_adapter_backward.
+ * skip_into_dx != 0: the forward was `out = X + adapter(X, Y)` (residual aliased X), so dX also receives dOut
+ * (dX = dOut + d adapter / dX) -- saves the caller's gradient-accumulation pass over [BT][N][C]. */
 int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep,
                               const void* X, const void* Y, const void* saved,
                               const void* dOut, const float* dMap, const float* dTmap,
-                              void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream);
+                              void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream,
+                              int skip_into_dx);
 
 /* ---- introspection / test hooks (used by tests/ only) ------------------------------------------ */
 /* i-th named region of the `saved` buffer; returns 0 and fills name/offset/bytes, or 1 past the end. */

@@ -57,6 +57,7 @@ void gemm(const Ctx& ctx, const Gemm& g) {
         else if (g.act == ACT_SIGMOID) v = sigm(v);
         if (g.mask && !(ld(g.mask, E, (long)b * g.maskbs + (long)m * g.ldmask + n) > 0.f)) v = 0.f;
         if (g.R) v += g.beta * ld(g.R, g.rdt, (long)b * g.rbs + (long)m * g.ldr + n);
+        if (g.R2) v += ld(g.R2, g.rdt, (long)b * g.rbs + (long)m * g.ldr + n);
         const long o = (long)b * g.dbs + (long)m * g.ldd + n;
         if (g.atomic) ((float*)g.D)[o] += v;
         else st(g.D, g.ddt, o, v);
@@ -312,7 +313,8 @@ void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long 
 }
 
 void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
-              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd) {
+              const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd,
+              const void* residual) {
   std::vector<float> x(C);
   const float gv = gate ? *gate : 1.f;
   for (long r = 0; r < rows; ++r) {
@@ -323,7 +325,8 @@ void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2
       x[c] = v;
     }
     if (lnw) ln_row(x, lnw, lnb, eps, mu + r, rstd + r);
-    for (int c = 0; c < C; ++c) st(out, ctx.mode, r * C + c, gate_first ? x[c] : x[c] * gv);
+    for (int c = 0; c < C; ++c)
+      st(out, ctx.mode, r * C + c, (gate_first ? x[c] : x[c] * gv) + (residual ? ld(residual, ctx.mode, r * C + c) : 0.f));
   }
 }
 

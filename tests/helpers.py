@@ -74,8 +74,9 @@ def nrm_err(a, b):
     return ((a - b).abs().max() / max(1e-12, b.abs().max().item())).item()
 
 
-def run_library(lib, fx, device, dtype=torch.float32, training=True):
-    """Run prepare + forward + backward of `lib` on a golden fixture.  Returns a dict of results."""
+def run_library(lib, fx, device, dtype=torch.float32, training=True, residual=None, skip=False):
+    """Run prepare + forward + backward of `lib` on a golden fixture.  Returns a dict of results.
+    residual ("x" | tensor) / skip exercise the fused `f + adapter(...)` entry points (dgsct_adapter_*_ex)."""
     cfg = fx["cfg"]
     spec = spec_of(cfg)
     state = {k: v.clone() for k, v in fx["state0"].items()}
@@ -85,12 +86,13 @@ def run_library(lib, fx, device, dtype=torch.float32, training=True):
     X = fx["X"].to(device=device, dtype=dtype).contiguous()
     Y = fx["Y"].to(device=device, dtype=dtype).contiguous()
     prep = ops.prepare(lib, spec, params, dtype, device)
-    out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, training)
+    rz = X if skip else (residual.to(device=device, dtype=dtype).contiguous() if residual is not None else None)
+    out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, training, rz)
     res = dict(out=out, map=amap, tmap=tmap, params=params, spec=spec, saved=saved, desc=d)
     if training:
         dOut = fx["dOut"].to(device=device, dtype=dtype).contiguous()
         dMap = fx["dMap"].to(device)
         dTmap = fx["dTmap"].to(device) if fx["dTmap"] is not None else None
-        dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, dTmap)
+        dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, dTmap, skip_into_dx=skip)
         res.update(dX=dX, dY=dY, grads={PARAM_NAMES[i]: g for i, g in enumerate(grads) if g is not None})
     return res

@@ -172,6 +172,23 @@ def test_full_size_frames_are_independent(shape):
                                                      False)[0].float().cpu()) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL_F32), (torch.bfloat16, 2e-2)])
+def test_fused_residual_and_skip(dtype, tol):
+    """8f row f2 on the GPU: dgsct_adapter_forward_ex / backward_ex(skip_into_dx) vs the plain entry points."""
+    fx = load_golden("ave_orderB")
+    lib = default_lib()
+    base = run_library(lib, fx, DEV, dtype, training=True)
+    Rz = torch.randn(fx["X"].shape, generator=torch.Generator().manual_seed(5))
+    r = run_library(lib, fx, DEV, dtype, training=True, residual=Rz)
+    assert nrm_err(r["out"], base["out"].float().cpu() + Rz.to(dtype).float()) < tol
+    assert nrm_err(r["dX"], base["dX"].float().cpu()) < 1e-6 + (0 if dtype == torch.float32 else 1e-2)
+    r = run_library(lib, fx, DEV, dtype, training=True, skip=True)
+    X = fx["X"].to(dtype).float(); dO = fx["dOut"].to(dtype).float()
+    assert nrm_err(r["out"], base["out"].float().cpu() + X) < tol
+    assert nrm_err(r["dX"], base["dX"].float().cpu() + dO) < tol
+    assert nrm_err(r["dY"], base["dY"].float().cpu()) < 1e-6 + (0 if dtype == torch.float32 else 1e-2)
+
+
 def test_module_dropin_matches_oracle():
     """nn.Module boundary: reference call convention ([BT,C,N,1] views), state_dict names, autograd."""
     from types import SimpleNamespace

@@ -112,6 +112,37 @@ def test_stack_schedule_matches_reference_loop():
     assert all(int(m.bn1.num_batches_tracked) == 1 for m in st.vis_adapter_blocks_p1)
 
 
+@pytest.mark.parametrize("mode", ["unfused", "frozen_blocks"])
+def test_stack_residual_variants_agree(mode):
+    """The fused residual (default, pinned against the reference fixture above) must agree with (a) the un-fused
+    `f + adapter(...)` schedule and (b) stay consistent when frozen blocks sit between adapter and add (the
+    `residual=` entry point: the block output, not x, is the addend)."""
+    emu = Lib(build_emu())
+    fx = load_golden("stack_2stage")
+
+    def run(**kw):
+        blocks = kw.pop("blocks", False)
+        st = _stack_from_fixture(fx, emu, **kw).train()
+        feats = [(a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for a, b in fx["feats"]]
+        vb = (lambda idx, half, f: 0.25 * torch.tanh(f)) if blocks else None
+        ab = (lambda idx, f: f + 0.125 * torch.sin(f)) if blocks else None
+        outs, maps = st(feats, vis_block=vb, aud_block=ab)
+        torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
+                                [g for pr in fx["cots"] for g in pr] + list(fx["mcots"]))
+        return outs, feats, {k: p.grad for k, p in st.named_parameters() if p.grad is not None}
+
+    blocks = mode == "frozen_blocks"
+    o1, f1, g1 = run(fuse_residual=True, blocks=blocks)
+    o2, f2, g2 = run(fuse_residual=False, blocks=blocks)
+    for (a, b), (c, d) in zip(o1, o2):
+        assert rel_err(a, c) < 1e-5 and rel_err(b, d) < 1e-5
+    for (a, b), (c, d) in zip(f1, f2):
+        assert rel_err(a.grad, c.grad) < 1e-4 and rel_err(b.grad, d.grad) < 1e-4
+    assert set(g1) == set(g2)
+    for k in g1:
+        assert rel_err(g1[k], g2[k]) < 1e-4, k
+
+
 def test_flattened_parameters_keep_the_checkpoint_format_and_the_gradients():
     """flatten_parameters(): one flat fp32 Parameter per adapter (gradient = the library's flat buffer, adopted by
     autograd without a copy); state_dict keys/values stay the reference's; gradients equal the reference's."""

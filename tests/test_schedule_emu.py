@@ -63,3 +63,22 @@ def test_schedule_bf16_storage(emu, name):
     assert nrm_err(r["out"], fx["out"]) < tol
     assert nrm_err(r["dX"], fx["dX"]) < tol
     assert nrm_err(r["dY"], fx["dY"]) < tol
+
+
+@pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "avs_s4"])
+def test_fused_residual_and_skip(emu, name):
+    """`f = f + adapter(...)[0]` (net_trans.py:894-906) fused into the adapter's last kernel.
+    residual=R: out = R + ref_out, gradients unchanged.  skip: out = X + ref_out and dX = ref_dX + dOut."""
+    fx = load_golden(name)
+    tol = 1e-4
+    Rz = torch.randn(fx["X"].shape, generator=torch.Generator().manual_seed(5))
+    r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True, residual=Rz)
+    assert rel_err(r["out"], fx["out"] + Rz) < tol
+    assert rel_err(r["dX"], fx["dX"]) < tol and rel_err(r["dY"], fx["dY"]) < tol
+    r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True, skip=True)
+    assert rel_err(r["out"], fx["out"] + fx["X"]) < tol
+    assert rel_err(r["map"], fx["map"]) < tol
+    assert rel_err(r["dX"], fx["dX"] + fx["dOut"]) < tol
+    assert rel_err(r["dY"], fx["dY"]) < tol
+    for k, g in fx["grads"].items():
+        assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
