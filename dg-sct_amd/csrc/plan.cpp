@@ -393,24 +393,37 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   float* bn1 = b.S<float>(s.bn1);
   float* bn2 = b.S<float>(s.bn2);
   {
-    Gemm g1 = mk((int)R, ds / g, C / g, g);                      // Zp = X3 (x)_g Wd
-    g1.A = km(b.S(s.X3), C, C / g);
-    g1.B = km(b.W(DGSCT_P_WD), C / g, (long)(ds / g) * (C / g));
-    outE(g1, b.S(s.Zp), E, ds, ds / g);
-    gemm(ctx, g1);
+    // dg = ds/g <= 8 (stages 0-1 of every backbone): the grouped projections are HBM streams with 6..8-wide GEMM
+    // dimensions -> vector-unit row kernels (prims_proj.hip) instead of 80 %-padded MFMA tiles
+    const bool vproj = gproj_supported(ctx.mode, C, ds, g);
+    const long cgl = C / g, dgl = ds / g;
+    if (vproj) {
+      gproj_narrow(ctx, b.S(s.X3), R, C, ds, g, b.F(DGSCT_P_WD), dgl * cgl, cgl, 1, b.S(s.Zp));     // Zp = X3 (x)_g Wd
+    } else {
+      Gemm g1 = mk((int)R, ds / g, C / g, g);                    // Zp = X3 (x)_g Wd
+      g1.A = km(b.S(s.X3), C, C / g);
+      g1.B = km(b.W(DGSCT_P_WD), C / g, (long)(ds / g) * (C / g));
+      outE(g1, b.S(s.Zp), E, ds, ds / g);
+      gemm(ctx, g1);
+    }
     if (d.use_bn) {
       if (d.training) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
       bn_finalize(ctx, b.S<float>(s.bnacc1), R, ds, b.F(DGSCT_P_BN1_W), b.F(DGSCT_P_BN1_B), b.Fm(DGSCT_P_BN1_RM),
                   b.Fm(DGSCT_P_BN1_RV), d.bn_momentum, d.eps, d.training, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds);
     }
     affine_act(ctx, b.S(s.Zp), b.S(s.Z), R, ds, d.use_bn ? bn1 + 2 * ds : nullptr, d.use_bn ? bn1 + 3 * ds : nullptr, 1);
-    Gemm g2 = mk((int)R, C / g, ds / g, g);                      // Op = Z (x)_g Wu
-    g2.A = km(b.S(s.Z), ds, ds / g);
-    g2.B = km(b.W(DGSCT_P_WU), ds / g, (long)(C / g) * (ds / g));
-    outE(g2, b.S(s.Op), E, C, C / g);
-    gemm(ctx, g2);
+    const bool stats2 = d.use_bn && d.training;
+    if (vproj) {                                                 // Op = Z (x)_g Wu, BN2 sums in the same pass
+      gproj_wide(ctx, b.S(s.Z), R, C, ds, g, b.F(DGSCT_P_WU), cgl * dgl, 1, dgl, b.S(s.Op), stats2 ? b.S<float>(s.bnacc2) : nullptr);
+    } else {
+      Gemm g2 = mk((int)R, C / g, ds / g, g);                    // Op = Z (x)_g Wu
+      g2.A = km(b.S(s.Z), ds, ds / g);
+      g2.B = km(b.W(DGSCT_P_WU), ds / g, (long)(C / g) * (ds / g));
+      outE(g2, b.S(s.Op), E, C, C / g);
+      gemm(ctx, g2);
+    }
     if (d.use_bn) {
-      if (d.training) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
+      if (stats2 && !vproj) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
       bn_finalize(ctx, b.S<float>(s.bnacc2), R, C, b.F(DGSCT_P_BN2_W), b.F(DGSCT_P_BN2_B), b.Fm(DGSCT_P_BN2_RM),
                   b.Fm(DGSCT_P_BN2_RV), d.bn_momentum, d.eps, d.training, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C);
     }
@@ -443,6 +456,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   const float* bn2 = b.S<float>(s.bn2);
   const float* tg = d.temporal ? b.S<float>(s.tg) : nullptr;
   const int cg = C / g, dg = ds / g;
+  const bool vproj = gproj_supported(ctx.mode, C, ds, g);
 
   // B11 ---- ln_post / gate, BN2 sums
   void* dO = b.Wk(wb.dO);
@@ -462,11 +476,15 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     atomic_out(g1);
     side_begin();
     gemm(side, g1);
-    Gemm g2 = mk((int)R, dg, cg, g);                             // dZ = dOp (x)_g Wu
-    g2.A = km(dO, C, cg);
-    g2.B = mn(b.W(DGSCT_P_WU), dg, (long)cg * dg);
-    outE(g2, b.Wk(wb.dZ), E, ds, dg);
-    gemm(ctx, g2);
+    if (vproj) {                                                 // dZ = dOp (x)_g Wu
+      gproj_narrow(ctx, dO, R, C, ds, g, b.F(DGSCT_P_WU), (long)cg * dg, 1, dg, b.Wk(wb.dZ));
+    } else {
+      Gemm g2 = mk((int)R, dg, cg, g);                           // dZ = dOp (x)_g Wu
+      g2.A = km(dO, C, cg);
+      g2.B = mn(b.W(DGSCT_P_WU), dg, (long)cg * dg);
+      outE(g2, b.Wk(wb.dZ), E, ds, dg);
+      gemm(ctx, g2);
+    }
   }
   // B9 ---- relu, BN1 backward, down projection
   void* dZ = b.Wk(wb.dZ);
@@ -484,11 +502,15 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     atomic_out(g1);
     side_begin();
     gemm(side, g1);
-    Gemm g2 = mk((int)R, cg, dg, g);                             // dX3 = dZp (x)_g Wd
-    g2.A = km(dZ, ds, dg);
-    g2.B = mn(b.W(DGSCT_P_WD), cg, (long)dg * cg);
-    outE(g2, b.Wk(wb.dX3), E, C, cg);
-    gemm(ctx, g2);
+    if (vproj) {                                                 // dX3 = dZp (x)_g Wd
+      gproj_wide(ctx, dZ, R, C, ds, g, b.F(DGSCT_P_WD), (long)dg * cg, cg, 1, b.Wk(wb.dX3), nullptr);
+    } else {
+      Gemm g2 = mk((int)R, cg, dg, g);                           // dX3 = dZp (x)_g Wd
+      g2.A = km(dZ, ds, dg);
+      g2.B = mn(b.W(DGSCT_P_WD), cg, (long)dg * cg);
+      outE(g2, b.Wk(wb.dX3), E, C, cg);
+      gemm(ctx, g2);
+    }
   }
   // B8 ---- ln_before, modulation
   void* dX1 = b.Wk(wb.dX1);

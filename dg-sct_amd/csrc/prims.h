@@ -109,6 +109,16 @@ void modln_bwd(const Ctx&, const void* dX3, const void* X1, const float* ch, con
                float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N, int C,
                void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg);
 
+// Grouped projections with a tiny per-group narrow width dg = ds/g <= 8 (early-stage bottlenecks), on the vector units:
+//   narrow: y[r][gi*dg + jl] = sum_cl x[r][gi*cg + cl] * W(gi, jl, cl)      x E [rows][C]  -> y E [rows][ds]
+//   wide:   y[r][gi*cg + cl] = sum_jl x[r][gi*dg + jl] * W(gi, jl, cl)      x E [rows][ds] -> y E [rows][C]
+// with W(gi, jl, cl) = W[gi*sg + jl*sj + cl*sc] (fp32 master weight, either orientation), cg = C/g.
+// wide + stats (3*C floats, pre-zeroed): also accumulates bn_stats(y) in the same pass.
+bool gproj_supported(int mode, int C, int ds, int g);
+void gproj_narrow(const Ctx&, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc, void* y);
+void gproj_wide(const Ctx&, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc, void* y,
+                float* stats);
+
 // acc = [shift | sum(x-shift) | sum((x-shift)^2)] per column, 3*C floats, pre-zeroed.  x is E [rows][C].
 void bn_stats(const Ctx&, const void* x, long rows, int C, float* acc);
 // training: mean/var from acc, running stats updated (momentum, unbiased var); eval: mean/var = running.

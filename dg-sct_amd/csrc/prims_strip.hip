@@ -7,7 +7,9 @@
 // with all loads issued before the first use, so every lane keeps UNR x 16 B (x number of inputs) in
 // flight -- these kernels are pure HBM streams and latency hiding is the whole game.  Reductions are
 // combined across the row-slots of the workgroup in LDS (ds_add_f32) and leave as one fp32 atomic per
-// channel per workgroup.
+// channel per workgroup.  The UNR loads of a trip are UNCONDITIONAL (tail rows read a clamped, valid row and are
+// masked afterwards): a per-row "load or zero" makes hipcc branch around each load and emit s_waitcnt vmcnt(0)
+// after every one of them, i.e. four serial HBM round trips instead of four loads in flight.
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "prims.h"
@@ -114,15 +116,12 @@ __global__ __launch_bounds__(256) void colsum_k(const void* x, long ld, long bs,
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const long nn = n + (long)u * rpp;
-          if (nn < r_end) {
-            ldv<DT, VE>(x, (long)b * bs + nn * ld + vc * VE, t[u]);
-            rw[u] = roww ? roww[(long)b * roww_bs + nn] : 1.f;
-          } else {
-#pragma unroll
-            for (int e = 0; e < VE; ++e) t[u][e] = 0.f;
-            rw[u] = 0.f;
-          }
+          const long nc = nn < r_end ? nn : r_end - 1;            // unconditional, clamped (see the header comment)
+          ldv<DT, VE>(x, (long)b * bs + nc * ld + vc * VE, t[u]);
+          rw[u] = roww ? roww[(long)b * roww_bs + nc] : 1.f;
         }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) rw[u] = n + (long)u * rpp < r_end ? rw[u] : 0.f;
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
@@ -172,11 +171,13 @@ __global__ __launch_bounds__(256) void bn_stats_k(const void* x, long rows, int 
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const long rr = r + (long)u * rpp;
-          if (rr < r_end) ldv<DT, VE>(x, rr * C + vc * VE, t[u]);
-          else {
+          ldv<DT, VE>(x, (rr < r_end ? rr : r_end - 1) * C + vc * VE, t[u]);
+        }
 #pragma unroll
-            for (int e = 0; e < VE; ++e) t[u][e] = sft[e];
-          }
+        for (int u = 0; u < UNR; ++u) {
+          const bool ok = r + (long)u * rpp < r_end;
+#pragma unroll
+          for (int e = 0; e < VE; ++e) t[u][e] = ok ? t[u][e] : sft[e];
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const long rr = r + (long)u * rpp;
-        if (rr < r_end) ldv<DT, VE>(x, rr * C + vc * VE, t[u]);
+        ldv<DT, VE>(x, (rr < r_end ? rr : r_end - 1) * C + vc * VE, t[u]);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -285,11 +286,15 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const long rr = r + (long)u * rpp;
-          if (rr < r_end) { ldv<DT, VE>(dy, rr * C + vc * VE, g[u]); ldv<DT, VE>(x, rr * C + vc * VE, t[u]); }
-          else {
+          const long rc = rr < r_end ? rr : r_end - 1;
+          ldv<DT, VE>(dy, rc * C + vc * VE, g[u]);
+          ldv<DT, VE>(x, rc * C + vc * VE, t[u]);
+        }
 #pragma unroll
-            for (int e = 0; e < VE; ++e) { g[u][e] = 0.f; t[u][e] = 0.f; }
-          }
+        for (int u = 0; u < UNR; ++u) {
+          const bool ok = r + (long)u * rpp < r_end;
+#pragma unroll
+          for (int e = 0; e < VE; ++e) { g[u][e] = ok ? g[u][e] : 0.f; t[u][e] = ok ? t[u][e] : 0.f; }
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
@@ -341,7 +346,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const void* dy, const void
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const long rr = r + (long)u * rpp;
-        if (rr < r_end) { ldv<DT, VE>(dy, rr * C + vc * VE, g[u]); ldv<DT, VE>(x, rr * C + vc * VE, t[u]); }
+        const long rc = rr < r_end ? rr : r_end - 1;
+        ldv<DT, VE>(dy, rc * C + vc * VE, g[u]);
+        ldv<DT, VE>(x, rc * C + vc * VE, t[u]);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(256) void scale_cols_k(const void* x, void* y, int 
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const long nn = n + (long)u * rpp;
-        if (nn < r_end) ldv<DT, VE>(x, ((long)b * N + nn) * C + vc * VE, t[u]);
+        ldv<DT, VE>(x, ((long)b * N + (nn < r_end ? nn : r_end - 1)) * C + vc * VE, t[u]);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -431,10 +438,9 @@ __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, 
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const long nn = n + (long)u * rpp;
-          if (nn < r_end) {
-            ldv<DT, VE>(x, ((long)b * N + nn) * C + vc * VE, t[u]);
-            rw[u] = roww ? roww[(long)b * N + nn] : 1.f;
-          }
+          const long nc = nn < r_end ? nn : r_end - 1;
+          ldv<DT, VE>(x, ((long)b * N + nc) * C + vc * VE, t[u]);
+          rw[u] = roww ? roww[(long)b * N + nc] : 1.f;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -489,10 +495,8 @@ __global__ __launch_bounds__(256) void xc_bwd_k(const void* dXc, const void* X1,
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const long nn = n + (long)u * rpp;
-          if (nn < r_end) {
-            const long o = ((long)b * N + nn) * C + vc * VE;
-            ldv<DT, VE>(dXc, o, g[u]); ldv<DT, VE>(X1, o, x[u]); ldv<DT, VE>(dX1, o, d[u]);
-          }
+          const long o = ((long)b * N + (nn < r_end ? nn : r_end - 1)) * C + vc * VE;
+          ldv<DT, VE>(dXc, o, g[u]); ldv<DT, VE>(X1, o, x[u]); ldv<DT, VE>(dX1, o, d[u]);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {

@@ -6,6 +6,7 @@
 // the CPU-only build container.  The gfx950 kernels themselves are checked on the GPU against torch.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -245,6 +246,39 @@ void modln_bwd(const Ctx& ctx, const void* dX3, const void* X1, const float* ch,
       dsg[row] = beta * (float)rsum;
       if (tg && dtg) dtg[b] += gamma * (float)rsum;
     }
+}
+
+bool gproj_supported(int mode, int C, int ds, int g) {
+  if (getenv("DGSCT_NO_GPROJ") && atoi(getenv("DGSCT_NO_GPROJ"))) return false;
+  if (g < 1 || C % g || ds % g) return false;
+  const int ve = mode == DT_BF16 ? 8 : 4, cg = C / g, dg = ds / g;
+  if (dg < 1 || dg > 8 || (dg & 1) || cg % ve) return false;
+  int gs = 1;
+  while (gs < C / ve) gs <<= 1;
+  return gs <= 64 && ds <= gs && C <= 512 && (long)ds * cg <= 4096;
+}
+void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,
+                  void* y) {
+  const int cg = C / g, dg = ds / g;
+  for (long r = 0; r < rows; ++r)
+    for (int gi = 0; gi < g; ++gi)
+      for (int jl = 0; jl < dg; ++jl) {
+        double s = 0;
+        for (int cl = 0; cl < cg; ++cl) s += (double)ld(x, ctx.mode, r * C + gi * cg + cl) * W[gi * sg + jl * sj + cl * sc];
+        st(y, ctx.mode, r * ds + gi * dg + jl, (float)s);
+      }
+}
+void gproj_wide(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,
+                void* y, float* stats) {
+  const int cg = C / g, dg = ds / g;
+  for (long r = 0; r < rows; ++r)
+    for (int gi = 0; gi < g; ++gi)
+      for (int cl = 0; cl < cg; ++cl) {
+        double s = 0;
+        for (int jl = 0; jl < dg; ++jl) s += (double)ld(x, ctx.mode, r * ds + gi * dg + jl) * W[gi * sg + jl * sj + cl * sc];
+        st(y, ctx.mode, r * C + gi * cg + cl, (float)s);
+      }
+  if (stats) bn_stats(ctx, y, rows, C, stats);
 }
 
 void bn_stats(const Ctx& ctx, const void* x, long rows, int C, float* acc) {
