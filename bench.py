@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="run the RCCL gradient all-reduce path even with one rank (self-test)")
     ap.add_argument("--overlap", action="store_true", help="DP: launch each stage's all-reduce from autograd hooks while the "
                     "earlier stages' backward still runs (default: one grouped all-reduce after backward; see DESIGN.md section 5)")
+    ap.add_argument("--phases", action="store_true", help="also report GPU ms of forward / backward (events on the main stream)")
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of eager launches "
                     "(ROCm 7.2: replaying ~6000 nodes costs as much host time as launching them, so this is off by default)")
     args = ap.parse_args()
@@ -199,11 +200,20 @@ def main():
             opt = torch.optim.Adam(params, lr=1e-5, capturable=use_graph)
     feats, cots, mcots = make_inputs(stages, BT, dtype, device, seed=1 + rank)
 
+    phase_ev = []                          # (start, end-of-forward, end-of-backward) events of the timed steps (--phases)
+
     def fwd_bwd():
+        if args.phases:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
         outs, maps = stack(feats)
+        if args.phases:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
         tensors = [t for pair in outs for t in pair] + [maps[0], maps[1]]
         grads = [g for pair in cots for g in pair] + [mcots[0], mcots[1]]
         torch.autograd.backward(tensors, grads)
+        if args.phases:
+            e2 = torch.cuda.Event(enable_timing=True); e2.record()
+            phase_ev.append((e0, e1, e2))
         for fv, fa in feats:
             fv.grad = None
             fa.grad = None
@@ -347,7 +357,10 @@ def main():
                         global_batch=args.batch * world, frames_per_clip=T, parallelism=f"dp{world}",
                         step="fwd+bwd" + ("+allreduce" if dp else "") + ("" if args.no_optim else "+adam"),
                         streams=1 if args.serial else 2, hip_graph=use_graph, host_enqueue_ms_per_step=round(host_s / args.steps * 1e3, 2),
-                        host_ms_fwdbwd_allreduce_optim=host_ms),
+                        host_ms_fwdbwd_allreduce_optim=host_ms,
+                        **({"gpu_ms_fwd_bwd": [round(sum(a.elapsed_time(b) for a, b, _ in phase_ev[-args.steps:]) / args.steps, 2),
+                                               round(sum(b.elapsed_time(c) for _, b, c in phase_ev[-args.steps:]) / args.steps, 2)]}
+                           if args.phases and len(phase_ev) >= args.steps else {})),
             roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if dp:

@@ -161,6 +161,54 @@ __device__ __forceinline__ void stage_store(const uint4 (&reg)[NLD_], char* lds,
   }
 }
 
+// ---- FAST staging (bf16, 16-byte chunks never straddle an edge: host-checked) ----------------------------------
+// Straight-line code: every chunk is loaded UNCONDITIONALLY from a clamped (always valid) address and the edge mask is
+// applied when the registers are written to LDS.  The guarded generic path above compiles to branch + load +
+// s_waitcnt vmcnt(0) per chunk (hipcc materialises the select at the merge point), i.e. the chunks of a k-tile are
+// fetched one after the other and the register prefetch overlaps nothing.
+template <bool KM, int ROWS, int NLD_>
+__device__ __forceinline__ void stage_load_fast(uint4 (&reg)[NLD_], const char* base, long ld, long kbs, int r0, int rows_total,
+                                                int kf0, int K, int Kflat, unsigned kinv, int tid) {
+  using G = TileGeom<DT_BF16, KM, ROWS>;
+  constexpr int VE = G::VE;
+#pragma unroll
+  for (int i = 0; i < G::NLD; ++i) {
+    int c = tid + i * 256;
+    if (G::NCHUNK % 256 != 0) c = c < G::NCHUNK ? c : G::NCHUNK - 1;
+    int r, k;
+    if (KM) { r = c / (G::BKT / VE); k = (c % (G::BKT / VE)) * VE; }
+    else    { k = c / (ROWS / VE);   r = (c % (ROWS / VE)) * VE; }
+    int rg = r0 + r, kf = kf0 + k;
+    if (KM) { rg = rg < rows_total ? rg : rows_total - 1; kf = kf < Kflat ? kf : Kflat - VE; }
+    else    { rg = rg < rows_total ? rg : rows_total - VE; kf = kf < Kflat ? kf : Kflat - 1; }
+    // branch-free (kf, K) -> (frame, k): kinv = ceil(2^32 / K) gives frame 0 for kf < K, so one-level contractions need no
+    // special case (a branch here makes hipcc drain vmcnt at its merge point)
+    const int kb = (int)__umulhi((unsigned)kf, kinv);
+    const int kk = kf - kb * K;
+    const char* p = base + ((long)kb * kbs + (KM ? (long)rg * ld + kk : (long)kk * ld + rg)) * 2;
+    reg[i] = *reinterpret_cast<const uint4*>(p);
+  }
+}
+template <bool KM, int ROWS, int NLD_>
+__device__ __forceinline__ void stage_store_fast(const uint4 (&reg)[NLD_], char* lds, int r0, int rows_total, int kf0, int Kflat,
+                                                 int tid) {
+  using G = TileGeom<DT_BF16, KM, ROWS>;
+  constexpr int VE = G::VE;
+#pragma unroll
+  for (int i = 0; i < G::NLD; ++i) {
+    const int c = tid + i * 256;
+    if (G::NCHUNK % 256 != 0 && c >= G::NCHUNK) continue;
+    int r, k;
+    if (KM) { r = c / (G::BKT / VE); k = (c % (G::BKT / VE)) * VE; }
+    else    { k = c / (ROWS / VE);   r = (c % (ROWS / VE)) * VE; }
+    const bool ok = r0 + r < rows_total && kf0 + k < Kflat;
+    uint4 v = reg[i];
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    if (KM) *reinterpret_cast<uint4*>(lds + r * G::PITCH + k * 2) = v;
+    else    *reinterpret_cast<uint4*>(lds + k * G::PITCH + r * 2) = v;
+  }
+}
+
 // ---- LDS -> MFMA fragment (bf16) ---------------------------------------------------------------
 // 32x32x16 operand fragment: lane l holds X[row = l&31][k = 8*(l>>5) .. +7] of the 16-deep k-step kk.
 template <bool KM, int ROWS>
@@ -185,8 +233,10 @@ __device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row0, int kk,
   }
 }
 
-template <int MODE, bool AK, bool BK, int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmK p) {
+// Occupancy: 3 workgroups per CU (168 VGPRs) everywhere except the 128x128 tile with one K-major and one MN-major
+// operand, whose two address streams + two prefetch sets + 64 accumulators need ~200 registers (spilled 120 at 168).
+template <int MODE, bool AK, bool BK, int WGM, int WGN, int TM, int TN, bool FAST>
+__global__ __launch_bounds__(256, (TM * TN == 4 && AK != BK) ? 2 : 3) void gemm_kernel(const GemmK p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   using GA = TileGeom<MODE, AK, BM>;
   using GB = TileGeom<MODE, BK, BN>;
@@ -269,28 +319,42 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmK p) {
   };
 #define DGSCT_PREFETCH(RA, RB, KT)                                                                                     \
   do {                                                                                                                 \
-    stage_load<MODE, AK, BM>(RA, Ab, p.lda, p.a_kbs, m0, p.M, (KT) * BKT, p.K, p.kflat, p.kinv, p.a_vec, tid);           \
-    stage_load<MODE, BK, BN>(RB, Bb, p.ldb, p.b_kbs, n0, p.N, (KT) * BKT, p.K, p.kflat, p.kinv, p.b_vec, tid);           \
+    if constexpr (FAST) {                                                                                              \
+      stage_load_fast<AK, BM>(RA, Ab, p.lda, p.a_kbs, m0, p.M, (KT) * BKT, p.K, p.kflat, p.kinv, tid);                   \
+      stage_load_fast<BK, BN>(RB, Bb, p.ldb, p.b_kbs, n0, p.N, (KT) * BKT, p.K, p.kflat, p.kinv, tid);                   \
+    } else {                                                                                                           \
+      stage_load<MODE, AK, BM>(RA, Ab, p.lda, p.a_kbs, m0, p.M, (KT) * BKT, p.K, p.kflat, p.kinv, p.a_vec, tid);         \
+      stage_load<MODE, BK, BN>(RB, Bb, p.ldb, p.b_kbs, n0, p.N, (KT) * BKT, p.K, p.kflat, p.kinv, p.b_vec, tid);         \
+    }                                                                                                                  \
+  } while (0)
+#define DGSCT_STORE(RA, RB, KT)                                                                                        \
+  do {                                                                                                                 \
+    if constexpr (FAST) {                                                                                              \
+      stage_store_fast<AK, BM>(RA, ldsA, m0, p.M, (KT) * BKT, p.kflat, tid);                                             \
+      stage_store_fast<BK, BN>(RB, ldsB, n0, p.N, (KT) * BKT, p.kflat, tid);                                             \
+    } else {                                                                                                           \
+      stage_store<MODE, AK, BM>(RA, ldsA, tid);                                                                        \
+      stage_store<MODE, BK, BN>(RB, ldsB, tid);                                                                        \
+    }                                                                                                                  \
   } while (0)
   if (kt_begin < kt_end) DGSCT_PREFETCH(ra0, rb0, kt_begin);
   if (kt_begin + 1 < kt_end) DGSCT_PREFETCH(ra1, rb1, kt_begin + 1);
   for (int kt = kt_begin; kt < kt_end; kt += 2) {
     __syncthreads();                       // previous tile's fragment reads are done
-    stage_store<MODE, AK, BM>(ra0, ldsA, tid);
-    stage_store<MODE, BK, BN>(rb0, ldsB, tid);
+    DGSCT_STORE(ra0, rb0, kt);
     __syncthreads();
     if (kt + 2 < kt_end) DGSCT_PREFETCH(ra0, rb0, kt + 2);
     compute();
     if (kt + 1 < kt_end) {
       __syncthreads();
-      stage_store<MODE, AK, BM>(ra1, ldsA, tid);
-      stage_store<MODE, BK, BN>(rb1, ldsB, tid);
+      DGSCT_STORE(ra1, rb1, kt + 1);
       __syncthreads();
       if (kt + 3 < kt_end) DGSCT_PREFETCH(ra1, rb1, kt + 3);
       compute();
     }
   }
 #undef DGSCT_PREFETCH
+#undef DGSCT_STORE
 
   // ---- epilogue: accumulator element r of tile (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
   const float alpha = p.alpha * (p.alpha_ptr ? *p.alpha_ptr : 1.f);
@@ -467,12 +531,19 @@ void gemm_prof_collect(long* launches, double* total_ms, double* total_flops) {
   if (total_flops) *total_flops = fl;
 }
 
+template <int MODE, int WGM, int WGN, int TM, int TN, bool FAST>
+static void launch_lay(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s) {
+  if (ak && bk)       hipLaunchKernelGGL((gemm_kernel<MODE, true, true, WGM, WGN, TM, TN, FAST>), grid, dim3(256), 0, s, k);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<MODE, true, false, WGM, WGN, TM, TN, FAST>), grid, dim3(256), 0, s, k);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<MODE, false, true, WGM, WGN, TM, TN, FAST>), grid, dim3(256), 0, s, k);
+  else                hipLaunchKernelGGL((gemm_kernel<MODE, false, false, WGM, WGN, TM, TN, FAST>), grid, dim3(256), 0, s, k);
+}
 template <int MODE, int WGM, int WGN, int TM, int TN>
-static void launch_cfg(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s) {
-  if (ak && bk)       hipLaunchKernelGGL((gemm_kernel<MODE, true, true, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<MODE, true, false, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<MODE, false, true, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
-  else                hipLaunchKernelGGL((gemm_kernel<MODE, false, false, WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
+static void launch_cfg(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s, bool fast) {
+  if constexpr (MODE == DT_BF16) {
+    if (fast) { launch_lay<MODE, WGM, WGN, TM, TN, true>(k, ak, bk, grid, s); return; }
+  }
+  launch_lay<MODE, WGM, WGN, TM, TN, false>(k, ak, bk, grid, s);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -553,12 +624,16 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   shp.bytes = ((double)g.M * g.K * g.KB * (g.A.bs ? g.batch : 1) + (double)g.N * g.K * g.KB * (g.B.bs ? g.batch : 1)) * ES +
               (double)g.M * g.N * g.batch * (g.ddt == DT_F32 ? 4 : 2) * (g.R ? 2 : 1);
   ProfRec* rec = prof_begin(s, 2.0 * g.M * g.N * (double)g.K * g.KB * g.batch, shp);
+  // FAST staging: 16-byte chunks are aligned and never straddle a matrix edge or a frame of a two-level contraction
+  static const bool no_fast = getenv("DGSCT_GEMM_NOFAST") != nullptr;
+  const bool fast = MODE == DT_BF16 && !no_fast && k.a_vec && k.b_vec && g.K % VE == 0 && (long)g.K * g.KB >= VE &&
+                    (ak || g.M % VE == 0) && (bk || g.N % VE == 0) && g.M >= VE && g.N >= VE;
   switch (cfg) {
-    case 0: launch_cfg<MODE, 2, 2, 2, 2>(k, ak, bk, grid, s); break;
-    case 1: launch_cfg<MODE, 4, 1, 1, 3>(k, ak, bk, grid, s); break;
-    case 2: launch_cfg<MODE, 4, 1, 1, 1>(k, ak, bk, grid, s); break;
-    case 3: launch_cfg<MODE, 1, 4, 1, 1>(k, ak, bk, grid, s); break;
-    default: launch_cfg<MODE, 2, 2, 1, 1>(k, ak, bk, grid, s); break;
+    case 0: launch_cfg<MODE, 2, 2, 2, 2>(k, ak, bk, grid, s, fast); break;
+    case 1: launch_cfg<MODE, 4, 1, 1, 3>(k, ak, bk, grid, s, fast); break;
+    case 2: launch_cfg<MODE, 4, 1, 1, 1>(k, ak, bk, grid, s, fast); break;
+    case 3: launch_cfg<MODE, 1, 4, 1, 1>(k, ak, bk, grid, s, fast); break;
+    default: launch_cfg<MODE, 2, 2, 1, 1>(k, ak, bk, grid, s, fast); break;
   }
   prof_end(rec, s);
 }
