@@ -589,11 +589,14 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.batch; };
   if (g.N <= 32) cfg = 2;                                       // 128 x 32
   else if (g.M <= 32) cfg = 3;                                  // 32 x 128
+  else if (kflat <= 64 && g.M >= 1024 && g.N <= 128 && g.N % 128 != 0) cfg = 2;   // token x tk products: N = 96 as 3 x 32
+  else if (!g.atomic && g.N % 96 == 0 && g.N % 128 != 0 && g.M >= 128 && kflat >= 64) cfg = 1;   // 128 x 96: no padded columns
   else if (kflat >= 1024 && !g.atomic) {
-    if (g.N % 128 != 0 && g.N % 96 == 0 && g.M >= 96) cfg = 1; // 128 x 96
+    if (tiles(128, 128) < 64) cfg = 4;                          // B x C gate GEMMs (M = 160): 8-16 big tiles leave the chip idle
     else if (g.M >= 96 && g.N >= 96) cfg = 0;                   // 128 x 128
     else cfg = 4;
   } else if (g.atomic && g.M >= 1024 && g.N >= 1024 && kflat >= 8192) cfg = 0;   // dWn: a plain big GEMM
+  else if (g.atomic && g.M <= 128 && g.M % 64 != 0 && g.M % 32 == 0) cfg = 3;     // 96-row weight gradients: 3 x 32 rows
   else {
     const long w0 = tiles(128, 128);
     const long last = w0 % 768;

@@ -9,21 +9,50 @@ from dgsct_amd._lib import GemmArgs, default_lib
 DEV = "cuda:0"
 # (M, N, K, KB, batch, ak, bk, a_shared, atomic, out_bf16, residual)
 SHAPES = [
-    (128, 128, 368640, 1, 1, 0, 0, 0, 1, 0, 0),      # dWv1 stage 0 (TN, split-K atomics)
-    (64, 128, 368640, 1, 1, 0, 0, 0, 1, 0, 0),       # dWv2 stage 0
-    (128, 96, 368640, 1, 1, 0, 0, 0, 1, 0, 0),       # dWc stage 0
-    (256, 256, 92160, 1, 1, 0, 0, 0, 1, 0, 0),       # dWv1 stage 1
-    (512, 512, 23040, 1, 1, 0, 0, 0, 1, 0, 0),       # dWv1 stage 2
-    (1024, 1024, 5760, 1, 1, 0, 0, 0, 1, 0, 0),      # dWv1 stage 3
-    (64, 8, 368640, 1, 2, 0, 0, 0, 1, 0, 0),         # dWu stage 0 (grouped)
-    (8, 64, 368640, 1, 2, 0, 0, 0, 1, 0, 0),         # dWd stage 0
-    (368640, 128, 128, 1, 1, 1, 0, 0, 0, 1, 1),      # dX1 += dvq1.Wv1 stage 0
-    (368640, 128, 64, 1, 1, 1, 0, 0, 0, 1, 0),       # dXc = dvq2.Wv2
-    (368640, 96, 128, 1, 1, 1, 0, 0, 0, 1, 0),       # dT1 = dYp.Wc
+    # --- stage 0 (M = BT*N tokens; C = 96 / 128)
+    (4096, 96, 2304, 1, 160, 1, 1, 1, 0, 1, 0),      # remap fwd audio  T = Wn.T2   (A shared across the batch)
+    (2304, 96, 4096, 1, 160, 1, 0, 1, 0, 1, 0),      # remap fwd visual
+    (4096, 96, 2304, 1, 160, 0, 0, 1, 0, 1, 0),      # remap bwd
+    (4096, 2304, 96, 160, 1, 1, 0, 0, 1, 0, 0),      # dWn audio (two-level K, atomics)
+    (2304, 4096, 96, 160, 1, 1, 1, 0, 1, 0, 0),      # dWn visual
+    (655360, 96, 96, 1, 1, 1, 1, 0, 0, 1, 0),        # vq1 = X1.Wv1^T
+    (655360, 96, 96, 1, 1, 1, 0, 0, 0, 1, 1),        # dX1 += dvq1.Wv1
+    (655360, 48, 96, 1, 1, 1, 1, 0, 0, 1, 0),        # vq2
+    (368640, 128, 128, 1, 1, 1, 1, 0, 0, 1, 0),
     (368640, 128, 96, 1, 1, 1, 1, 0, 0, 1, 0),       # Yp = T1.Wc^T
+    (4096, 96, 32, 1, 160, 1, 0, 0, 0, 1, 1),        # X1 = X + P2.tok
+    (4096, 32, 96, 1, 160, 1, 1, 0, 0, 0, 0),        # S2 = X.tok^T (fp32 out)
+    (32, 96, 4096, 1, 160, 0, 0, 0, 0, 0, 0),        # dtok = P2^T.dX1
+    (96, 96, 655360, 1, 1, 0, 0, 0, 1, 0, 0),        # dWv1 stage 0
+    (128, 128, 368640, 1, 1, 0, 0, 0, 1, 0, 0),
+    # --- stage 1
+    (163840, 192, 192, 1, 1, 1, 1, 0, 0, 1, 0),
+    (92160, 256, 256, 1, 1, 1, 1, 0, 0, 1, 0),
+    (256, 256, 92160, 1, 1, 0, 0, 0, 1, 0, 0),
+    (1024, 192, 576, 1, 160, 1, 1, 1, 0, 1, 0),      # remap stage 1
+    (576, 1024, 192, 160, 1, 1, 0, 0, 1, 0, 0),      # dWn stage 1
+    # --- stage 2
+    (40960, 384, 384, 1, 1, 1, 1, 0, 0, 1, 0),
+    (23040, 512, 512, 1, 1, 1, 1, 0, 0, 1, 0),
+    (23040, 512, 512, 1, 1, 1, 0, 0, 0, 1, 1),
+    (23040, 256, 512, 1, 1, 1, 1, 0, 0, 1, 0),
+    (512, 512, 23040, 1, 1, 0, 0, 0, 1, 0, 0),
+    (384, 384, 40960, 1, 1, 0, 0, 0, 1, 0, 0),
+    (144, 512, 256, 1, 160, 1, 0, 1, 0, 1, 0),       # remap stage 2
+    (144, 256, 384, 160, 1, 1, 1, 0, 1, 0, 0),       # dWn stage 2
+    (256, 384, 32, 1, 160, 1, 0, 0, 0, 1, 1),
+    (32, 256, 384, 1, 160, 1, 1, 0, 0, 0, 0),
+    # --- stage 3 and the B x C gate GEMMs
+    (5760, 1024, 1024, 1, 1, 1, 1, 0, 0, 1, 0),
+    (5760, 512, 1024, 1, 1, 1, 1, 0, 0, 1, 0),
+    (1024, 1024, 5760, 1, 1, 0, 0, 0, 1, 0, 0),
+    (160, 1024, 1024, 1, 1, 1, 1, 0, 0, 1, 0),
+    (160, 512, 1024, 1, 1, 1, 0, 0, 0, 1, 0),
+    (160, 512, 512, 1, 1, 1, 1, 0, 0, 1, 0),
+    (160, 256, 512, 1, 1, 1, 1, 0, 0, 1, 0),
 ]
 
-def run(shape, iters=20):
+def run(shape, iters=10):
     M, N, K, KB, batch, ak, bk, ash, atomic, obf, res = shape
     lib = default_lib()
     dt = torch.bfloat16
