@@ -24,6 +24,7 @@
 #include <vector>
 #include "prims.h"
 #include "device_util.h"
+#include "err.h"
 
 namespace dgsct {
 
@@ -45,6 +46,7 @@ struct GemmK {
   const char* R; int rdt; long ldr, rbs; float beta;
   const char* R2;
   const char* mask; long ldmask, maskbs;
+  const float* sm_scale; float* sm_dot;
   int atomic;
   int wide;
 };
@@ -363,6 +365,84 @@ __global__ __launch_bounds__(256, (TM * TN == 4 && AK != BK) ? 2 : 3) void gemm_
   const char* R2b = p.R2 ? p.R2 + (long)b * p.rbs * (p.rdt == DT_F32 ? 4 : 2) : nullptr;
   const char* Mb = p.mask ? p.mask + (long)b * p.maskbs * ES : nullptr;
   const float* bias_n = p.bias_n ? p.bias_n + (long)b * p.bias_n_bs : nullptr;
+  if constexpr (WGM == 1 && TM == 1 && TN == 1) {
+    // Column-wise softmax epilogues (ACT_SOFTMAX / ACT_SOFTMAX_BWD) over the M <= 32 rows of the tile, output written
+    // TRANSPOSED: D[n][m].  The GEMM is issued as logits^T = tok . X^T, so the softmax axis (the latent tokens) runs
+    // along the accumulator REGISTERS of a lane -- 16 values per lane, the other 16 in lane^32 -- and one token's
+    // softmax costs ~35 VALU ops + 2 cross-half exchanges (a row-wise formulation needs 160 ds_bpermutes per tile).
+    if (p.act == ACT_SOFTMAX || p.act == ACT_SOFTMAX_BWD) {
+      const int n = n0 + wn * 32 + (lane & 31);
+      const int h = lane >> 5;
+      const bool nok = n < p.N;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = alpha * acc[0][0][r];
+      const int esz = p.ddt == DT_F32 ? 4 : 2;
+      char* drow = Db + (long)(nok ? n : 0) * p.ldd * esz;
+      float dot_total = 0.f;
+      if (p.act == ACT_SOFTMAX) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (t < p.M) mx = fmaxf(mx, v[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = (r & 3) + 8 * (r >> 2) + 4 * h;
+          v[r] = t < p.M ? __expf(v[r] - mx) : 0.f;
+          sum += v[r];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= inv;
+      } else {
+        const char* prow = Mb + (long)(nok ? n : 0) * p.ldmask * ES;
+        float pv[16];
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = (r & 3) + 8 * (r >> 2) + 4 * h;
+          pv[r] = (t < p.M) ? lde_rt(prow, MODE, t) : 0.f;
+          dot += pv[r] * v[r];
+        }
+        dot += __shfl_xor(dot, 32, 64);
+        const float sc = p.sm_scale ? *p.sm_scale : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = sc * pv[r] * (v[r] - dot);
+        if (nok && h == 0) dot_total = dot;
+      }
+      if (nok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                    // 4 consecutive rows t = 8q + 4h + {0..3} per store
+          const int t0 = 8 * q + 4 * h;
+          if (t0 + 4 <= p.M && (p.ldd & 3) == 0) {
+            if (p.ddt == DT_F32) {
+              *reinterpret_cast<float4*>(drow + (long)t0 * 4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            } else {
+              uint2 w;
+              w.x = (unsigned)f2bf(v[4 * q]) | ((unsigned)f2bf(v[4 * q + 1]) << 16);
+              w.y = (unsigned)f2bf(v[4 * q + 2]) | ((unsigned)f2bf(v[4 * q + 3]) << 16);
+              *reinterpret_cast<uint2*>(drow + (long)t0 * 2) = w;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (t0 + e < p.M) ste_rt(drow, p.ddt, t0 + e, v[4 * q + e]);
+          }
+        }
+      }
+      if (p.act == ACT_SOFTMAX_BWD && p.sm_dot) {        // one atomic per workgroup
+        __syncthreads();
+        const float tsum = block_sum(dot_total, reinterpret_cast<float*>(smem));
+        if (tid == 0) unsafeAtomicAdd(p.sm_dot, tsum);
+      }
+      return;
+    }
+  }
   if (p.wide) {
     // Wide path: stage each wave's 32 x (TN*32) block through LDS (fp32) and write full token rows with 16-byte
     // stores (32-byte for fp32 out); the residual is read the same way.  An MFMA accumulator holds a COLUMN per lane,
@@ -567,10 +647,12 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   k.R = (const char*)g.R; k.rdt = g.rdt; k.ldr = g.ldr; k.rbs = g.rbs; k.beta = g.beta;
   k.R2 = g.R ? (const char*)g.R2 : nullptr;
   k.mask = (const char*)g.mask; k.ldmask = g.ldmask; k.maskbs = g.maskbs;
+  k.sm_scale = g.sm_scale; k.sm_dot = g.sm_dot;
   k.atomic = g.atomic;
+  const bool rowwise = g.act == ACT_SOFTMAX || g.act == ACT_SOFTMAX_BWD;
   {
     const int dv = g.ddt == DT_F32 ? 4 : 8, rv = g.rdt == DT_F32 ? 4 : 8;
-    bool w = !g.atomic && !g.mask && aligned16(g.D) && g.ldd % dv == 0 && g.dbs % dv == 0 && g.N >= 8;
+    bool w = !g.atomic && !g.mask && !rowwise && aligned16(g.D) && g.ldd % dv == 0 && g.dbs % dv == 0 && g.N >= 8;
     if (g.R) w = w && aligned16(g.R) && g.ldr % rv == 0 && g.rbs % rv == 0 && (!g.R2 || aligned16(g.R2));
     k.wide = w;
   }
@@ -604,6 +686,13 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     cfg = (kflat > 256 && g.M >= 128 && g.N >= 128 && fills && !g.atomic) ? 0 : 4;
   }
   if (const char* e = getenv("DGSCT_GEMM_CFG")) { const int c = atoi(e); if (c >= 0 && c <= 4) cfg = c; }   // tuning hook
+  if (rowwise) {
+    if (g.M > 32 || g.R || g.atomic || g.splitk > 1 || g.bias_m || g.bias_n) {
+      set_error("gemm: softmax epilogue needs M <= 32 and a plain, unsplit output");
+      return;
+    }
+    cfg = 3;                                                      // 32 x 128: the softmax axis in one tile's registers
+  }
   static const int BMs[5] = {128, 128, 128, 32, 64}, BNs[5] = {128, 96, 32, 128, 64};
   k.tiles_m = (g.M + BMs[cfg] - 1) / BMs[cfg];
   k.tiles_n = (g.N + BNs[cfg] - 1) / BNs[cfg];

@@ -333,9 +333,18 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     Gemm g1 = mk(N, tk, C, B);                                   // S2 = X . tok^T
     g1.A = km(X, C, (long)N * C);
     g1.B = km(b.S(s.tok), C, (long)tk * C);
-    outF(g1, b.Wk<float>(wf.S2), tkp, (long)N * tkp);
-    gemm(ctx, g1);
-    softmax_rows(ctx, b.Wk<float>(wf.S2), tkp, b.S(s.P2), E, tkp, R, tk, 0);
+    if (tk <= 32) {                                              // P2 = softmax_tk(X . tok^T) in one launch: the GEMM runs
+      Gemm gt = mk(tk, N, C, B);                                 // transposed (tok . X^T) and its epilogue does the softmax
+      gt.A = km(b.S(s.tok), C, (long)tk * C);
+      gt.B = km(X, C, (long)N * C);
+      gt.act = ACT_SOFTMAX;
+      outE(gt, b.S(s.P2), E, tkp, (long)N * tkp);
+      gemm(ctx, gt);
+    } else {
+      outF(g1, b.Wk<float>(wf.S2), tkp, (long)N * tkp);
+      gemm(ctx, g1);
+      softmax_rows(ctx, b.Wk<float>(wf.S2), tkp, b.S(s.P2), E, tkp, R, tk, 0);
+    }
     Gemm g2 = mk(N, C, tk, B);                                   // X1 = X + gate_av * P2 . tok
     g2.A = km(b.S(s.P2), tkp, (long)N * tkp);
     g2.B = mn(b.S(s.tok), C, (long)tk * C);
@@ -622,10 +631,21 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g1 = mk(N, tk, C, B);                                   // U = dX1 . tok^T
     g1.A = km(dX1, C, (long)N * C);
     g1.B = km(b.S(s.tok), C, (long)tk * C);
-    outF(g1, b.Wk<float>(wb.U), tkp, (long)N * tkp);
-    gemm(ctx, g1);
-    softmax_bwd_rows(ctx, b.S(s.P2), tkp, b.Wk<float>(wb.U), tkp, b.Wk(wb.dS2), E, tkp, R, tk, b.F(DGSCT_P_GATE_AV),
-                     G(DGSCT_P_GATE_AV));
+    if (tk <= 32) {                                              // dS2 = softmax'(U) fused: U^T = tok . dX1^T, epilogue
+      Gemm gt = mk(tk, N, C, B);
+      gt.A = km(b.S(s.tok), C, (long)tk * C);
+      gt.B = km(dX1, C, (long)N * C);
+      gt.act = ACT_SOFTMAX_BWD;
+      gt.mask = b.S(s.P2); gt.ldmask = tkp; gt.maskbs = (long)N * tkp;
+      gt.sm_scale = b.F(DGSCT_P_GATE_AV); gt.sm_dot = G(DGSCT_P_GATE_AV);
+      outE(gt, b.Wk(wb.dS2), E, tkp, (long)N * tkp);
+      gemm(ctx, gt);
+    } else {
+      outF(g1, b.Wk<float>(wb.U), tkp, (long)N * tkp);
+      gemm(ctx, g1);
+      softmax_bwd_rows(ctx, b.S(s.P2), tkp, b.Wk<float>(wb.U), tkp, b.Wk(wb.dS2), E, tkp, R, tk, b.F(DGSCT_P_GATE_AV),
+                       G(DGSCT_P_GATE_AV));
+    }
     Gemm g2 = mk(N, C, tk, B);                                   // dX = dX1 + dS2 . tok
     g2.A = km(b.Wk(wb.dS2), tkp, (long)N * tkp);
     g2.B = mn(b.S(s.tok), C, (long)tk * C);

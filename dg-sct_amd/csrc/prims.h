@@ -44,7 +44,11 @@ struct MatOp {
   long kbs = 0;
 };
 
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+// ACT_SOFTMAX / ACT_SOFTMAX_BWD: fused epilogues of the X <- latent-token attention (net_trans.py:583-589).  The GEMM
+// computes logits^T (M = latent tokens <= 32, N = tokens) and the epilogue works down each COLUMN and writes the
+// result TRANSPOSED, D[b][n*ldd + m]:  softmax_m(acc)   /   s * P * (acc - sum_m P*acc)  with P[b][n*ldmask + m] = `mask`
+// (dtype E), s = *sm_scale (or 1), and *sm_dot += sum_{m,n} P*acc (the gate_av gradient).
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_SOFTMAX = 3, ACT_SOFTMAX_BWD = 4 };
 
 // D[b][m][n] = epi( sum_{kb<KB} sum_{k<K} A[b][m][(kb,k)] * B[b][n][(kb,k)] )
 //   v  = alpha * (alpha_ptr ? *alpha_ptr : 1) * acc
@@ -62,6 +66,7 @@ struct Gemm {
   const void* R = nullptr; int rdt = DT_F32; long ldr = 0, rbs = 0; float beta = 1.f;
   const void* R2 = nullptr;                                  // second residual, same dtype / ld / batch stride as R, weight 1
   const void* mask = nullptr; long ldmask = 0, maskbs = 0;   // dtype E
+  const float* sm_scale = nullptr; float* sm_dot = nullptr;  // ACT_SOFTMAX_BWD only
 };
 
 void gemm(const Ctx&, const Gemm&);

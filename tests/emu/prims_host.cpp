@@ -36,7 +36,44 @@ void stream_join(const Ctx&) {}
 
 void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
 
+static void gemm_softmax(const Ctx& ctx, const Gemm& g) {      // ACT_SOFTMAX / ACT_SOFTMAX_BWD: column-wise, transposed out
+  const int E = ctx.mode;
+  const float alpha = g.alpha * (g.alpha_ptr ? *g.alpha_ptr : 1.f);
+  const float sc = g.sm_scale ? *g.sm_scale : 1.f;
+  std::vector<float> col(g.M);
+  double tot = 0;
+  for (int b = 0; b < g.batch; ++b)
+    for (int n = 0; n < g.N; ++n) {
+      for (int m = 0; m < g.M; ++m) {
+        double acc = 0;
+        for (int kb = 0; kb < g.KB; ++kb)
+          for (int k = 0; k < g.K; ++k) {
+            const long ao = (long)b * g.A.bs + (long)kb * g.A.kbs + (g.A.kmajor ? (long)m * g.A.ld + k : (long)k * g.A.ld + m);
+            const long bo = (long)b * g.B.bs + (long)kb * g.B.kbs + (g.B.kmajor ? (long)n * g.B.ld + k : (long)k * g.B.ld + n);
+            acc += (double)ld(g.A.p, E, ao) * (double)ld(g.B.p, E, bo);
+          }
+        col[m] = alpha * (float)acc;
+      }
+      const long o = (long)b * g.dbs + (long)n * g.ldd;
+      const long po = (long)b * g.maskbs + (long)n * g.ldmask;
+      if (g.act == ACT_SOFTMAX) {
+        float mx = -INFINITY;
+        for (int m = 0; m < g.M; ++m) mx = std::max(mx, col[m]);
+        double s = 0;
+        for (int m = 0; m < g.M; ++m) s += std::exp(col[m] - mx);
+        for (int m = 0; m < g.M; ++m) st(g.D, g.ddt, o + m, (float)(std::exp(col[m] - mx) / s));
+      } else {
+        double pd = 0;
+        for (int m = 0; m < g.M; ++m) pd += (double)ld(g.mask, E, po + m) * col[m];
+        tot += pd;
+        for (int m = 0; m < g.M; ++m) st(g.D, g.ddt, o + m, sc * ld(g.mask, E, po + m) * (col[m] - (float)pd));
+      }
+    }
+  if (g.act == ACT_SOFTMAX_BWD && g.sm_dot) *g.sm_dot += (float)tot;
+}
+
 void gemm(const Ctx& ctx, const Gemm& g) {
+  if (g.act == ACT_SOFTMAX || g.act == ACT_SOFTMAX_BWD) { gemm_softmax(ctx, g); return; }
   const int E = ctx.mode;
   const float alpha = g.alpha * (g.alpha_ptr ? *g.alpha_ptr : 1.f);
   for (int b = 0; b < g.batch; ++b)
