@@ -238,7 +238,8 @@ __device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row0, int kk,
 // Occupancy: 3 workgroups per CU (168 VGPRs) everywhere except the 128x128 tile with one K-major and one MN-major
 // operand, whose two address streams + two prefetch sets + 64 accumulators need ~200 registers (spilled 120 at 168).
 template <int MODE, bool AK, bool BK, int WGM, int WGN, int TM, int TN, bool FAST>
-__global__ __launch_bounds__(256, (TM * TN == 4 && AK != BK) ? 2 : 3) void gemm_kernel(const GemmK p) {
+__global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : ((TM * TN >= 6 || (TM * TN == 4 && AK != BK)) ? 2 : 3))
+void gemm_kernel(const GemmK p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   using GA = TileGeom<MODE, AK, BM>;
   using GB = TileGeom<MODE, BK, BN>;
@@ -339,6 +340,17 @@ __global__ __launch_bounds__(256, (TM * TN == 4 && AK != BK) ? 2 : 3) void gemm_
       stage_store<MODE, BK, BN>(RB, ldsB, tid);                                                                        \
     }                                                                                                                  \
   } while (0)
+  constexpr bool ONE_SET = TM * TN >= 6 && TM * TN < 8;   // 256 x 96: two sets (88 VGPRs) + 96 accumulators spill at 2 WG/CU
+  if constexpr (ONE_SET) {
+    if (kt_begin < kt_end) DGSCT_PREFETCH(ra0, rb0, kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      __syncthreads();
+      DGSCT_STORE(ra0, rb0, kt);
+      __syncthreads();
+      if (kt + 1 < kt_end) DGSCT_PREFETCH(ra0, rb0, kt + 1);
+      compute();
+    }
+  } else {
   if (kt_begin < kt_end) DGSCT_PREFETCH(ra0, rb0, kt_begin);
   if (kt_begin + 1 < kt_end) DGSCT_PREFETCH(ra1, rb1, kt_begin + 1);
   for (int kt = kt_begin; kt < kt_end; kt += 2) {
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4 && AK != BK) ? 2 : 3) void gemm_
       if (kt + 3 < kt_end) DGSCT_PREFETCH(ra1, rb1, kt + 3);
       compute();
     }
+  }
   }
 #undef DGSCT_PREFETCH
 #undef DGSCT_STORE
@@ -672,7 +685,9 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   if (g.N <= 32) cfg = 2;                                       // 128 x 32
   else if (g.M <= 32) cfg = 3;                                  // 32 x 128
   else if (kflat <= 64 && g.M >= 1024 && g.N <= 128 && g.N % 128 != 0) cfg = 2;   // token x tk products: N = 96 as 3 x 32
-  else if (!g.atomic && g.N % 96 == 0 && g.N % 128 != 0 && g.M >= 128 && kflat >= 64) cfg = 1;   // 128 x 96: no padded columns
+  else if (!g.atomic && g.N % 96 == 0 && g.N % 128 != 0 && g.M >= 128 && kflat >= 64)
+    cfg = (g.A.kmajor && g.M % 256 == 0 && kflat >= 1024) ? 5 : 1;   // 128 x 96: no padded columns; 256 x 96 (wave tile 64 x 96:
+                                                                     // 0.85 instead of 1.37 KB of LDS reads per MFMA) for the deep ones
   else if (kflat >= 1024 && !g.atomic) {
     if (tiles(128, 128) < 64) cfg = 4;                          // B x C gate GEMMs (M = 160): 8-16 big tiles leave the chip idle
     else if (g.M >= 96 && g.N >= 96) cfg = 0;                   // 128 x 128
@@ -685,7 +700,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     const bool fills = w0 >= 192 && (last == 0 || last >= 576 || w0 >= 6144);
     cfg = (kflat > 256 && g.M >= 128 && g.N >= 128 && fills && !g.atomic) ? 0 : 4;
   }
-  if (const char* e = getenv("DGSCT_GEMM_CFG")) { const int c = atoi(e); if (c >= 0 && c <= 4) cfg = c; }   // tuning hook
+  if (const char* e = getenv("DGSCT_GEMM_CFG")) { const int c = atoi(e); if (c >= 0 && c <= 5) cfg = c; }   // tuning hook
   if (rowwise) {
     if (g.M > 32 || g.R || g.atomic || g.splitk > 1 || g.bias_m || g.bias_n) {
       set_error("gemm: softmax epilogue needs M <= 32 and a plain, unsplit output");
@@ -693,7 +708,14 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     }
     cfg = 3;                                                      // 32 x 128: the softmax axis in one tile's registers
   }
-  static const int BMs[5] = {128, 128, 128, 32, 64}, BNs[5] = {128, 96, 32, 128, 64};
+  const int ak = g.A.kmajor, bk = g.B.kmajor;
+  // FAST staging: 16-byte chunks are aligned and never straddle a matrix edge or a frame of a two-level contraction
+  static const bool no_fast = getenv("DGSCT_GEMM_NOFAST") != nullptr;
+  const bool fast_ok = MODE == DT_BF16 && !no_fast && k.a_vec && k.b_vec && g.K % VE == 0 && (long)g.K * g.KB >= VE &&
+                    (ak || g.M % VE == 0) && (bk || g.N % VE == 0) && g.M >= VE && g.N >= VE;
+  const bool fast = fast_ok;
+  if (cfg >= 5 && !(MODE == DT_BF16 && fast_ok)) cfg = 1;        // big tiles exist for FAST bf16 only
+  static const int BMs[6] = {128, 128, 128, 32, 64, 256}, BNs[6] = {128, 96, 32, 128, 64, 96};
   k.tiles_m = (g.M + BMs[cfg] - 1) / BMs[cfg];
   k.tiles_n = (g.N + BNs[cfg] - 1) / BNs[cfg];
   int splitk = g.splitk;
@@ -709,22 +731,18 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   splitk = (k.kt_total + k.kt_per_split - 1) / k.kt_per_split;
   dim3 grid(k.tiles_m * k.tiles_n, g.batch, splitk);
   hipStream_t s = (hipStream_t)ctx.stream;
-  const int ak = g.A.kmajor, bk = g.B.kmajor;
   ProfRec shp{};
   shp.M = g.M; shp.N = g.N; shp.K = g.K; shp.KB = g.KB; shp.batch = g.batch; shp.splitk = splitk; shp.cfg = cfg;
   shp.ak = ak; shp.bk = bk; shp.atomic = g.atomic; shp.wide = k.wide;
   shp.bytes = ((double)g.M * g.K * g.KB * (g.A.bs ? g.batch : 1) + (double)g.N * g.K * g.KB * (g.B.bs ? g.batch : 1)) * ES +
               (double)g.M * g.N * g.batch * (g.ddt == DT_F32 ? 4 : 2) * (g.R ? 2 : 1);
   ProfRec* rec = prof_begin(s, 2.0 * g.M * g.N * (double)g.K * g.KB * g.batch, shp);
-  // FAST staging: 16-byte chunks are aligned and never straddle a matrix edge or a frame of a two-level contraction
-  static const bool no_fast = getenv("DGSCT_GEMM_NOFAST") != nullptr;
-  const bool fast = MODE == DT_BF16 && !no_fast && k.a_vec && k.b_vec && g.K % VE == 0 && (long)g.K * g.KB >= VE &&
-                    (ak || g.M % VE == 0) && (bk || g.N % VE == 0) && g.M >= VE && g.N >= VE;
   switch (cfg) {
     case 0: launch_cfg<MODE, 2, 2, 2, 2>(k, ak, bk, grid, s, fast); break;
     case 1: launch_cfg<MODE, 4, 1, 1, 3>(k, ak, bk, grid, s, fast); break;
     case 2: launch_cfg<MODE, 4, 1, 1, 1>(k, ak, bk, grid, s, fast); break;
     case 3: launch_cfg<MODE, 1, 4, 1, 1>(k, ak, bk, grid, s, fast); break;
+    case 5: if constexpr (MODE == DT_BF16) launch_lay<DT_BF16, 4, 1, 2, 3, true>(k, ak, bk, grid, s); break;   // 256 x 96
     default: launch_cfg<MODE, 2, 2, 1, 1>(k, ak, bk, grid, s, fast); break;
   }
   prof_end(rec, s);
