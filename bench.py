@@ -322,8 +322,29 @@ def main():
         for _ in range(nprof):
             eager_step()                 # eager launches: the library brackets each GEMM launch with HIP events
         torch.cuda.synchronize()
+        import csv
+        import tempfile
+        dump = os.path.join(tempfile.gettempdir(), f"dgsct_gemm_prof_{os.getpid()}.csv")
+        os.environ["DGSCT_PROF_DUMP"] = dump            # the library also writes one line per launch (shape, ms)
         launches, gemm_ms, gemm_flops = lib.prof_collect()
+        os.environ.pop("DGSCT_PROF_DUMP", None)
         lib.prof_enable(False)
+        heaviest = None
+        try:                                            # the single heaviest launch shape of the family (by time)
+            by_shape = {}
+            for r in csv.DictReader(open(dump)):
+                key = (r["M"], r["N"], r["K"], r["KB"], r["batch"], r["ak"], r["bk"], r["atomic"])
+                a = by_shape.setdefault(key, [0, 0.0, 0.0])
+                a[0] += 1; a[1] += float(r["ms"]); a[2] += float(r["flops"])
+            key, (cnt, ms, fl) = max(by_shape.items(), key=lambda kv: kv[1][1])
+            heaviest = dict(shape=dict(M=int(key[0]), N=int(key[1]), K=int(key[2]), K_frames=int(key[3]), batch=int(key[4]),
+                                       a_kmajor=int(key[5]), b_kmajor=int(key[6]), split_k_atomic=int(key[7])),
+                            launches_per_step=cnt // nprof, avg_launch_us=round(ms / cnt * 1e3, 1),
+                            achieved=round(fl / (ms * 1e-3) / 1e12, 1), frac=round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4),
+                            share_of_gemm_time=round(ms / gemm_ms, 3))
+            os.remove(dump)
+        except Exception:
+            pass
         stack.concurrent, _ops.USE_AUX_STREAM = conc, aux
         alg = 3.0 * alg_flops_per_frame(stages) * BT                 # fwd + bwd, per step
         peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -339,7 +360,7 @@ def main():
                         alg_bytes_per_launch=round(alg_bytes_per_step(stages, BT) / max(launches // nprof, 1)), kernel="dgsct::gemm_kernel<*> (all MFMA GEMM launches of a step)",
                         launches_per_step=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
-                        gemm_ms_per_step=round(gemm_ms / nprof, 3),
+                        gemm_ms_per_step=round(gemm_ms / nprof, 3), heaviest_launch=heaviest,
                         step_frac_of_mfma_peak=round(alg / (ms_per_step * 1e-3) / 1e12 / peak, 4))
     if dp:
         barrier()

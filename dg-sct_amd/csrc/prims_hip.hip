@@ -255,7 +255,10 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
   }
   float tsum = 0.f;
   uint4 pg[MAXNV], px[MAXNV];
+  float psg = 0.f, pmean = 0.f, prs = 1.f;              // per-row scalars travel with the row prefetch (see tail_bwd_k)
   auto fetch = [&](long row) {
+    psg = sg[row];
+    if (lnw) { pmean = mu[row]; prs = rstd[row]; }
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
@@ -265,10 +268,10 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
   if (blockIdx.x * rpc + sub < n_end) fetch((long)b * N + blockIdx.x * rpc + sub);
   for (int n = blockIdx.x * rpc + sub; n < n_end; n += rpp) {
     const long row = (long)b * N + n;
-    const float sgv = beta * sg[row];
+    const float sgv = beta * psg;
     float g[MAXNV][VE], x1[MAXNV][VE], xh[MAXNV][VE];
     float s1 = 0.f, s2 = 0.f;
-    const float mean = lnw ? mu[row] : 0.f, rs = lnw ? rstd[row] : 1.f;
+    const float mean = pmean, rs = prs;
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
@@ -451,8 +454,12 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
   }
   float gsum = 0.f;
   // software pipeline: the next row's two 16-byte loads are in flight while this row is reduced and stored
+  // The row statistics are fetched WITH the row: vmcnt retires in order, so a scalar load issued after the prefetch of
+  // the next row would force a wait for that prefetch as well (hipcc emitted s_waitcnt vmcnt(0) right behind it).
   uint4 pg[MAXNV], pop[MAXNV];
+  float pmean = 0.f, prs = 1.f;
   auto fetch = [&](long row) {
+    if (lnw) { pmean = mu[row]; prs = rstd[row]; }
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
@@ -467,8 +474,8 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
       const int col = (v * gs + gl) * VE;
       if (v < nv && col < C) { unpack<DT, VE>(pg[v], g[v]); unpack<DT, VE>(pop[v], op[v]); }
     }
+    const float mean = pmean, rs = prs;
     if (row + rpp < r_end) fetch(row + rpp);
-    const float mean = lnw ? mu[row] : 0.f, rs = lnw ? rstd[row] : 1.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
