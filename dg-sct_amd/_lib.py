@@ -87,7 +87,7 @@ class Lib:
                                              C.c_void_p, C.c_void_p]
         c.dgsct_adapter_backward_ex.argtypes = c.dgsct_adapter_backward.argtypes + [C.c_void_p, C.c_int]
         fa = list(c.dgsct_adapter_forward.argtypes)
-        c.dgsct_adapter_forward_ex.argtypes = fa[:5] + [C.c_void_p] + fa[5:]
+        c.dgsct_adapter_forward_ex.argtypes = fa[:5] + [C.c_void_p] + fa[5:] + [C.c_void_p]
         c.dgsct_saved_region.argtypes = [C.POINTER(AdapterDesc), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]
         c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
@@ -116,9 +116,9 @@ class Lib:
     def prepare(self, desc, ptrs, prep: int, stream: int):
         self._check(self.c.dgsct_prepare(C.byref(desc), C.cast(ptrs, _PP), prep, stream), "dgsct_prepare")
 
-    def forward(self, desc, ptrs, prep, X, Y, out, amap, tmap, saved, ws, stream, residual=None):
+    def forward(self, desc, ptrs, prep, X, Y, out, amap, tmap, saved, ws, stream, residual=None, aux_stream=None):
         self._check(self.c.dgsct_adapter_forward_ex(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, residual, out, amap, tmap,
-                                                    saved, ws, stream), "dgsct_adapter_forward")
+                                                    saved, ws, stream, aux_stream), "dgsct_adapter_forward")
 
     def backward(self, desc, ptrs, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream=None,
                  skip_into_dx=False):

@@ -53,7 +53,7 @@ int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, 
 
 int dgsct_adapter_forward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
                              const void* Y, const void* residual, void* out, float* map, float* tmap, void* saved, void* ws,
-                             void* stream) {
+                             void* stream, void* aux_stream) {
   clear_error();
   if (!desc || !params || !prep || !X || !Y || !out || !map || !saved || !ws) {
     set_error("dgsct_adapter_forward_ex: NULL argument");
@@ -65,7 +65,7 @@ int dgsct_adapter_forward_ex(const dgsct_adapter_desc* desc, float* const* param
   }
   Plan p(*desc);
   if (!p.ok) return 2;
-  return p.forward(params, prep, X, Y, out, map, tmap, saved, ws, stream, residual);
+  return p.forward(params, prep, X, Y, out, map, tmap, saved, ws, stream, residual, aux_stream);
 }
 
 int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,

@@ -278,9 +278,14 @@ int Plan::prepare(float* const* params, void* prep, void* stream) const {
 
 // ------------------------------------------------------------------------------------------------
 int Plan::forward(float* const* params, const void* prep, const void* X, const void* Y, void* out, float* map,
-                  float* tmap, void* saved, void* ws, void* stream, const void* residual) const {
+                  float* tmap, void* saved, void* ws, void* stream, const void* residual, void* aux_stream) const {
   Bound b(*this, params, prep, saved, ws, stream);
+  b.ctx.aux = aux_stream;
   const Ctx& ctx = b.ctx;
+  // The audio-query branch (a = mean_N Yp -> aq1, aq2) depends on Yp only: on the aux stream it runs beside the two
+  // token attentions instead of extending the chain by four small launches.
+  Ctx side = ctx;
+  if (aux_stream) { side.stream = aux_stream; side.aux = nullptr; }
   const float invN = 1.f / (float)N;
   zero(ctx, b.S(0), (size_t)s.zero_end);
 
@@ -311,6 +316,19 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     outE(g2, Yp, E, C, (long)N * C);
     gemm(ctx, g2);
   }
+  {
+    stream_fork(ctx);                                            // Yp is complete on the main stream
+    colsum_batched(side, Yp, C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.a), C);  // a = mean_N(Yp)
+    cvt(side, b.S<float>(s.a), b.S(s.aE), E, (long)B * C);
+    Gemm g1 = mk(B, C, C);                                       // aq1 = relu(a Wa1^T + b)
+    g1.A = km(b.S(s.aE), C); g1.B = km(b.W(DGSCT_P_WA1), C); g1.bias_n = b.F(DGSCT_P_BA1); g1.act = ACT_RELU;
+    outE(g1, b.S(s.aq1), E, C);
+    gemm(side, g1);
+    Gemm g2 = mk(B, dd, C);                                      // aq2 = relu(a Wa2^T + b)
+    g2.A = km(b.S(s.aE), C); g2.B = km(b.W(DGSCT_P_WA2), C); g2.bias_n = b.F(DGSCT_P_BA2); g2.act = ACT_RELU;
+    outE(g2, b.S(s.aq2), E, dd);
+    gemm(side, g2);
+  }
   // F2 ---- latent tokens attend to the remapped tokens                  :572-580, :592
   {
     Gemm g1 = mk(tk, N, C, B);                                   // S1 = T0 . Yp^T
@@ -325,8 +343,6 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     resid(g2, b.W(DGSCT_P_TOKENS), E, C, 0);
     outE(g2, b.S(s.tok), E, C, (long)tk * C);
     gemm(ctx, g2);
-    colsum_batched(ctx, Yp, C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.a), C);   // a = mean_N(Yp)
-    cvt(ctx, b.S<float>(s.a), b.S(s.aE), E, (long)B * C);
   }
   // F3 ---- X attends to the latent tokens                               :583-589
   {
@@ -355,19 +371,12 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   }
   // F4-F6 ---- channel gate                                              :593-598
   {
-    Gemm g1 = mk(B, C, C);                                       // aq1 = relu(a Wa1^T + b)
-    g1.A = km(b.S(s.aE), C); g1.B = km(b.W(DGSCT_P_WA1), C); g1.bias_n = b.F(DGSCT_P_BA1); g1.act = ACT_RELU;
-    outE(g1, b.S(s.aq1), E, C);
-    gemm(ctx, g1);
-    Gemm g2 = mk(B, dd, C);                                      // aq2 = relu(a Wa2^T + b)
-    g2.A = km(b.S(s.aE), C); g2.B = km(b.W(DGSCT_P_WA2), C); g2.bias_n = b.F(DGSCT_P_BA2); g2.act = ACT_RELU;
-    outE(g2, b.S(s.aq2), E, dd);
-    gemm(ctx, g2);
     Gemm g3 = mk((int)R, C, C);                                  // vq1 = relu(X1 Wv1^T + b)
     g3.A = km(b.S(s.X1), C); g3.B = km(b.W(DGSCT_P_WV1), C); g3.bias_n = b.F(DGSCT_P_BV1); g3.act = ACT_RELU;
     outE(g3, b.S(s.vq1), E, C);
     gemm(ctx, g3);
     colsum_batched(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C);
+    stream_join(ctx);                                            // aq1 / aq2 / a from the aux stream
     ew(ctx, EW_MUL, b.S(s.m1), E, Earg(b.S(s.aq1), E), F32(b.S(s.mvq1)), NOARG, (long)B * C, 0.f, 1);
     Gemm g4 = mk(B, dd, C);                                      // q = relu(m1 Wb^T + b)
     g4.A = km(b.S(s.m1), C); g4.B = km(b.W(DGSCT_P_WB), C); g4.bias_n = b.F(DGSCT_P_BB); g4.act = ACT_RELU;
@@ -532,7 +541,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                 b.Wk<float>(wb.dsl), G(DGSCT_P_BS));
     colsum_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd);  // u
     ew(ctx, EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1);
-    sum_batch(ctx, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 1);                 // dws
+    side_begin();
+    sum_batch(side, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 1);                // dws (a gradient: off the chain)
     ew(ctx, EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd);
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
     relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
@@ -559,7 +569,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g1, G(DGSCT_P_WCATT), dd);
     side_begin();
     gemm(side, g1);
-    colsum_batched(ctx, b.Wk(wb.dpre_c), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BCATT), 0);
+    colsum_batched(side, b.Wk(wb.dpre_c), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BCATT), 0);
     Gemm g2 = mk(B, dd, C);                                      // dq = (dpre . Wcatt) * (q > 0)
     g2.A = km(b.Wk(wb.dpre_c), C); g2.B = mn(b.W(DGSCT_P_WCATT), dd);
     g2.mask = b.S(s.q); g2.ldmask = dd;
@@ -570,7 +580,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g3, G(DGSCT_P_WB), C);
     side_begin();
     gemm(side, g3);
-    colsum_batched(ctx, b.Wk(wb.dq), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BB), 0);
+    colsum_batched(side, b.Wk(wb.dq), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BB), 0);
     Gemm g4 = mk(B, C, dd);                                      // dm1 = dq . Wb
     g4.A = km(b.Wk(wb.dq), dd); g4.B = mn(b.W(DGSCT_P_WB), C);
     outF(g4, b.Wk<float>(wb.dm1), C);
@@ -601,13 +611,13 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g1, G(DGSCT_P_WA1), C);
     side_begin();
     gemm(side, g1);
-    colsum_batched(ctx, b.Wk(wb.dpa1), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BA1), 0);
+    colsum_batched(side, b.Wk(wb.dpa1), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BA1), 0);
     Gemm g2 = mk(dd, C, B);                                      // dWa2 = dpa2^T . a
     g2.A = mn(b.Wk(wb.dpa2), dd); g2.B = mn(b.S(s.aE), C);
     outF(g2, G(DGSCT_P_WA2), C);
     side_begin();
     gemm(side, g2);
-    colsum_batched(ctx, b.Wk(wb.dpa2), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BA2), 0);
+    colsum_batched(side, b.Wk(wb.dpa2), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BA2), 0);
     Gemm g3 = mk(B, C, C);                                       // da = dpa1 . Wa1 + dpa2 . Wa2
     g3.A = km(b.Wk(wb.dpa1), C); g3.B = mn(b.W(DGSCT_P_WA1), C);
     outF(g3, b.Wk<float>(wb.da), C);
@@ -690,7 +700,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     resid(g2, b.Wk(wb.dtokF), DT_F32, C, (long)tk * C);
     outF(g2, b.Wk<float>(wb.dtokF), C, (long)tk * C);
     gemm(ctx, g2);
-    sum_batch(ctx, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
+    side_begin();
+    sum_batch(side, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
     ew(ctx, EW_SCALE, b.Wk(wb.daN), DT_F32, F32(b.Wk(wb.da)), NOARG, NOARG, (long)B * C, 1.f / (float)N, 1);
     Gemm g3 = mk(N, C, tk, B);                                   // dYp = P1^T . dtok + da/N
     g3.A = mn(b.S(s.P1), Np, (long)tk * Np);
@@ -708,12 +719,13 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B1 ---- remap
   {
     const bool conv = d.remap == DGSCT_REMAP_CONV;
+    side_begin();                                                // bias gradients of the remap: gradients only -> aux stream
     if (conv) {
-      rowdot_batched(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
-      sum_batch(ctx, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                             // dbn
-      colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);    // d rowsum(Wc)
+      rowdot_batched(side, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
+      sum_batch(side, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                            // dbn
+      colsum_batched(side, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);   // d rowsum(Wc)
     } else {
-      colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);
+      colsum_batched(side, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);
     }
     if (orderA) {
       Gemm g1 = mk((int)R, Co, C);                               // dT1 = dYp . Wc

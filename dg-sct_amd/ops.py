@@ -168,7 +168,7 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
     ws = _workspace(dev, stream, int(sz.ws_fwd_bytes))
     lib.forward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), out.data_ptr(), amap.data_ptr(),
                 tmap.data_ptr() if tmap is not None else None, saved.data_ptr(), ws.data_ptr(), stream,
-                residual.data_ptr() if residual is not None else None)
+                residual.data_ptr() if residual is not None else None, _aux_stream(lib, X, stream))
     return out, amap, tmap, saved, d
 
 

@@ -126,10 +126,12 @@ int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, 
 /* Same, with the caller's residual add fused into the last kernel (reference call sites
  * net_trans.py:894-898,903-906: `f = f + adapter(...)[0].squeeze(-1).permute(0,2,1)`):
  *   out = residual + adapter(X, Y)        residual [BT][N][C] (dtype), may alias X (identity / pre-block skip).
- * residual == NULL is dgsct_adapter_forward. */
+ * aux_stream (optional, any other stream of the device): the audio-query branch (a = mean_N Yp, aq1, aq2), which depends
+ * on Yp only, runs on it beside the two token attentions; the call forks from and joins back into `stream`.
+ * residual == NULL and aux_stream == NULL is dgsct_adapter_forward. */
 int dgsct_adapter_forward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep,
                              const void* X, const void* Y, const void* residual, void* out, float* map, float* tmap,
-                             void* saved, void* ws, void* stream);
+                             void* saved, void* ws, void* stream, void* aux_stream);
 
 /* dOut [BT][N][C] (dtype); dMap [BT][N] fp32 or NULL; dTmap [BT] fp32 or NULL.
  * Writes dX [BT][N][C], dY [BT][No][Co] (dtype) and the flat fp32 gradient buffer `grads`
