@@ -396,8 +396,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     gemm(ctx, g1);
     rowdot_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.S(s.aq2), E, dd, b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
                    b.S<float>(s.sl));
-    spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map));
-    ew(ctx, EW_COPY, map, DT_F32, F32(b.S(s.map)), NOARG, NOARG, R, 0.f, 1);
+    spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map), map);   // saved copy + the returned map
     if (d.temporal) {
       temporal_fwd(ctx, b.S<float>(s.a), b.F(DGSCT_P_WT), b.F(DGSCT_P_BT), B, C, b.S<float>(s.tg));
       if (tmap) ew(ctx, EW_COPY, tmap, DT_F32, F32(b.S(s.tg)), NOARG, NOARG, B, 0.f, 1);
@@ -662,7 +661,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     resid(g2, dX1, E, C, (long)N * C);
     if (skip_into_dx) g2.R2 = dOut;                              // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
     outE(g2, dX, E, C, (long)N * C);
-    gemm(ctx, g2);
+    side_begin();                                                // dX is an OUTPUT: nothing below reads it, and dX1 / dS2 / tok
+    gemm(side, g2);                                              // are not written again -> aux stream, off the chain
     Gemm g3 = mk(tk, C, N, B);                                   // dtok = gate_av * P2^T . dX1
     g3.A = mn(b.S(s.P2), tkp, (long)N * tkp);
     g3.B = mn(dX1, C, (long)N * C);

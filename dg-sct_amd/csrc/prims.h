@@ -100,7 +100,7 @@ void relu_bwd_scale(const Ctx&, const void* x, void* y, int B, int N, int C, con
 void xc_bwd(const Ctx&, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch);
 
 // sg = sigmoid(sl); map = softmax_N(tanh(sl))                [B][N] fp32
-void spatial_fwd(const Ctx&, const float* sl, int B, int N, float* sg, float* map);
+void spatial_fwd(const Ctx&, const float* sl, int B, int N, float* sg, float* map, float* map2 = nullptr);   // map2: second copy (the returned map)
 // dsl = dsg*sg*(1-sg) + [dMap] map*(dMap - sum map*dMap)*(1 - tanh(sl)^2);  *dbs += sum dsl
 void spatial_bwd(const Ctx&, const float* sl, const float* sg, const float* map, const float* dsg, const float* dMap,
                  int B, int N, float* dsl, float* dbs);

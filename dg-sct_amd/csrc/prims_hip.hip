@@ -721,7 +721,7 @@ void softmax_bwd_rows(const Ctx& ctx, const void* P, long ldp, const float* dP, 
 // ================================================================================================
 // spatial gate                                                 (reference net_trans.py:604-608)
 // ================================================================================================
-__global__ __launch_bounds__(256) void spatial_fwd_k(const float* sl, int N, float* sg, float* map) {
+__global__ __launch_bounds__(256) void spatial_fwd_k(const float* sl, int N, float* sg, float* map, float* map2) {
   __shared__ float red[4];
   const long o = (long)blockIdx.x * N;
   float m = -INFINITY;
@@ -734,11 +734,13 @@ __global__ __launch_bounds__(256) void spatial_fwd_k(const float* sl, int N, flo
   for (int n = threadIdx.x; n < N; n += 256) {
     const float v = sl[o + n];
     sg[o + n] = sigmoidf_(v);
-    map[o + n] = __expf(tanhf(v) - m) * inv;
+    const float mv = __expf(tanhf(v) - m) * inv;
+    map[o + n] = mv;
+    if (map2) map2[o + n] = mv;
   }
 }
-void spatial_fwd(const Ctx& ctx, const float* sl, int B, int N, float* sg, float* map) {
-  hipLaunchKernelGGL(spatial_fwd_k, dim3(B), dim3(256), 0, STREAM(ctx), sl, N, sg, map);
+void spatial_fwd(const Ctx& ctx, const float* sl, int B, int N, float* sg, float* map, float* map2) {
+  hipLaunchKernelGGL(spatial_fwd_k, dim3(B), dim3(256), 0, STREAM(ctx), sl, N, sg, map, map2);
 }
 __global__ __launch_bounds__(256) void spatial_bwd_k(const float* sl, const float* sg, const float* map, const float* dsg,
                                                      const float* dMap, int N, float* dsl, float* dbs) {

@@ -197,7 +197,7 @@ void xc_bwd(const Ctx& ctx, const void* dXc, const void* X1, void* dX1, int B, i
     }
 }
 
-void spatial_fwd(const Ctx&, const float* sl, int B, int N, float* sg, float* map) {
+void spatial_fwd(const Ctx&, const float* sl, int B, int N, float* sg, float* map, float* map2) {
   for (int b = 0; b < B; ++b) {
     const float* x = sl + (long)b * N;
     float m = -INFINITY;
@@ -207,6 +207,7 @@ void spatial_fwd(const Ctx&, const float* sl, int B, int N, float* sg, float* ma
     for (int n = 0; n < N; ++n) {
       sg[(long)b * N + n] = sigm(x[n]);
       map[(long)b * N + n] = (float)(std::exp(std::tanh(x[n]) - m) / s);
+      if (map2) map2[(long)b * N + n] = map[(long)b * N + n];
     }
   }
 }
