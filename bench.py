@@ -324,10 +324,12 @@ def main():
         torch.cuda.synchronize()
         import csv
         import tempfile
-        dump = os.path.join(tempfile.gettempdir(), f"dgsct_gemm_prof_{os.getpid()}.csv")
+        keep_dump = "DGSCT_PROF_DUMP" in os.environ       # (kept when the caller asked for the per-launch log)
+        dump = os.environ.get("DGSCT_PROF_DUMP") or os.path.join(tempfile.gettempdir(), f"dgsct_gemm_prof_{os.getpid()}.csv")
         os.environ["DGSCT_PROF_DUMP"] = dump            # the library also writes one line per launch (shape, ms)
         launches, gemm_ms, gemm_flops = lib.prof_collect()
-        os.environ.pop("DGSCT_PROF_DUMP", None)
+        if not keep_dump:
+            os.environ.pop("DGSCT_PROF_DUMP", None)
         lib.prof_enable(False)
         heaviest = None
         try:                                            # the single heaviest launch shape of the family (by time)
@@ -342,7 +344,8 @@ def main():
                             launches_per_step=cnt // nprof, avg_launch_us=round(ms / cnt * 1e3, 1),
                             achieved=round(fl / (ms * 1e-3) / 1e12, 1), frac=round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4),
                             share_of_gemm_time=round(ms / gemm_ms, 3))
-            os.remove(dump)
+            if not keep_dump:
+                os.remove(dump)
         except Exception:
             pass
         stack.concurrent, _ops.USE_AUX_STREAM = conc, aux

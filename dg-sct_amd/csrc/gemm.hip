@@ -685,7 +685,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   if (g.N <= 32) cfg = 2;                                       // 128 x 32
   else if (g.M <= 32) cfg = 3;                                  // 32 x 128
   else if (kflat <= 64 && g.M >= 1024 && g.N <= 128 && g.N % 128 != 0) cfg = 2;   // token x tk products: N = 96 as 3 x 32
-  else if (!g.atomic && g.N % 96 == 0 && g.N % 128 != 0 && g.M >= 128 && kflat >= 64)
+  else if (!g.atomic && g.N % 96 == 0 && g.N % 128 != 0 && g.M >= 128 && kflat >= 64 && tiles(128, 96) >= 256)
     cfg = (g.A.kmajor && g.M % 256 == 0 && kflat >= 1024) ? 5 : 1;   // 128 x 96: no padded columns; 256 x 96 (wave tile 64 x 96:
                                                                      // 0.85 instead of 1.37 KB of LDS reads per MFMA) for the deep ones
   else if (kflat >= 1024 && !g.atomic) {
