@@ -211,6 +211,73 @@ __device__ __forceinline__ void stage_store_fast(const uint4 (&reg)[NLD_], char*
   }
 }
 
+// ---- LDS-DMA staging (STAGE 2: bf16, FAST conditions + K a multiple of the 64-deep k-tile) ---------------------------
+// `global_load_lds_dwordx4` writes 64 lanes x 16 B = 1 KiB CONTIGUOUS bytes of LDS per wave instruction (wave-uniform
+// base + lane*16), the global source address is per lane.  So the LDS image is dense (no padding) and bank conflicts
+// are avoided by choosing WHICH global chunk each lane fetches (swizzle on the source side):
+//  * K-major tile [ROWS][64 k] = 128-byte rows, 8 chunks: chunk c of row r lives at slot c ^ ((r >> 1) & 7).  A 16-lane
+//    ds_read_b128 group reads 16 consecutive rows of one k-chunk: row parity picks the 128-byte half of the 256-byte bank
+//    line and (r >> 1) & 7 the slot -> 16 distinct 16-byte slots, conflict-free.
+//  * MN-major tile [64 k][ROWS] = ROWS*2-byte k-rows: a transpose-read group touches 4 consecutive k-rows x 32 B; with a
+//    192-byte (ROWS = 96) or 64-byte (32) pitch those fall on different bank granules already, for 128 / 256 / 512-byte
+//    pitches chunk rc of k-row k lives at slot rc ^ (2 * (k & 3)).
+// No staging registers, no ds_write pass; the tile needs no edge masking because row reads are clamped (garbage rows
+// only feed accumulators that are never stored) and K is a whole number of k-tiles.
+template <bool KM, int ROWS>
+struct GldsGeom {
+  static constexpr int CPR = KM ? 8 : ROWS / 8;          // 16-byte chunks per LDS row
+  static constexpr int NSLOT = ROWS * 8;
+  static constexpr int NI = NSLOT / 256;                 // DMA instructions per thread
+  static constexpr int LDS_BYTES = NSLOT * 16;
+  static constexpr bool SWZ_MN = !(ROWS == 32 || ROWS == 96);
+  static_assert(NSLOT % 256 == 0, "tile must be a whole number of 4-wave DMA rounds");
+};
+template <bool KM, int ROWS>
+__device__ __forceinline__ void glds_tile(char* lds, const char* base, long ld, long kbs, int r0, int rows_total, int kf0, int K,
+                                          unsigned kinv, int wave, int lane) {
+  using G = GldsGeom<KM, ROWS>;
+#pragma unroll
+  for (int j = 0; j < G::NI; ++j) {
+    const int sbase = (j * 4 + wave) * 64;               // wave-uniform slot base
+    const int s = sbase + lane;
+    const int q = s / G::CPR, cpos = s % G::CPR;
+    int rg, kf;
+    if (KM) {
+      const int c = cpos ^ ((q >> 1) & 7);
+      rg = r0 + q; rg = rg < rows_total ? rg : rows_total - 1;
+      kf = kf0 + c * 8;
+    } else {
+      const int rc = G::SWZ_MN ? (cpos ^ (2 * (q & 3))) : cpos;
+      rg = r0 + rc * 8; rg = rg < rows_total ? rg : rows_total - 8;
+      kf = kf0 + q;
+    }
+    const int kb = (int)__umulhi((unsigned)kf, kinv);
+    const int kk = kf - kb * K;
+    const char* gp = base + ((long)kb * kbs + (KM ? (long)rg * ld + kk : (long)kk * ld + rg)) * 2;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                     (__attribute__((address_space(3))) void*)(lds + sbase * 16), 16, 0, 0);
+  }
+}
+template <bool KM, int ROWS>
+__device__ __forceinline__ bf16x8_t frag_glds(const char* lds, int row0, int kk, int lane) {
+  using G = GldsGeom<KM, ROWS>;
+  if (KM) {
+    const int row = row0 + (lane & 31);
+    const int cc = kk * 2 + (lane >> 5);
+    return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + ((cc ^ ((row >> 1) & 7)) * 16));
+  } else {
+    constexpr int PITCH = ROWS * 2;
+    const int kbase = kk * 16 + (lane >> 5) * 8 + ((lane & 15) >> 2);
+    const int r = row0 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const int sw = G::SWZ_MN ? 2 * (kbase & 3) : 0;       // (kbase + 4) & 3 == kbase & 3: same swizzle for both reads
+    const char* p0 = lds + kbase * PITCH + (((r >> 3) ^ sw) * 16) + (r & 7) * 2;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * PITCH));
+    s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
 // ---- LDS -> MFMA fragment (bf16) ---------------------------------------------------------------
 // 32x32x16 operand fragment: lane l holds X[row = l&31][k = 8*(l>>5) .. +7] of the 16-deep k-step kk.
 template <bool KM, int ROWS>
@@ -237,19 +304,23 @@ __device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row0, int kk,
 
 // Occupancy: 3 workgroups per CU (168 VGPRs) everywhere except the 128x128 tile with one K-major and one MN-major
 // operand, whose two address streams + two prefetch sets + 64 accumulators need ~200 registers (spilled 120 at 168).
-template <int MODE, bool AK, bool BK, int WGM, int WGN, int TM, int TN, bool FAST>
-__global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : ((TM * TN >= 6 || (TM * TN == 4 && AK != BK)) ? 2 : 3))
+// STAGE: 0 = guarded generic staging, 1 = FAST register staging, 2 = LDS-DMA staging (glds)
+template <int MODE, bool AK, bool BK, int WGM, int WGN, int TM, int TN, int STAGE>
+__global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : ((TM * TN >= 6 || (STAGE != 2 && TM * TN == 4 && AK != BK)) ? 2 : 3))
 void gemm_kernel(const GemmK p) {
+  constexpr bool FAST = STAGE == 1;
+  constexpr bool GLDS = STAGE == 2;
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   using GA = TileGeom<MODE, AK, BM>;
   using GB = TileGeom<MODE, BK, BN>;
   constexpr int BKT = GA::BKT;
   constexpr int ES = GA::ES;
   constexpr int STG_BYTES = 4 * 32 * (TN * 32 + 4) * 4;      // wide-epilogue staging, 4 waves
-  constexpr int OPND_BYTES = GA::LDS_BYTES + GB::LDS_BYTES;
+  constexpr int A_BYTES = GLDS ? GldsGeom<AK, BM>::LDS_BYTES : GA::LDS_BYTES;
+  constexpr int OPND_BYTES = A_BYTES + (GLDS ? GldsGeom<BK, BN>::LDS_BYTES : GB::LDS_BYTES);
   __shared__ __attribute__((aligned(16))) char smem[OPND_BYTES > STG_BYTES ? OPND_BYTES : STG_BYTES];
   char* ldsA = smem;
-  char* ldsB = smem + GA::LDS_BYTES;
+  char* ldsB = smem + A_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -291,9 +362,11 @@ void gemm_kernel(const GemmK p) {
       for (int kk = 0; kk < BKT / 16; ++kk) {
         bf16x8_t af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = frag_bf16<AK, BM>(ldsA, (wm * TM + i) * 32, kk, lane);
+        for (int i = 0; i < TM; ++i)
+          af[i] = GLDS ? frag_glds<AK, BM>(ldsA, (wm * TM + i) * 32, kk, lane) : frag_bf16<AK, BM>(ldsA, (wm * TM + i) * 32, kk, lane);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = frag_bf16<BK, BN>(ldsB, (wn * TN + j) * 32, kk, lane);
+        for (int j = 0; j < TN; ++j)
+          bf[j] = GLDS ? frag_glds<BK, BN>(ldsB, (wn * TN + j) * 32, kk, lane) : frag_bf16<BK, BN>(ldsB, (wn * TN + j) * 32, kk, lane);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -340,6 +413,18 @@ void gemm_kernel(const GemmK p) {
       stage_store<MODE, BK, BN>(RB, ldsB, tid);                                                                        \
     }                                                                                                                  \
   } while (0)
+  if constexpr (GLDS) {
+    // one LDS buffer, two barriers per k-tile: the DMA of a workgroup is not overlapped with its own MFMAs -- the 3-4
+    // resident workgroups of the CU overlap each other
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      __syncthreads();                     // previous tile's fragment reads are done
+      glds_tile<AK, BM>(ldsA, Ab, p.lda, p.a_kbs, m0, p.M, kt * BKT, p.K, p.kinv, wave, lane);
+      glds_tile<BK, BN>(ldsB, Bb, p.ldb, p.b_kbs, n0, p.N, kt * BKT, p.K, p.kinv, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute();
+    }
+  } else {
   constexpr bool ONE_SET = TM * TN >= 6 && TM * TN < 8;   // 256 x 96: two sets (88 VGPRs) + 96 accumulators spill at 2 WG/CU
   if constexpr (ONE_SET) {
     if (kt_begin < kt_end) DGSCT_PREFETCH(ra0, rb0, kt_begin);
@@ -366,6 +451,7 @@ void gemm_kernel(const GemmK p) {
       if (kt + 3 < kt_end) DGSCT_PREFETCH(ra1, rb1, kt + 3);
       compute();
     }
+  }
   }
   }
 #undef DGSCT_PREFETCH
@@ -624,19 +710,21 @@ void gemm_prof_collect(long* launches, double* total_ms, double* total_flops) {
   if (total_flops) *total_flops = fl;
 }
 
-template <int MODE, int WGM, int WGN, int TM, int TN, bool FAST>
+template <int MODE, int WGM, int WGN, int TM, int TN, int STAGE>
 static void launch_lay(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s) {
-  if (ak && bk)       hipLaunchKernelGGL((gemm_kernel<MODE, true, true, WGM, WGN, TM, TN, FAST>), grid, dim3(256), 0, s, k);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<MODE, true, false, WGM, WGN, TM, TN, FAST>), grid, dim3(256), 0, s, k);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<MODE, false, true, WGM, WGN, TM, TN, FAST>), grid, dim3(256), 0, s, k);
-  else                hipLaunchKernelGGL((gemm_kernel<MODE, false, false, WGM, WGN, TM, TN, FAST>), grid, dim3(256), 0, s, k);
+  if (ak && bk)       hipLaunchKernelGGL((gemm_kernel<MODE, true, true, WGM, WGN, TM, TN, STAGE>), grid, dim3(256), 0, s, k);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<MODE, true, false, WGM, WGN, TM, TN, STAGE>), grid, dim3(256), 0, s, k);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<MODE, false, true, WGM, WGN, TM, TN, STAGE>), grid, dim3(256), 0, s, k);
+  else                hipLaunchKernelGGL((gemm_kernel<MODE, false, false, WGM, WGN, TM, TN, STAGE>), grid, dim3(256), 0, s, k);
 }
+// stage: 0 generic, 1 FAST, 2 glds
 template <int MODE, int WGM, int WGN, int TM, int TN>
-static void launch_cfg(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s, bool fast) {
+static void launch_cfg(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s, int stage) {
   if constexpr (MODE == DT_BF16) {
-    if (fast) { launch_lay<MODE, WGM, WGN, TM, TN, true>(k, ak, bk, grid, s); return; }
+    if (stage == 2) { launch_lay<MODE, WGM, WGN, TM, TN, 2>(k, ak, bk, grid, s); return; }
+    if (stage == 1) { launch_lay<MODE, WGM, WGN, TM, TN, 1>(k, ak, bk, grid, s); return; }
   }
-  launch_lay<MODE, WGM, WGN, TM, TN, false>(k, ak, bk, grid, s);
+  launch_lay<MODE, WGM, WGN, TM, TN, 0>(k, ak, bk, grid, s);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -713,7 +801,13 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   static const bool no_fast = getenv("DGSCT_GEMM_NOFAST") != nullptr;
   const bool fast_ok = MODE == DT_BF16 && !no_fast && k.a_vec && k.b_vec && g.K % VE == 0 && (long)g.K * g.KB >= VE &&
                     (ak || g.M % VE == 0) && (bk || g.N % VE == 0) && g.M >= VE && g.N >= VE;
-  const bool fast = fast_ok;
+  // LDS-DMA staging (DGSCT_GEMM_GLDS=1: every eligible GEMM, =2: contractions >= 512 deep).  Measured on MI355X: -12 % on
+  // the two-level / MN-major remap GEMMs in isolation (tools/gemm_bench.py), 688 vs 730 TFLOP/s at 4096^3, and no
+  // difference on the whole step (77.1 / 77.6 / 76.8 ms off / deep-only / all) -- with 3 workgroups per CU the
+  // two-deep register prefetch already hides the staging, so it stays off by default.
+  static const int glds_mode = getenv("DGSCT_GEMM_GLDS") ? atoi(getenv("DGSCT_GEMM_GLDS")) : 0;
+  const bool glds_ok = fast_ok && kflat % BKT == 0 && (glds_mode == 1 || (glds_mode == 2 && kflat >= 512));
+  const int fast = glds_ok ? 2 : (fast_ok ? 1 : 0);
   if (cfg >= 5 && !(MODE == DT_BF16 && fast_ok)) cfg = 1;        // big tiles exist for FAST bf16 only
   static const int BMs[6] = {128, 128, 128, 32, 64, 256}, BNs[6] = {128, 96, 32, 128, 64, 96};
   k.tiles_m = (g.M + BMs[cfg] - 1) / BMs[cfg];
@@ -742,7 +836,10 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     case 1: launch_cfg<MODE, 4, 1, 1, 3>(k, ak, bk, grid, s, fast); break;
     case 2: launch_cfg<MODE, 4, 1, 1, 1>(k, ak, bk, grid, s, fast); break;
     case 3: launch_cfg<MODE, 1, 4, 1, 1>(k, ak, bk, grid, s, fast); break;
-    case 5: if constexpr (MODE == DT_BF16) launch_lay<DT_BF16, 4, 1, 2, 3, true>(k, ak, bk, grid, s); break;   // 256 x 96
+    case 5: if constexpr (MODE == DT_BF16) {                                                                 // 256 x 96
+        if (fast == 2) launch_lay<DT_BF16, 4, 1, 2, 3, 2>(k, ak, bk, grid, s);
+        else launch_lay<DT_BF16, 4, 1, 2, 3, 1>(k, ak, bk, grid, s);
+      } break;
     default: launch_cfg<MODE, 2, 2, 1, 1>(k, ak, bk, grid, s, fast); break;
   }
   prof_end(rec, s);
