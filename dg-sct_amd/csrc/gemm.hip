@@ -758,7 +758,11 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     k.wide = w;
   }
   k.kflat = g.K * g.KB;
-  k.kinv = g.K > 1 ? (unsigned)((0x100000000ULL + (unsigned long long)g.K - 1) / (unsigned long long)g.K) : 0u;
+  // frame index of a flat contraction index: floor(kf / K) = umulhi(kf, ceil(2^32 / K)), exact while kf * K < 2^32.
+  // One-level contractions (KB == 1) can be far deeper than that (a weight gradient over 655 360 token rows): they get
+  // kinv = 0, i.e. frame 0 for every kf, which is also what the branch-free fast paths rely on.
+  k.kinv = (g.KB > 1 && g.K > 1) ? (unsigned)((0x100000000ULL + (unsigned long long)g.K - 1) / (unsigned long long)g.K) : 0u;
+  if (g.KB > 1 && (unsigned long long)g.K * g.KB * g.K >= 0x100000000ULL) { set_error("gemm: two-level contraction too deep for the 32-bit frame split"); return; }
   k.kt_total = (k.kflat + BKT - 1) / BKT;
 
   // tile configuration (measured on MI355X with tools/gemm_bench.py over the shapes of the adapter stack):

@@ -65,11 +65,11 @@ def test_golden_bf16(name):
         assert nrm_err(r["dY"], fx["dY"]) < 8e-2
 
 
-def _real_case(N, C, No, Co, BT, dtype, seed=0):
-    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
+def _real_case(N, C, No, Co, BT, dtype, seed=0, flavour="ave"):
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour]})
     # weights at the reference's default-init scale: nn.Linear/Conv2d init is U(-1/sqrt(fan_in), 1/sqrt(fan_in)),
     # i.e. std = 0.577/sqrt(fan_in) (random_params draws N(0, scale^2/fan_in)); my_tokens ~ U[0,1) as in the reference
-    p = O.random_params(cfg, "ave", seed=seed, scale=0.577)
+    p = O.random_params(cfg, flavour, seed=seed, scale=0.577)
     gen = torch.Generator().manual_seed(seed + 1)
     X = torch.randn(BT, N, C, generator=gen)
     Y = torch.randn(BT, No, Co, generator=gen)
@@ -89,7 +89,9 @@ def _real_case(N, C, No, Co, BT, dtype, seed=0):
     dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(DEV, dtype).contiguous(),
                                      dMap.to(DEV), None)
     return dict(out=(out, out_o), map=(amap, map_o), dX=(dX, dX_o), dY=(dY, dY_o),
-                grads={PARAM_NAMES[i]: (g, g_o[PARAM_NAMES[i]]) for i, g in enumerate(grads) if g is not None})
+                grads={PARAM_NAMES[i]: (g, g_o[PARAM_NAMES[i]]) for i, g in enumerate(grads)
+                       if g is not None and PARAM_NAMES[i] in g_o},
+                extra=[PARAM_NAMES[i] for i, g in enumerate(grads) if g is not None and PARAM_NAMES[i] not in g_o])
 
 
 # (N, C, No, Co) of AVE stage 2 / stage 3, visual and audio direction, Swin-V2-B widths (BASELINE config 2)
@@ -133,6 +135,130 @@ def test_real_shapes_bf16(shape):
             assert _l2(g, go.reshape(-1)) < 0.6, (k, _l2(g, go.reshape(-1)))
         else:
             assert _l2(g, go.reshape(-1)) < 0.15, (k, _l2(g, go.reshape(-1)))
+
+
+@pytest.mark.parametrize("flavour", ["avvp", "avs_s4", "avs_ms3", "avqa", "pretrain"])
+def test_real_shapes_flavours_fp32(flavour):
+    """every call-site flavour of SURVEY 8a row a-0 (bicubic remap, gate-before-LN, tk=2/g=4/no BN, temporal gate) at
+    a real stage-2 shape (12x12 visual tokens <- 16x16 audio tokens) against the oracle"""
+    r = _real_case(144, 512, 256, 384, BT=10, dtype=torch.float32, flavour=flavour)
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(*r[k]) < TOL_F32, k
+    assert not r["extra"], r["extra"]
+    assert r["grads"]
+    for k, (g, go) in r["grads"].items():
+        assert rel_err(g, go.reshape(-1)) < TOL_F32, k
+
+
+def _full_size_setup(shape, seed, gate=None):
+    N, C, No, Co = shape
+    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
+    p = O.random_params(cfg, "ave", seed=seed, scale=0.577)
+    if gate is not None:
+        p["gate"] = torch.full_like(p["gate"], gate)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    params = param_table(p, spec, DEV)
+    gen = torch.Generator().manual_seed(seed + 1)
+    X = torch.randn(160, N, C, generator=gen).to(DEV, torch.bfloat16)
+    Y = torch.randn(160, No, Co, generator=gen).to(DEV, torch.bfloat16)
+    prep = ops.prepare(lib, spec, params, torch.bfloat16, DEV)
+    return lib, spec, params, prep, X, Y, gen
+
+
+@pytest.mark.parametrize("shape", [(2304, 128, 4096, 96), (4096, 96, 2304, 128)])
+def test_full_size_zero_gate_and_map_normalisation(shape):
+    """BASELINE size (160 frames, stage 0, bf16).  The reference initialises `gate` to 0 (net_trans.py:447): the adapter
+    output is then exactly 0 -- and exactly the residual with the fused skip -- whatever the other 9.6 M parameters are;
+    the returned map is a softmax over the N tokens of every frame (SURVEY 8c "analytic edge cases")."""
+    lib, spec, params, prep, X, Y, _ = _full_size_setup(shape, seed=11, gate=0.0)
+    out, amap, _, _, _ = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+    assert float(out.float().abs().max()) == 0.0
+    out2, amap2, _, _, _ = ops.raw_forward(lib, spec, params, prep, X, Y, True, X)
+    assert torch.equal(out2, X)
+    assert torch.isfinite(amap).all() and float((amap.sum(-1) - 1).abs().max()) < 1e-4
+    assert float(amap.min()) >= 0.0
+
+
+def test_full_size_backward_is_linear_in_the_cotangents():
+    """BASELINE size (160 frames, stage-0 audio adapter, bf16): backward is a linear map of (dOut, dMap), so
+    bwd(g1 + g2) = bwd(g1) + bwd(g2) for dX, dY and every parameter gradient (up to bf16 rounding of the cotangents'
+    intermediates) -- a size-independent check of the whole backward schedule, split-K atomics included."""
+    shape = (4096, 96, 2304, 128)
+    lib, spec, params, prep, X, Y, gen = _full_size_setup(shape, seed=21)
+    N, C = shape[0], shape[1]
+    g1 = torch.randn(160, N, C, generator=gen).to(DEV, torch.bfloat16)
+    g2 = torch.randn(160, N, C, generator=gen).to(DEV, torch.bfloat16)
+    m1 = torch.randn(160, N, generator=gen).to(DEV)
+    m2 = torch.randn(160, N, generator=gen).to(DEV)
+
+    def bwd(g, m):
+        _, _, _, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)      # backward consumes `saved`
+        dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, g.contiguous(), m.contiguous(), None)
+        torch.cuda.synchronize()
+        return dX.float(), dY.float(), [x.clone() if x is not None else None for x in grads]
+
+    a = bwd(g1, m1)
+    b = bwd(g2, m2)
+    c = bwd((g1.float() + g2.float()).to(torch.bfloat16), m1 + m2)
+    assert _l2(a[0] + b[0], c[0]) < 2e-2 and _l2(a[1] + b[1], c[1]) < 2e-2
+    bad = []
+    for i, (x, y, z) in enumerate(zip(a[2], b[2], c[2])):
+        if z is None or z.numel() < 64 or float(z.norm()) == 0:
+            continue
+        # weight matrices: 3e-2.  Vectors (biases, LN/BN affine): sums over 655 360 rows of bf16-rounded terms with heavy
+        # cancellation -- each run rounds differently, so linearity only holds to the accuracy of one run (cf. 0.6 above)
+        if PARAM_NAMES[i] == "ln_before.bias":      # analytically zero (BatchNorm removes it): pure rounding noise
+            continue
+        tol = 3e-2 if z.numel() > 4096 else 0.25
+        e = _l2(x + y, z)
+        if not e < tol:
+            bad.append((PARAM_NAMES[i], z.numel(), round(e, 4)))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("shape", [(2304, 128, 4096, 96), (4096, 96, 2304, 128), (144, 512, 256, 384)])
+def test_full_size_bf16_path_matches_fp32_path(shape):
+    """BASELINE size (160 frames): the bf16 production path (FAST staging, big tiles, split-K atomics, vector-unit
+    projections) against the library's own fp32 parity path (generic staging, exact-fp32 MFMA), which the golden and
+    real-shape tests pin to the oracle at sizes the CPU oracle can run.  Catches size-dependent addressing bugs (one was
+    a 32-bit overflow in the frame split of contractions deeper than 65 536)."""
+    N, C, No, Co = shape
+    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
+    p = O.random_params(cfg, "ave", seed=31, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    gen = torch.Generator().manual_seed(32)
+    X = torch.randn(160, N, C, generator=gen).bfloat16().float()
+    Y = torch.randn(160, No, Co, generator=gen).bfloat16().float()
+    g = torch.randn(160, N, C, generator=gen).bfloat16().float()
+    m = torch.randn(160, N, generator=gen)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+        prep = ops.prepare(lib, spec, params, dt, DEV)
+        Xd, Yd = X.to(DEV, dt), Y.to(DEV, dt)
+        out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
+        dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, g.to(DEV, dt), m.to(DEV), None)
+        torch.cuda.synchronize()
+        res[dt] = (out.float().cpu(), amap.cpu(), dX.float().cpu(), dY.float().cpu(),
+                   [x.cpu() if x is not None else None for x in grads])
+        del out, amap, saved, dX, dY, grads, prep
+        ops.release_workspaces()
+        torch.cuda.empty_cache()
+    f, h = res[torch.float32], res[torch.bfloat16]
+    assert all(torch.isfinite(t).all() for t in h[:4])
+    assert _l2(h[0], f[0]) < TOL_BF16 and _l2(h[1], f[1]) < TOL_BF16
+    assert _l2(h[2], f[2]) < 0.1 and _l2(h[3], f[3]) < 0.1
+    bad = []
+    for i, (a, b) in enumerate(zip(h[4], f[4])):
+        if b is None or b.dim() == 0 or b.numel() <= 4096:
+            continue                                   # vectors / scalars: see test_real_shapes_bf16
+        assert torch.isfinite(a).all(), PARAM_NAMES[i]
+        e = _l2(a, b)
+        if not e < 0.15:
+            bad.append((PARAM_NAMES[i], round(e, 4)))
+    assert not bad, bad
 
 
 STAGE01 = [(2304, 128, 4096, 96), (4096, 96, 2304, 128), (576, 256, 1024, 192), (1024, 192, 576, 256)]
