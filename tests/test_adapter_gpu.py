@@ -317,6 +317,52 @@ def test_fused_residual_and_skip(dtype, tol):
     assert nrm_err(r["dY"], base["dY"].float().cpu()) < 1e-6 + (0 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("flat", [False, True])
+def test_stack_on_gpu_matches_reference_fixture(flat):
+    """SURVEY row a-10 on the device: 12 adapters through AdapterStack with everything the benchmark uses switched on
+    (two adapter streams, aux streams in forward and backward, fused residual/skip, flat parameters) against the
+    reference-generated stack fixture; repeated to give stream-ordering bugs a chance to show."""
+    from dgsct_amd import AdapterStack
+    from dgsct_amd.stack import default_opt
+    fx = load_golden("stack_2stage")
+    st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4), concurrent=True)
+    st.load_state_dict(fx["state0"])
+    st = st.to(DEV)
+    if flat:
+        st.flatten_parameters()
+    st.train()
+    for rep in range(3):
+        if rep:                                              # BN running stats moved in the previous repetition
+            st.load_state_dict(fx["state0"])
+        for p in st.parameters():
+            p.grad = None
+        feats = [(a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for a, b in fx["feats"]]
+        outs, maps = st(feats)
+        for (fv, fa), (rv, ra) in zip(outs, fx["outs"]):
+            assert rel_err(fv, rv) < TOL_F32 and rel_err(fa, ra) < TOL_F32
+        assert rel_err(maps[0], fx["maps"][0]) < TOL_F32 and rel_err(maps[1], fx["maps"][1]) < TOL_F32
+        torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
+                                [g.to(DEV) for pr in fx["cots"] for g in pr] + [fx["mcots"][0].to(DEV), fx["mcots"][1].to(DEV)])
+        torch.cuda.synchronize()
+        for (fv, fa), (gv, ga) in zip(feats, fx["dfeats"]):
+            assert rel_err(fv.grad, gv) < TOL_F32 and rel_err(fa.grad, ga) < TOL_F32
+        if flat:
+            n = 0
+            for name, m in st.named_modules():
+                if hasattr(m, "flat_param"):
+                    for pn, (off, cnt, shape) in m._flat_layout.items():
+                        ref = fx["grads"].get(name + "." + pn)
+                        if ref is not None:
+                            assert rel_err(m.flat_param.grad[off:off + cnt].view(shape), ref) < TOL_F32, name + "." + pn
+                            n += 1
+            assert n == len(fx["grads"])
+        else:
+            got = {k: p.grad for k, p in st.named_parameters() if p.grad is not None}
+            assert set(got) == set(fx["grads"])
+            for k, g in fx["grads"].items():
+                assert rel_err(got[k], g) < TOL_F32, k
+
+
 def test_module_dropin_matches_oracle():
     """nn.Module boundary: reference call convention ([BT,C,N,1] views), state_dict names, autograd."""
     from types import SimpleNamespace
