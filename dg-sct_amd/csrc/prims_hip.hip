@@ -456,9 +456,9 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
   // software pipeline: the next row's two 16-byte loads are in flight while this row is reduced and stored
   // The row statistics are fetched WITH the row: vmcnt retires in order, so a scalar load issued after the prefetch of
   // the next row would force a wait for that prefetch as well (hipcc emitted s_waitcnt vmcnt(0) right behind it).
-  uint4 pg[MAXNV], pop[MAXNV];
-  float pmean = 0.f, prs = 1.f;
-  auto fetch = [&](long row) {
+  // Two prefetch slots: the loads of rows i+1 and i+2 are in flight while row i is reduced and stored (one slot kept
+  // the kernel at ~1.9 TB/s: 32 bytes per lane in flight at 3 waves per SIMD).
+  auto fetch = [&](long row, uint4 (&pg)[MAXNV], uint4 (&pop)[MAXNV], float& pmean, float& prs) {
     if (lnw) { pmean = mu[row]; prs = rstd[row]; }
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
@@ -466,16 +466,13 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
       if (v < nv && col < C) { pg[v] = ldraw<DT, VE>(dOut, row * C + col); pop[v] = ldraw<DT, VE>(Op, row * C + col); }
     }
   };
-  if ((long)blockIdx.x * rpc + sub < r_end) fetch((long)blockIdx.x * rpc + sub);
-  for (long row = (long)blockIdx.x * rpc + sub; row < r_end; row += rpp) {
+  auto body = [&](long row, const uint4 (&pg)[MAXNV], const uint4 (&pop)[MAXNV], float mean, float rs) {
     float g[MAXNV][VE], o[MAXNV][VE], xh[MAXNV][VE], op[MAXNV][VE];
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
       if (v < nv && col < C) { unpack<DT, VE>(pg[v], g[v]); unpack<DT, VE>(pop[v], op[v]); }
     }
-    const float mean = pmean, rs = prs;
-    if (row + rpp < r_end) fetch(row + rpp);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
@@ -532,6 +529,27 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
           }
         }
         stv<DT, VE>(dO, row * C + col, d);
+      }
+    }
+    };
+  {
+    uint4 pgA[MAXNV], popA[MAXNV], pgB[MAXNV], popB[MAXNV], cg[MAXNV], cop[MAXNV];
+    float mA = 0.f, rA = 1.f, mB = 0.f, rB = 1.f;
+    long row = (long)blockIdx.x * rpc + sub;
+    if (row < r_end) fetch(row, pgA, popA, mA, rA);
+    if (row + rpp < r_end) fetch(row + rpp, pgB, popB, mB, rB);
+    for (; row < r_end; row += 2 * rpp) {
+      float cm = mA, cr = rA;
+#pragma unroll
+      for (int v = 0; v < MAXNV; ++v) { cg[v] = pgA[v]; cop[v] = popA[v]; }
+      if (row + 2 * rpp < r_end) fetch(row + 2 * rpp, pgA, popA, mA, rA);
+      body(row, cg, cop, cm, cr);
+      if (row + rpp < r_end) {
+        cm = mB; cr = rB;
+#pragma unroll
+        for (int v = 0; v < MAXNV; ++v) { cg[v] = pgB[v]; cop[v] = popB[v]; }
+        if (row + 3 * rpp < r_end) fetch(row + 3 * rpp, pgB, popB, mB, rB);
+        body(row + rpp, cg, cop, cm, cr);
       }
     }
   }
