@@ -817,6 +817,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   k.tiles_m = (g.M + BMs[cfg] - 1) / BMs[cfg];
   k.tiles_n = (g.N + BNs[cfg] - 1) / BNs[cfg];
   int splitk = g.splitk;
+  if (g.atomic && splitk <= 0) { if (const char* e = getenv("DGSCT_GEMM_SPLITK")) splitk = atoi(e); }   // tuning hook
   if (!g.atomic) splitk = 1;
   else if (splitk <= 0) {                                       // auto: aim for >= 1024 workgroups, >= 4 k-tiles each
     long wg = (long)k.tiles_m * k.tiles_n * g.batch;
