@@ -52,7 +52,8 @@ class GemmArgs(C.Structure):
                 ("bias_m", C.c_void_p), ("bias_n", C.c_void_p), ("bias_n_bs", C.c_int64), ("m_mod", C.c_int32),
                 ("r1_m", C.c_void_p), ("r1_n", C.c_void_p), ("act", C.c_int32),
                 ("R", C.c_void_p), ("rdt", C.c_int32), ("ldr", C.c_int64), ("rbs", C.c_int64), ("beta", C.c_float),
-                ("mask", C.c_void_p), ("ldmask", C.c_int64), ("maskbs", C.c_int64)]
+                ("mask", C.c_void_p), ("ldmask", C.c_int64), ("maskbs", C.c_int64),
+                ("R2", C.c_void_p), ("sm_scale", C.c_void_p), ("sm_dot", C.c_void_p)]
 
 
 EXPORTS = ["dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",

@@ -128,6 +128,7 @@ int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
   g.r1_m = a->r1_m; g.r1_n = a->r1_n; g.act = a->act;
   g.R = a->R; g.rdt = a->rdt; g.ldr = a->ldr; g.rbs = a->rbs; g.beta = a->beta;
   g.mask = a->mask; g.ldmask = a->ldmask; g.maskbs = a->maskbs;
+  g.R2 = a->R2; g.sm_scale = a->sm_scale; g.sm_dot = a->sm_dot;
   gemm(ctx, g);
   return has_error() ? 1 : 0;
 }

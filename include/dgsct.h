@@ -169,6 +169,8 @@ typedef struct dgsct_gemm_args {
   int32_t act;
   const void* R; int32_t rdt; int64_t ldr, rbs; float beta;
   const void* mask; int64_t ldmask, maskbs;
+  const void* R2;                                   /* second residual (dtype/ld/stride of R), weight 1            */
+  const float* sm_scale; float* sm_dot;             /* act 3/4 (column softmax epilogues, transposed output)       */
 } dgsct_gemm_args;
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream);
 

@@ -87,6 +87,10 @@ def run_case(mode, M, N, K, ak, bk, batch=1, KB=1, shared_a=False, pad=0, epi=No
         t = torch.randn(batch, M, N, generator=gen).to(torch.bfloat16 if rdt else torch.float32)
         keep.append(t.to(DEV)); a.R, a.rdt, a.ldr, a.rbs = keep[-1].data_ptr(), rdt, N, M * N
         ref = ref + a.beta * t.double()
+        if epi.get("R2"):
+            t2 = torch.randn(batch, M, N, generator=gen).to(torch.bfloat16 if rdt else torch.float32)
+            keep.append(t2.to(DEV)); a.R2 = keep[-1].data_ptr()
+            ref = ref + t2.double()
     lib.test_gemm(a, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = D[..., :N].double().cpu()
@@ -134,3 +138,69 @@ def test_gemm_shared_a_and_epilogues(mode):
     run_case(mode, 90, 40, 16, 1, 0, batch=3, epi=dict(alpha_ptr=True, R=True, rdt=mode), out_bf16=(mode == 1))
     run_case(mode, 33, 40, 64, 1, 0, batch=1, epi=dict(mask=True, bias_m=True))
     run_case(mode, 64, 64, 4, 1, 0, batch=2, epi=dict(R=True, beta=1.0))           # K smaller than one k-tile (tk = 2 / 4)
+
+
+def test_gemm_second_residual():
+    run_case(1, 300, 96, 32, 1, 0, batch=3, epi=dict(alpha_ptr=True, R=True, R2=True, rdt=1), out_bf16=True)   # dX = dX1 + dS2.tok + dOut
+    run_case(0, 70, 40, 16, 1, 0, batch=2, epi=dict(R=True, R2=True, rdt=0))
+
+
+@pytest.mark.parametrize("ak,bk", LAYOUTS)
+def test_gemm_deep_one_level_contraction(ak, bk):
+    """K = 200 000 > 65 536: the frame split of the FAST staging must not be applied to one-level contractions (a 32-bit
+    multiply-high overflow corrupted the last k-rows of every 160-frame weight gradient before it was fixed)."""
+    run_case(1, 64, 48, 200000, ak, bk, batch=1, atomic=True, splitk=0)
+
+
+def test_gemm_deep_tiles_and_shared_operand():
+    run_case(1, 512, 96, 2048, 1, 1, batch=3, shared_a=True, out_bf16=True)      # 256 x 96 tile (remap forward)
+    run_case(1, 512, 96, 2048, 1, 0, batch=3, shared_a=True, out_bf16=True)
+    run_case(1, 256, 256, 96, 1, 0, batch=1, KB=40, atomic=True, splitk=0)       # dWn-style: two-level K, 128 x 128, split-K
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("tk", [32, 12, 4])
+def test_gemm_softmax_epilogues(mode, tk):
+    """ACT_SOFTMAX / ACT_SOFTMAX_BWD: column softmax over the M = tk rows, transposed output (X <- token attention)."""
+    lib = default_lib()
+    gen = torch.Generator().manual_seed(3)
+    dtype = torch.bfloat16 if mode == 1 else torch.float32
+    batch, Ntok, C = 2, 300, 96
+    tkp = (tk + 7) // 8 * 8
+    tok = (0.3 * torch.randn(batch, tk, C, generator=gen)).to(dtype)
+    X = torch.randn(batch, Ntok, C, generator=gen).to(dtype)
+    logits = torch.einsum("btc,bnc->bnt", tok.double(), X.double())            # [b, n, t]
+    P_ref = torch.softmax(logits, dim=-1)
+    a = GemmArgs()
+    a.mode, a.M, a.N, a.K, a.KB, a.batch, a.splitk, a.atomic = mode, tk, Ntok, C, 1, batch, 1, 0
+    tokd, Xd = tok.to(DEV).contiguous(), X.to(DEV).contiguous()
+    a.A, a.lda, a.a_kmajor, a.a_bs, a.a_kbs = tokd.data_ptr(), C, 1, tk * C, 0
+    a.B, a.ldb, a.b_kmajor, a.b_bs, a.b_kbs = Xd.data_ptr(), C, 1, Ntok * C, 0
+    P = torch.zeros(batch, Ntok, tkp, dtype=dtype, device=DEV)
+    a.D, a.ddt, a.ldd, a.dbs = P.data_ptr(), mode, tkp, Ntok * tkp
+    a.alpha, a.beta, a.act = 1.0, 1.0, 3
+    st = torch.cuda.current_stream().cuda_stream
+    lib.test_gemm(a, st)
+    torch.cuda.synchronize()
+    tol = 1e-2 if mode == 1 else 2e-5
+    assert (P[..., :tk].double().cpu() - P_ref).abs().max().item() < tol
+    # backward: dS = s * P * (U - sum_t P U), U^T = tok . dX1^T ; dot = sum P U
+    dX1 = torch.randn(batch, Ntok, C, generator=gen).to(dtype)
+    U = torch.einsum("btc,bnc->bnt", tok.double(), dX1.double())
+    Pd = P[..., :tk].double().cpu()
+    s_val = 0.3
+    dot = (Pd * U).sum(-1, keepdim=True)
+    dS_ref = s_val * Pd * (U - dot)
+    dX1d = dX1.to(DEV).contiguous()
+    a.B = dX1d.data_ptr()
+    dS = torch.zeros(batch, Ntok, tkp, dtype=dtype, device=DEV)
+    a.D = dS.data_ptr()
+    a.act = 4
+    a.mask, a.ldmask, a.maskbs = P.data_ptr(), tkp, Ntok * tkp
+    sc = torch.tensor([s_val], device=DEV); acc = torch.zeros(1, device=DEV)
+    a.sm_scale, a.sm_dot = sc.data_ptr(), acc.data_ptr()
+    lib.test_gemm(a, st)
+    torch.cuda.synchronize()
+    scale = max(1.0, dS_ref.abs().max().item())
+    assert (dS[..., :tk].double().cpu() - dS_ref).abs().max().item() / scale < (2e-2 if mode == 1 else 2e-5)
+    assert abs(acc.item() - dot.sum().item()) < (2e-2 if mode == 1 else 1e-4) * max(1.0, abs(dot.sum().item()))
