@@ -18,14 +18,14 @@ namespace dgsct {
 #define STREAM(ctx) ((hipStream_t)(ctx).stream)
 static inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 
-constexpr int PROJ_DG = 8;          // max per-group narrow width held in registers
+constexpr int PROJ_DG_MAX = 16;     // max per-group narrow width (weight block of a lane in registers: DG x VE floats)
 
 struct ProjGeom { int ve, gs, rpp, rpc, chunks; };
 static bool proj_geom(int mode, int C, int ds, int g, long rows, long target_wgs, ProjGeom& pg) {
   if (g < 1 || C % g || ds % g) return false;
   const int cg = C / g, dg = ds / g;
   pg.ve = mode == DT_BF16 ? 8 : 4;
-  if (dg < 1 || dg > PROJ_DG || cg % pg.ve || (dg & 1)) return false;
+  if (dg < 1 || dg > PROJ_DG_MAX || cg % pg.ve || (dg & 1)) return false;
   const int nvec = C / pg.ve;
   pg.gs = 1;
   while (pg.gs < nvec) pg.gs <<= 1;
@@ -49,10 +49,11 @@ bool gproj_supported(int mode, int C, int ds, int g) {
 // ---- narrow ---------------------------------------------------------------------------------------------------------
 // Per row: every lane forms its dg partial dot products; the lanes of a channel group are combined through LDS (the
 // row group sits inside one wavefront, whose DS instructions execute in order: no workgroup barrier).
-constexpr int PROJ_UNR = 4;         // rows per lane per trip: all loads are issued before the first use (latency hiding)
+// UNR rows per lane per trip: all loads are issued before the first use (latency hiding).  DG = 8 (stage 0: dg = 6, 8)
+// keeps 4 rows in flight; DG = 16 (stage 1: dg = 12, 16) has a 128-register weight block and runs 2 rows at 2 WG/CU.
 
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void gproj_narrow_k(const void* x, long rows, int C, int ds, int g, const float* W, long sg,
+template <int DT, int VE, int PROJ_DG, int PROJ_UNR>
+__global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void gproj_narrow_k(const void* x, long rows, int C, int ds, int g, const float* W, long sg,
                                                       long sj, long sc, int gs, int rpc, void* y) {
   // [UNR][row slot][lane][DG] partial dot products (+8 floats per row slot: spreads the slots over the banks)
   __shared__ __attribute__((aligned(16))) float lds[PROJ_UNR * (256 * PROJ_DG + 128 * 8)];
@@ -107,8 +108,8 @@ __global__ __launch_bounds__(256) void gproj_narrow_k(const void* x, long rows, 
         p[jl] = a;
       }
       float4* dst = reinterpret_cast<float4*>(slot0 + u * unr_stride + gl * PROJ_DG);
-      dst[0] = make_float4(p[0], p[1], p[2], p[3]);
-      dst[1] = make_float4(p[4], p[5], p[6], p[7]);
+#pragma unroll
+      for (int q4 = 0; q4 < PROJ_DG / 4; ++q4) dst[q4] = make_float4(p[4 * q4], p[4 * q4 + 1], p[4 * q4 + 2], p[4 * q4 + 3]);
     }
     // the row group lives inside one wavefront: its DS instructions execute in order, only the compiler must not move
     // the reads above the writes
@@ -134,19 +135,20 @@ void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g
                   void* y) {
   ProjGeom pg;
   if (!proj_geom(ctx.mode, C, ds, g, rows, 2048, pg)) { set_error("gproj_narrow: unsupported shape C=%d ds=%d g=%d", C, ds, g); return; }
-  if (ctx.mode == DT_BF16)
-    hipLaunchKernelGGL((gproj_narrow_k<DT_BF16, 8>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc,
-                       pg.gs, pg.rpc, y);
-  else
-    hipLaunchKernelGGL((gproj_narrow_k<DT_F32, 4>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc,
-                       pg.gs, pg.rpc, y);
+  const bool big = ds / g > 8;
+#define NARROW_(DT_, VE_, DG_, UNR_) \
+  hipLaunchKernelGGL((gproj_narrow_k<DT_, VE_, DG_, UNR_>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc, \
+                     pg.gs, pg.rpc, y)
+  if (ctx.mode == DT_BF16) { if (big) NARROW_(DT_BF16, 8, 16, 2); else NARROW_(DT_BF16, 8, 8, 4); }
+  else { if (big) NARROW_(DT_F32, 4, 16, 2); else NARROW_(DT_F32, 4, 8, 4); }
+#undef NARROW_
 }
 
 // ---- wide -----------------------------------------------------------------------------------------------------------
 // stats != null: the bn_stats accumulators of y AS STORED (rounded to E): stats[0..C) = y[0][c] (shift),
 // stats[C..2C) += sum (y - shift), stats[2C..3C) += sum (y - shift)^2.
-template <int DT, int VE>
-__global__ __launch_bounds__(256) void gproj_wide_k(const void* x, long rows, int C, int ds, int g, const float* W, long sg,
+template <int DT, int VE, int PROJ_DG, int PROJ_UNR>
+__global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void gproj_wide_k(const void* x, long rows, int C, int ds, int g, const float* W, long sg,
                                                     long sj, long sc, int gs, int rpc, void* y, float* stats) {
   __shared__ float lds[4096];
   const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
@@ -258,8 +260,10 @@ void gproj_wide(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, 
   ProjGeom pg;
   long target = 2048;
   if (stats) {          // a reduction: one full round of resident workgroups (see wg_capacity)
-    const void* fn = ctx.mode == DT_BF16 ? reinterpret_cast<const void*>(&gproj_wide_k<DT_BF16, 8>)
-                                         : reinterpret_cast<const void*>(&gproj_wide_k<DT_F32, 4>);
+    const bool big0 = ds / g > 8;
+    const void* fn = ctx.mode == DT_BF16
+        ? (big0 ? reinterpret_cast<const void*>(&gproj_wide_k<DT_BF16, 8, 16, 2>) : reinterpret_cast<const void*>(&gproj_wide_k<DT_BF16, 8, 8, 4>))
+        : (big0 ? reinterpret_cast<const void*>(&gproj_wide_k<DT_F32, 4, 16, 2>) : reinterpret_cast<const void*>(&gproj_wide_k<DT_F32, 4, 8, 4>));
     target = wg_capacity(fn, 0);
     if (target > 1024) target = 1024;
   }
@@ -267,12 +271,13 @@ void gproj_wide(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, 
     set_error("gproj_wide: unsupported shape C=%d ds=%d g=%d", C, ds, g);
     return;
   }
-  if (ctx.mode == DT_BF16)
-    hipLaunchKernelGGL((gproj_wide_k<DT_BF16, 8>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc,
-                       pg.gs, pg.rpc, y, stats);
-  else
-    hipLaunchKernelGGL((gproj_wide_k<DT_F32, 4>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc,
-                       pg.gs, pg.rpc, y, stats);
+  const bool big = ds / g > 8;
+#define WIDE_(DT_, VE_, DG_, UNR_) \
+  hipLaunchKernelGGL((gproj_wide_k<DT_, VE_, DG_, UNR_>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc, \
+                     pg.gs, pg.rpc, y, stats)
+  if (ctx.mode == DT_BF16) { if (big) WIDE_(DT_BF16, 8, 16, 2); else WIDE_(DT_BF16, 8, 8, 4); }
+  else { if (big) WIDE_(DT_F32, 4, 16, 2); else WIDE_(DT_F32, 4, 8, 4); }
+#undef WIDE_
 }
 
 }  // namespace dgsct

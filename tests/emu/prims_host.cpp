@@ -290,7 +290,7 @@ bool gproj_supported(int mode, int C, int ds, int g) {
   if (getenv("DGSCT_NO_GPROJ") && atoi(getenv("DGSCT_NO_GPROJ"))) return false;
   if (g < 1 || C % g || ds % g) return false;
   const int ve = mode == DT_BF16 ? 8 : 4, cg = C / g, dg = ds / g;
-  if (dg < 1 || dg > 8 || (dg & 1) || cg % ve) return false;
+  if (dg < 1 || dg > 16 || (dg & 1) || cg % ve) return false;
   int gs = 1;
   while (gs < C / ve) gs <<= 1;
   return gs <= 64 && ds <= gs && C <= 512 && (long)ds * cg <= 4096;
