@@ -23,14 +23,17 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
-// Cross-stream ordering with a small thread-local ring of timing-less events (re-recording an event whose earlier
-// wait is still pending is well defined: a wait captures the record that preceded it).
-static hipEvent_t next_event() {
-  static thread_local hipEvent_t ring[32];
-  static thread_local int n = 0, made = 0;
-  if (made < 32) { (void)hipEventCreateWithFlags(&ring[made], hipEventDisableTiming); return ring[made++]; }
-  hipEvent_t e = ring[n];
-  n = (n + 1) & 31;
+// Cross-stream ordering with thread-local rings of timing-less events.  A wait captures the record that preceded it, so
+// re-recording an event is well defined -- but the rings are long (an event is reused ~60 adapter calls later, when its
+// wait has long been submitted) and separate per direction (a fork event is never reused as a join event), so the
+// ordering does not depend on how lazily the runtime resolves a pending wait.
+static hipEvent_t next_event(int dir) {
+  constexpr int RING = 1024;
+  static thread_local hipEvent_t ring[2][RING];
+  static thread_local int n[2] = {0, 0}, made[2] = {0, 0};
+  if (made[dir] < RING) { (void)hipEventCreateWithFlags(&ring[dir][made[dir]], hipEventDisableTiming); return ring[dir][made[dir]++]; }
+  hipEvent_t e = ring[dir][n[dir]];
+  n[dir] = (n[dir] + 1) % RING;
   return e;
 }
 void* stream_create(int priority_class) {
@@ -50,13 +53,13 @@ void stream_destroy(void* stream) {
 
 void stream_fork(const Ctx& ctx) {
   if (!ctx.aux) return;
-  hipEvent_t e = next_event();
+  hipEvent_t e = next_event(0);
   (void)hipEventRecord(e, (hipStream_t)ctx.stream);
   (void)hipStreamWaitEvent((hipStream_t)ctx.aux, e, 0);
 }
 void stream_join(const Ctx& ctx) {
   if (!ctx.aux) return;
-  hipEvent_t e = next_event();
+  hipEvent_t e = next_event(1);
   (void)hipEventRecord(e, (hipStream_t)ctx.aux);
   (void)hipStreamWaitEvent((hipStream_t)ctx.stream, e, 0);
 }

@@ -145,6 +145,15 @@ def prepare(lib: Lib, spec: AdapterSpec, params: List[Optional[torch.Tensor]], d
     return prep
 
 
+def _mark_stream_use(*tensors):
+    """Tell torch's caching allocator that these tensors are read on the CURRENT stream.  With AdapterStack's two adapter
+    streams an input map (or an incoming gradient) is usually allocated on the other stream; without this, the block can be
+    handed out again on its home stream while kernels enqueued here are still reading it."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(torch.cuda.current_stream(t.device))
+
+
 def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: torch.Tensor, training: bool,
                 residual: Optional[torch.Tensor] = None):
     """X [BT,N,C], Y [BT,No,Co] contiguous, same dtype (fp32|bf16).  Returns (out, map, tmap, saved, desc).
@@ -157,6 +166,7 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
         raise RuntimeError("dg-sct_amd: X and Y must both be float32 or both bfloat16")
     if residual is not None and (residual.shape != X.shape or residual.dtype != X.dtype or not residual.is_contiguous()):
         raise RuntimeError("dg-sct_amd: residual must be a contiguous tensor of X's shape and dtype")
+    _mark_stream_use(X, Y, residual, prep)
     d = spec.desc(BT, X.dtype, training)
     sz = _sizes(lib, d)
     dev = X.device
@@ -174,6 +184,7 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
 
 def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y, saved, dOut, dMap, dTmap, flat_out=False,
                  skip_into_dx=False):
+    _mark_stream_use(X, Y, saved, dOut, dMap, dTmap, prep)
     sz = _sizes(lib, d)
     dev = X.device
     dX = torch.empty_like(X)

@@ -129,6 +129,9 @@ class AdapterStack(nn.Module):
                 a = call(audio_mod, f_a, f_v, r_a)
             v = call(vis_mod, f_v, f_a, r_v)
             main.wait_stream(side)
+            for t in a:                                  # allocated on the side stream, consumed on the main one
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
             return a, v
 
         def step(p_audio, p_vis, f_a, f_v, idx, half, with_aud_block):
