@@ -140,9 +140,23 @@ def prepare(lib: Lib, spec: AdapterSpec, params: List[Optional[torch.Tensor]], d
     d = spec.desc(spec.T, dtype, False)
     sz = _sizes(lib, d)
     prep = torch.empty(max(int(sz.prep_bytes), 256), dtype=torch.uint8, device=device)
+    if os.environ.get("DGSCT_POISON", "0") == "1":
+        prep.fill_(0xFF)
     some = next(p for p in params if p is not None)
     lib.prepare(d, _ptrs(params), prep.data_ptr(), _stream_of(some))
     return prep
+
+
+_POISON = os.environ.get("DGSCT_POISON", "0") == "1"      # test hook: fill every buffer handed to the library with NaN
+
+
+def _poison(*tensors):
+    """DGSCT_POISON=1: every output / scratch / saved buffer starts as NaN bit patterns, so a kernel that reads memory it
+    (or an earlier kernel of the call) did not write shows up as NaN in the results instead of depending on what the
+    caching allocator happened to hand out."""
+    for t in tensors:
+        if t is not None:
+            t.view(torch.uint8).fill_(0xFF)
 
 
 def _mark_stream_use(*tensors):
@@ -176,6 +190,8 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
     saved = torch.empty(int(sz.saved_bytes), dtype=torch.uint8, device=dev)
     stream = _stream_of(X)
     ws = _workspace(dev, stream, int(sz.ws_fwd_bytes))
+    if _POISON:
+        _poison(out, amap, tmap, saved, ws)
     lib.forward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), out.data_ptr(), amap.data_ptr(),
                 tmap.data_ptr() if tmap is not None else None, saved.data_ptr(), ws.data_ptr(), stream,
                 residual.data_ptr() if residual is not None else None, _aux_stream(lib, X, stream))
@@ -192,6 +208,8 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     grads = torch.empty(int(sz.grad_floats), dtype=torch.float32, device=dev)
     stream = _stream_of(X)
     ws = _workspace(dev, stream, int(sz.ws_bwd_bytes))
+    if _POISON:
+        _poison(dX, dY, grads, ws)
     lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
                  dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
                  dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(lib, X, stream),
