@@ -308,19 +308,24 @@ def main():
     clips_per_s = args.batch * world / (elapsed / args.steps)
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not (dp and args.overlap):     # (overlap: autograd hooks would issue collectives)
         # dominant kernel family = the MFMA GEMM engine (gemm_kernel<...>): time every launch of two extra steps
         # with HIP events on the launch stream (the library records them itself: dgsct_prof_enable).
         lib = default_lib()
         from dgsct_amd import ops as _ops
         conc, aux = stack.concurrent, _ops.USE_AUX_STREAM
         stack.concurrent, _ops.USE_AUX_STREAM = False, False      # one stream: a kernel's events then bracket that kernel alone
-        eager_step()
+
+        def local_step():                # rank-local (no collective: the other ranks are not in this pass)
+            fwd_bwd()
+            update()
+
+        local_step()
         torch.cuda.synchronize()
         lib.prof_enable(True)
         nprof = 2
         for _ in range(nprof):
-            eager_step()                 # eager launches: the library brackets each GEMM launch with HIP events
+            local_step()                 # eager launches: the library brackets each GEMM launch with HIP events
         torch.cuda.synchronize()
         import csv
         import tempfile
