@@ -172,7 +172,7 @@ def main():
         if "RANK" not in os.environ:       # --force-dp without a launcher
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
         from dgsct_amd import init_process_group
-        init_process_group(device)       # "nccl" IS RCCL on ROCm; collective stream in the high-priority queue pool
+        init_process_group(device)       # "nccl" IS RCCL on ROCm (one process per GPU, bound to its device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     T = 10
     BT = args.batch * T
