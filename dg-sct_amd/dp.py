@@ -29,13 +29,14 @@ import torch.distributed as dist
 
 
 def init_process_group(device: torch.device, backend: str = "nccl", **kw):
-    """``dist.init_process_group`` for one-process-per-GPU data parallelism over RCCL ("nccl" IS RCCL on ROCm).
+    """``dist.init_process_group`` for one-process-per-GPU data parallelism over RCCL ("nccl" IS RCCL on ROCm), bound to
+    ``device`` (eager communicator creation, no device guessing in barriers).
 
-    The collective kernels run on ProcessGroupNCCL's internal stream.  Taken from torch's normal-priority pool that
-    stream may share a hardware queue with the compute stream (the HIP runtime multiplexes all streams of a priority
-    class onto 4 queues); its event waits then stall the compute stream and serialise the audio/visual adapter streams
-    (measured: 94 -> 148 ms per step on one MI355X).  The high-priority pool holds only this stream and the stack's
-    second adapter stream, which land on different queues."""
+    The collective kernels run on ProcessGroupNCCL's internal stream, taken from torch's NORMAL-priority pool by default.
+    The library's own side / aux streams live in the HIGH-priority pool (``dgsct_stream_create``), whose hardware queues
+    are separate, so the collective stream cannot land on one of their queues; putting it in the high pool as well
+    (``DGSCT_NCCL_HIGH_PRIORITY=1``) was measured to collide with the second adapter stream (97 -> 169 ms per step on one
+    MI355X).  See DESIGN.md section 5 and tools/dp_host_probe.py."""
     if backend == "nccl":
         hi = os.environ.get("DGSCT_NCCL_HIGH_PRIORITY", "0") == "1"
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=hi)
