@@ -22,13 +22,24 @@ namespace dgsct {
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
-constexpr int UNR = 4;
+// rows per trip, by the number of big tensors a kernel streams (more loads in flight per lane until the register
+// file pushes occupancy to 1: measured 76.9 / 75.6 / 75.0 / 77.5 ms per step for a uniform 4 / 8 / 16 / 32)
+#ifndef DGSCT_UNR1
+#define DGSCT_UNR1 16
+#endif
+#ifndef DGSCT_UNR2
+#define DGSCT_UNR2 8
+#endif
+#ifndef DGSCT_UNR3
+#define DGSCT_UNR3 8
+#endif
+constexpr int UNR1 = DGSCT_UNR1, UNR2 = DGSCT_UNR2, UNR3 = DGSCT_UNR3;
 
 struct ColGeom { int nvr, tpr, rpp, rpc, chunks; };
 // target_wgs: ~4096 for pure streams; ~768 (3 per CU) for reductions, whose per-workgroup LDS combine + one global
 // atomic per channel must be amortised over many rows (3840 workgroups x 128 channels of atomics on 128 addresses
 // cost more than the 94 MB stream itself).
-static ColGeom col_geom(int C, int VE, long rows, int B, long target_wgs = 4096, bool floor_to_cap = false) {
+static ColGeom col_geom(int UNR, int C, int VE, long rows, int B, long target_wgs = 4096, bool floor_to_cap = false) {
   ColGeom g;
   g.nvr = C / VE;
   g.tpr = imin(g.nvr, 256);
@@ -101,6 +112,7 @@ template <int DT, int VE>
 __global__ __launch_bounds__(256) void colsum_k(const void* x, long ld, long bs, int N, int C, const float* roww,
                                                 long roww_bs, float scale, int tpr, int rpp, int rpc, float* out,
                                                 long out_bs) {
+  constexpr int UNR = UNR1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y;
   STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
@@ -142,7 +154,7 @@ void colsum_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int 
   int cap = 768;
   COL_CAPACITY(cap, ctx, ve, colsum_k, (size_t)C * sizeof(float));
   if (cap > 800) cap = 800;            // light kernel (5 resident/CU): beyond ~3 per CU the extra atomics cost more than they hide
-  ColGeom g = col_geom(C, ve, N, B, cap, true);
+  ColGeom g = col_geom(UNR1, C, ve, N, B, cap, true);
   COL_DISPATCH(ctx, ve, colsum_k, dim3(g.chunks, B), (size_t)C * sizeof(float), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr,
                g.rpp, g.rpc, out, out_bs);
 }
@@ -151,6 +163,7 @@ void colsum_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int 
 // acc3[0..C) = shift (row 0), acc3[C..2C) += sum(x - shift), acc3[2C..3C) += sum((x - shift)^2)
 template <int DT, int VE>
 __global__ __launch_bounds__(256) void bn_stats_k(const void* x, long rows, int C, int tpr, int rpp, int rpc, float* acc3) {
+  constexpr int UNR = UNR1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
   for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_stats_k(const void* x, long rows, int 
 
 void bn_stats(const Ctx& ctx, const void* x, long rows, int C, float* acc) {
   const int ve = col_ve(ctx, C);
-  ColGeom g = col_geom(C, ve, rows, 1, 768);
+  ColGeom g = col_geom(UNR1, C, ve, rows, 1, 768);
   COL_DISPATCH(ctx, ve, bn_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), x, rows, C, g.tpr, g.rpp, g.rpc, acc);
 }
 
@@ -231,6 +244,7 @@ void bn_finalize(const Ctx& ctx, const float* acc, long rows, int C, const float
 template <int DT, int VE>
 __global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long rows, int C, int tpr, int rpp, int rpc,
                                                     const float* sc, const float* sh, int relu) {
+  constexpr int UNR = UNR1;
   STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
   for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
     const int vc = vc0 + tc;
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long
 
 void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu) {
   const int ve = col_ve(ctx, C);
-  ColGeom g = col_geom(C, ve, rows, 1);
+  ColGeom g = col_geom(UNR1, C, ve, rows, 1);
   COL_DISPATCH(ctx, ve, affine_act_k, dim3(g.chunks), 0, x, y, rows, C, g.tpr, g.rpp, g.rpc, sc, sh, relu);
 }
 
@@ -269,6 +283,7 @@ template <int DT, int VE>
 __global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void* x, long rows, int C, const float* mean,
                                                       const float* rstd, const float* sc, const float* sh, int relu,
                                                       int tpr, int rpp, int rpc, float* sums) {
+  constexpr int UNR = UNR2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
   for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void
 void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
                   const float* sc, const float* sh, int relu, float* sums) {
   const int ve = col_ve(ctx, C);
-  ColGeom g = col_geom(C, ve, rows, 1, 768);
+  ColGeom g = col_geom(UNR2, C, ve, rows, 1, 768);
   COL_DISPATCH(ctx, ve, bn_bwd_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), dy, x, rows, C, mean, rstd, sc, sh, relu,
                g.tpr, g.rpp, g.rpc, sums);
 }
@@ -326,6 +341,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const void* dy, const void
                                                       int rpp, int rpc, const float* mean, const float* rstd,
                                                       const float* sc, const float* sh, const float* sums, int relu,
                                                       int has_bn, int training) {
+  constexpr int UNR = UNR2;
   STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
   const float inv = 1.f / (float)rows;
   for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const void* dy, const void
 void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long rows, int C, const float* mean,
                   const float* rstd, const float* sc, const float* sh, const float* sums, int relu, int has_bn, int training) {
   const int ve = col_ve(ctx, C);
-  ColGeom g = col_geom(C, ve, rows, 1);
+  ColGeom g = col_geom(UNR2, C, ve, rows, 1);
   COL_DISPATCH(ctx, ve, bn_bwd_apply_k, dim3(g.chunks), 0, dy, x, dx, rows, C, g.tpr, g.rpp, g.rpc, mean, rstd, sc, sh, sums,
                relu, has_bn, training);
 }
@@ -379,6 +395,7 @@ void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long 
 template <int DT, int VE>
 __global__ __launch_bounds__(256) void scale_cols_k(const void* x, void* y, int N, int C, int tpr, int rpp, int rpc,
                                                     const float* colw, float add) {
+  constexpr int UNR = UNR1;
   const int b = blockIdx.y;
   STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
   for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(256) void scale_cols_k(const void* x, void* y, int 
 }
 void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* colw, float add) {
   const int ve = col_ve(ctx, C);
-  ColGeom g = col_geom(C, ve, N, B);
+  ColGeom g = col_geom(UNR1, C, ve, N, B);
   COL_DISPATCH(ctx, ve, scale_cols_k, dim3(g.chunks, B), 0, x, y, N, C, g.tpr, g.rpp, g.rpc, colw, add);
 }
 
@@ -417,6 +434,7 @@ template <int DT, int VE>
 __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, int N, int C, int tpr, int rpp, int rpc,
                                                         const float* roww, const void* colw, int cdt,
                                                         const float* colw2, float scale, float* colsum_out) {
+  constexpr int UNR = UNR1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y;
   STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
@@ -468,7 +486,7 @@ void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C,
   const int ve = col_ve(ctx, C);
   int cap = 4096;
   if (colsum_out) COL_CAPACITY(cap, ctx, ve, relu_bwd_scale_k, (size_t)C * sizeof(float));
-  ColGeom g = col_geom(C, ve, N, B, cap, colsum_out != nullptr);
+  ColGeom g = col_geom(UNR1, C, ve, N, B, cap, colsum_out != nullptr);
   COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), (size_t)C * sizeof(float), x, y, N, C, g.tpr, g.rpp, g.rpc, roww,
                colw, cdt, colw2, scale, colsum_out);
 }
@@ -477,6 +495,7 @@ void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C,
 template <int DT, int VE>
 __global__ __launch_bounds__(256) void xc_bwd_k(const void* dXc, const void* X1, void* dX1, int N, int C, const float* ch,
                                                 int tpr, int rpp, int rpc, float* dch) {
+  constexpr int UNR = UNR3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y;
   STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
@@ -517,7 +536,7 @@ void xc_bwd(const Ctx& ctx, const void* dXc, const void* X1, void* dX1, int B, i
   const int ve = col_ve(ctx, C);
   int cap = 768;
   COL_CAPACITY(cap, ctx, ve, xc_bwd_k, (size_t)C * sizeof(float));
-  ColGeom g = col_geom(C, ve, N, B, cap, true);
+  ColGeom g = col_geom(UNR3, C, ve, N, B, cap, true);
   COL_DISPATCH(ctx, ve, xc_bwd_k, dim3(g.chunks, B), (size_t)C * sizeof(float), dXc, X1, dX1, N, C, ch, g.tpr, g.rpp, g.rpc, dch);
 }
 
