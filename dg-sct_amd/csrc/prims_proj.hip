@@ -262,7 +262,7 @@ void gproj_wide(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, 
   if (stats) {          // a reduction: one full round of resident workgroups (see wg_capacity)
     const bool big0 = ds / g > 8;
     const void* fn = ctx.mode == DT_BF16
-        ? (big0 ? reinterpret_cast<const void*>(&gproj_wide_k<DT_BF16, 8, 16, 2>) : reinterpret_cast<const void*>(&gproj_wide_k<DT_BF16, 8, 8, 4>))
+        ? (big0 ? reinterpret_cast<const void*>(&gproj_wide_k<DT_BF16, 8, 16, 2>) : reinterpret_cast<const void*>(&gproj_wide_k<DT_BF16, 8, 8, 8>))
         : (big0 ? reinterpret_cast<const void*>(&gproj_wide_k<DT_F32, 4, 16, 2>) : reinterpret_cast<const void*>(&gproj_wide_k<DT_F32, 4, 8, 4>));
     target = wg_capacity(fn, 0);
     if (target > 1024) target = 1024;
@@ -275,7 +275,7 @@ void gproj_wide(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, 
 #define WIDE_(DT_, VE_, DG_, UNR_) \
   hipLaunchKernelGGL((gproj_wide_k<DT_, VE_, DG_, UNR_>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc, \
                      pg.gs, pg.rpc, y, stats)
-  if (ctx.mode == DT_BF16) { if (big) WIDE_(DT_BF16, 8, 16, 2); else WIDE_(DT_BF16, 8, 8, 4); }
+  if (ctx.mode == DT_BF16) { if (big) WIDE_(DT_BF16, 8, 16, 2); else WIDE_(DT_BF16, 8, 8, 8); }
   else { if (big) WIDE_(DT_F32, 4, 16, 2); else WIDE_(DT_F32, 4, 8, 4); }
 #undef WIDE_
 }
