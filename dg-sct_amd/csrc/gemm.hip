@@ -576,7 +576,7 @@ void gemm_kernel(const GemmK p) {
         }
       }
       __syncthreads();
-#pragma unroll 1
+#pragma unroll 3
       for (int it = 0; it < (32 * CPR) / 64; ++it) {
         const int c = it * 64 + lane;
         const int row = c / CPR, cc = c % CPR;
