@@ -227,6 +227,11 @@ void modln_fwd(const Ctx& ctx, const void* X1, const float* ch, const float* sg,
                float gamma, const float* lnw, const float* lnb, float eps, int B, int N, int C, void* X3, float* mu,
                float* rstd) {
   RowGeom g = row_geom(C, row_ve(ctx, C), N, B);
+  {                                                   // one full round of resident workgroups (2080 on 2048 slots = 2 rounds)
+    int cap = 2048;
+    ROW_CAPACITY(cap, ctx, C, g.nv, modln_fwd_k, 0);
+    g = row_geom(C, row_ve(ctx, C), N, B, cap, 1, true);
+  }
   ROW_DISPATCH(ctx, C, g.nv, modln_fwd_k, dim3(g.chunks, B), X1, ch, sg, tg, alpha, beta, gamma, lnw, lnb, eps, N, C, g.gs, g.nv,
                g.rpc, X3, mu, rstd);
 }
@@ -429,6 +434,11 @@ void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2
               const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd,
               const void* residual) {
   RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1);
+  {
+    int cap = 2048;
+    ROW_CAPACITY(cap, ctx, C, g.nv, tail_fwd_k, 0);
+    g = row_geom(C, row_ve(ctx, C), (int)rows, 1, cap, 1, true);
+  }
   ROW_DISPATCH(ctx, C, g.nv, tail_fwd_k, dim3(g.chunks), Op, sc2, sh2, lnw, lnb, gate, gate_first, eps, rows, C, g.gs, g.nv, g.rpc,
                out, mu, rstd, residual);
 }
@@ -636,6 +646,11 @@ void rowdot_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int 
   int ve = row_ve(ctx, C);
   if (ld % ve != 0 || bs % ve != 0) { set_error("rowdot_batched: unaligned ld/bs"); return; }
   RowGeom g = row_geom(C, ve, N, B);
+  {
+    int cap = 2048;
+    ROW_CAPACITY(cap, ctx, C, g.nv, rowdot_k, 0);
+    g = row_geom(C, ve, N, B, cap, 1, true);
+  }
   ROW_DISPATCH(ctx, C, g.nv, rowdot_k, dim3(g.chunks, B), x, ld, bs, N, C, w, wdt, w_bs, w2, bias, g.gs, g.nv, g.rpc, out);
 }
 
