@@ -10,6 +10,9 @@
 //   `prep`   : MFMA-operand (E) copies of the weights + three derived bias vectors.
 #include "plan.h"
 
+#include <functional>
+#include <vector>
+
 #include <cstdio>
 #include <cstring>
 
@@ -461,11 +464,21 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   b.ctx.aux = aux_stream;
   const Ctx& ctx = b.ctx;
   // Weight / bias gradients feed nothing downstream: they go to the aux stream (when given) and overlap the data-gradient
-  // chain.  side_begin() makes aux wait for everything enqueued so far (the operands); the final join orders it all
+  // chain.  A fork makes aux wait for everything enqueued so far (the operands); the final join orders it all
   // before the caller's next use of `grads` / `ws`.
   Ctx side = ctx;
   if (aux_stream) { side.stream = aux_stream; side.aux = nullptr; }
-  auto side_begin = [&]() { stream_fork(ctx); };
+  // A fork costs the MAIN stream ~6.5 us (the event record is a barrier packet in its queue), so gradient-only work is
+  // queued with defer() and released in groups: side_flush() records one event and enqueues everything pending.  Deferred
+  // work only reads buffers nothing overwrites before the final join (no workspace aliasing in the backward layout).
+  std::vector<std::function<void()>> pend;
+  auto defer = [&](std::function<void()> f) { pend.push_back(std::move(f)); };
+  auto side_flush = [&]() {
+    if (pend.empty()) return;
+    stream_fork(ctx);
+    for (auto& f : pend) f();
+    pend.clear();
+  };
   auto G = [&](int id) -> float* { return grad_off[id] >= 0 ? grads + grad_off[id] : nullptr; };
   zero(ctx, b.Wk(0), (size_t)wb.zero_end);
   zero(ctx, grads, (size_t)grad_floats * 4);
@@ -491,8 +504,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g1.B = mn(b.S(s.Z), ds, dg);
     outF(g1, G(DGSCT_P_WU), dg, (long)cg * dg);
     atomic_out(g1);
-    side_begin();
-    gemm(side, g1);
+    defer([=, &side] { gemm(side, g1); });                       // released with dWd
     if (vproj) {                                                 // dZ = dOp (x)_g Wu
       gproj_narrow(ctx, dO, R, C, ds, g, b.F(DGSCT_P_WU), (long)cg * dg, 1, dg, b.Wk(wb.dZ));
     } else {
@@ -517,8 +529,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g1.B = mn(b.S(s.X3), C, cg);
     outF(g1, G(DGSCT_P_WD), cg, (long)dg * cg);
     atomic_out(g1);
-    side_begin();
-    gemm(side, g1);
+    defer([=, &side] { gemm(side, g1); });
+    side_flush();
     if (vproj) {                                                 // dX3 = dZp (x)_g Wd
       gproj_wide(ctx, dZ, R, C, ds, g, b.F(DGSCT_P_WD), (long)dg * cg, cg, 1, b.Wk(wb.dX3), nullptr);
     } else {
@@ -540,8 +552,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                 b.Wk<float>(wb.dsl), G(DGSCT_P_BS));
     colsum_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd);  // u
     ew(ctx, EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1);
-    side_begin();
-    sum_batch(side, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 1);                // dws (a gradient: off the chain)
+    defer([=, &side, &b] { sum_batch(side, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 1); });   // dws
     ew(ctx, EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd);
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
     relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
@@ -556,8 +567,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g2.B = mn(b.S(s.Xc), C);
     outF(g2, G(DGSCT_P_WV2), C);
     atomic_out(g2);
-    side_begin();
-    gemm(side, g2);
+    defer([=, &side] { gemm(side, g2); });
+    side_flush();
     xc_bwd(ctx, b.Wk(wb.dXc), b.S(s.X1), dX1, B, N, C, b.S<float>(s.ch), b.Wk<float>(wb.dch));
   }
   // B6 ---- channel-gate head
@@ -566,9 +577,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g1 = mk(C, dd, B);                                      // dWcatt = dpre^T . q
     g1.A = mn(b.Wk(wb.dpre_c), C); g1.B = mn(b.S(s.q), dd);
     outF(g1, G(DGSCT_P_WCATT), dd);
-    side_begin();
-    gemm(side, g1);
-    colsum_batched(side, b.Wk(wb.dpre_c), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BCATT), 0);
+    defer([=, &side, &b] {
+      gemm(side, g1);
+      colsum_batched(side, b.Wk(wb.dpre_c), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BCATT), 0);
+    });
     Gemm g2 = mk(B, dd, C);                                      // dq = (dpre . Wcatt) * (q > 0)
     g2.A = km(b.Wk(wb.dpre_c), C); g2.B = mn(b.W(DGSCT_P_WCATT), dd);
     g2.mask = b.S(s.q); g2.ldmask = dd;
@@ -577,9 +589,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g3 = mk(dd, C, B);                                      // dWb = dq^T . m1
     g3.A = mn(b.Wk(wb.dq), dd); g3.B = mn(b.S(s.m1), C);
     outF(g3, G(DGSCT_P_WB), C);
-    side_begin();
-    gemm(side, g3);
-    colsum_batched(side, b.Wk(wb.dq), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BB), 0);
+    defer([=, &side, &b] {
+      gemm(side, g3);
+      colsum_batched(side, b.Wk(wb.dq), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BB), 0);
+    });
     Gemm g4 = mk(B, C, dd);                                      // dm1 = dq . Wb
     g4.A = km(b.Wk(wb.dq), dd); g4.B = mn(b.W(DGSCT_P_WB), C);
     outF(g4, b.Wk<float>(wb.dm1), C);
@@ -600,23 +613,25 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g2.A = mn(b.S(s.vq1), C); g2.B = mn(b.S(s.X1), C);
     outF(g2, G(DGSCT_P_WV1), C);
     atomic_out(g2);
-    side_begin();
-    gemm(side, g2);
+    defer([=, &side] { gemm(side, g2); });
   }
   // B4 ---- audio queries
   {
     Gemm g1 = mk(C, C, B);                                       // dWa1 = dpa1^T . a
     g1.A = mn(b.Wk(wb.dpa1), C); g1.B = mn(b.S(s.aE), C);
     outF(g1, G(DGSCT_P_WA1), C);
-    side_begin();
-    gemm(side, g1);
-    colsum_batched(side, b.Wk(wb.dpa1), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BA1), 0);
+    defer([=, &side, &b] {
+      gemm(side, g1);
+      colsum_batched(side, b.Wk(wb.dpa1), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BA1), 0);
+    });
     Gemm g2 = mk(dd, C, B);                                      // dWa2 = dpa2^T . a
     g2.A = mn(b.Wk(wb.dpa2), dd); g2.B = mn(b.S(s.aE), C);
     outF(g2, G(DGSCT_P_WA2), C);
-    side_begin();
-    gemm(side, g2);
-    colsum_batched(side, b.Wk(wb.dpa2), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BA2), 0);
+    defer([=, &side, &b] {
+      gemm(side, g2);
+      colsum_batched(side, b.Wk(wb.dpa2), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BA2), 0);
+    });
+    side_flush();                                                // dWcatt, dWb, dWv1, dWa1, dWa2 and their biases
     Gemm g3 = mk(B, C, C);                                       // da = dpa1 . Wa1 + dpa2 . Wa2
     g3.A = km(b.Wk(wb.dpa1), C); g3.B = mn(b.W(DGSCT_P_WA1), C);
     outF(g3, b.Wk<float>(wb.da), C);
@@ -661,8 +676,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     resid(g2, dX1, E, C, (long)N * C);
     if (skip_into_dx) g2.R2 = dOut;                              // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
     outE(g2, dX, E, C, (long)N * C);
-    side_begin();                                                // dX is an OUTPUT: nothing below reads it, and dX1 / dS2 / tok
-    gemm(side, g2);                                              // are not written again -> aux stream, off the chain
+    defer([=, &side] { gemm(side, g2); });                       // dX is an OUTPUT: nothing below reads it, and dX1 / dS2 /
+    side_flush();                                                // tok are not written again -> aux stream, off the chain
     Gemm g3 = mk(tk, C, N, B);                                   // dtok = gate_av * P2^T . dX1
     g3.A = mn(b.S(s.P2), tkp, (long)N * tkp);
     g3.B = mn(dX1, C, (long)N * C);
@@ -700,8 +715,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     resid(g2, b.Wk(wb.dtokF), DT_F32, C, (long)tk * C);
     outF(g2, b.Wk<float>(wb.dtokF), C, (long)tk * C);
     gemm(ctx, g2);
-    side_begin();
-    sum_batch(side, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
+    defer([=, &side, &b] { sum_batch(side, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1); });
     ew(ctx, EW_SCALE, b.Wk(wb.daN), DT_F32, F32(b.Wk(wb.da)), NOARG, NOARG, (long)B * C, 1.f / (float)N, 1);
     Gemm g3 = mk(N, C, tk, B);                                   // dYp = P1^T . dtok + da/N
     g3.A = mn(b.S(s.P1), Np, (long)tk * Np);
@@ -719,30 +733,31 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B1 ---- remap
   {
     const bool conv = d.remap == DGSCT_REMAP_CONV;
-    side_begin();                                                // bias gradients of the remap: gradients only -> aux stream
-    if (conv) {
-      rowdot_batched(side, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
-      sum_batch(side, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                            // dbn
-      colsum_batched(side, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);   // d rowsum(Wc)
-    } else {
-      colsum_batched(side, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);
-    }
+    // gradients only -> aux stream: the remap's bias gradients and whichever weight gradient needs nothing but dYp
+    defer([=, &side, &b] {
+      if (conv) {
+        rowdot_batched(side, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
+        sum_batch(side, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                            // dbn
+        colsum_batched(side, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);   // d rowsum(Wc)
+      } else {
+        colsum_batched(side, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);
+      }
+    });
     if (orderA) {
-      Gemm g1 = mk((int)R, Co, C);                               // dT1 = dYp . Wc
-      g1.A = km(dYp, C); g1.B = mn(b.W(DGSCT_P_WC), Co);
-      outE(g1, b.Wk(wb.dT), E, Co);
-      gemm(ctx, g1);
       Gemm g2 = mk(C, Co, (int)R);                               // dWc = dYp^T . T1
       g2.A = mn(dYp, C); g2.B = mn(b.S(s.T), Co);
       outF(g2, G(DGSCT_P_WC), Co);
       atomic_out(g2);
-      side_begin();
-      gemm(side, g2);
+      defer([=, &side] { gemm(side, g2); });
+      side_flush();
+      Gemm g1 = mk((int)R, Co, C);                               // dT1 = dYp . Wc
+      g1.A = km(dYp, C); g1.B = mn(b.W(DGSCT_P_WC), Co);
+      outE(g1, b.Wk(wb.dT), E, Co);
+      gemm(ctx, g1);
       Gemm g3 = mk(No, Co, N, B);                                // dY[b] = Wn^T . dT1[b]
       g3.A = mn(b.W(DGSCT_P_WN), No);
       g3.B = mn(b.Wk(wb.dT), Co, (long)N * Co);
       outE(g3, dY, E, Co, (long)No * Co);
-      gemm(ctx, g3);
       if (conv) {
         Gemm g4 = mk(N, No, Co);                                 // dWn = sum_b dT1[b] . Y[b]^T
         g4.KB = B;
@@ -750,15 +765,11 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         g4.B = km(Y, Co, 0, (long)No * Co);
         outF(g4, G(DGSCT_P_WN), No);
         atomic_out(g4);
-        side_begin();
-        gemm(side, g4);
+        defer([=, &side] { gemm(side, g4); });
+        side_flush();
       }
+      gemm(ctx, g3);
     } else {
-      Gemm g1 = mk(No, C, N, B);                                 // dT2[b] = Wn^T . dYp[b]     [No][C] token-major
-      g1.A = mn(b.W(DGSCT_P_WN), No);                            //   (M = No, N = C: the 128x96 remap tile; the transposed
-      g1.B = mn(dYp, C, (long)N * C);                            //    form M = C = 96 runs at half the rate)
-      outE(g1, b.Wk(wb.dT), E, C, (long)No * C);
-      gemm(ctx, g1);
       if (conv) {
         Gemm g2 = mk(N, No, C);                                  // dWn = sum_b dYp[b] . T2[b]^T
         g2.KB = B;
@@ -766,26 +777,32 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         g2.B = mn(b.S(s.T), Nop, 0, (long)C * Nop);
         outF(g2, G(DGSCT_P_WN), No);
         atomic_out(g2);
-        side_begin();
-        gemm(side, g2);
+        defer([=, &side] { gemm(side, g2); });
       }
-      Gemm g3 = mk(No, Co, C, B);                                // dY[b] = dT2[b] . Wc
-      g3.A = km(b.Wk(wb.dT), C, (long)No * C);
-      g3.B = mn(b.W(DGSCT_P_WC), Co);
-      outE(g3, dY, E, Co, (long)No * Co);
-      gemm(ctx, g3);
+      side_flush();
+      Gemm g1 = mk(No, C, N, B);                                 // dT2[b] = Wn^T . dYp[b]     [No][C] token-major
+      g1.A = mn(b.W(DGSCT_P_WN), No);                            //   (M = No, N = C: the 128x96 remap tile; the transposed
+      g1.B = mn(dYp, C, (long)N * C);                            //    form M = C = 96 runs at half the rate)
+      outE(g1, b.Wk(wb.dT), E, C, (long)No * C);
+      gemm(ctx, g1);
       Gemm g4 = mk(C, Co, No);                                   // dWc = sum_b dT2[b]^T . Y[b]
       g4.KB = B;
       g4.A = mn(b.Wk(wb.dT), C, 0, (long)No * C);
       g4.B = mn(Y, Co, 0, (long)No * Co);
       outF(g4, G(DGSCT_P_WC), Co);
       atomic_out(g4);
-      side_begin();
-      gemm(side, g4);
+      defer([=, &side] { gemm(side, g4); });
+      side_flush();
+      Gemm g3 = mk(No, Co, C, B);                                // dY[b] = dT2[b] . Wc
+      g3.A = km(b.Wk(wb.dT), C, (long)No * C);
+      g3.B = mn(b.W(DGSCT_P_WC), Co);
+      outE(g3, dY, E, Co, (long)No * Co);
+      gemm(ctx, g3);
     }
     if (conv)   // + d rowsum(Wc)[c] broadcast over co
       ew(side, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
   }
+  side_flush();
   stream_join(ctx);
   return has_error() ? 1 : 0;
 }
