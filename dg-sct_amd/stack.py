@@ -47,7 +47,6 @@ class AdapterStack(nn.Module):
         super().__init__()
         self.concurrent = concurrent
         self.fuse_residual = fuse_residual        # `f = f + adapter(...)` inside the adapter's last kernel (8f row f2)
-        self._side_streams = {}
         self.opt = opt or default_opt()
         o = self.opt
         self.stages = [dict(s) for s in stages]
@@ -101,11 +100,8 @@ class AdapterStack(nn.Module):
         dev = feats[0][0].device
         side = None
         if self.concurrent and dev.type == "cuda":
-            side = self._side_streams.get(dev.index)
-            if side is None:
-                from . import _lib, ops
-                lib = self.audio_adapter_blocks_p1[0]._lib or _lib.default_lib()
-                side = self._side_streams[dev.index] = ops.priority_stream(lib, dev, ops.COMPUTE_PRIORITY_CLASS)
+            from . import _lib, ops
+            side = ops.side_stream(self.audio_adapter_blocks_p1[0]._lib or _lib.default_lib(), dev)
 
         fuse = self.fuse_residual
 
