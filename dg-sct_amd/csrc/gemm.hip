@@ -24,6 +24,8 @@
 #include <vector>
 #include "prims.h"
 #include "device_util.h"
+#include <cmath>
+
 #include "err.h"
 
 namespace dgsct {
@@ -36,6 +38,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 struct GemmK {
   int M, N, K, KB;
   int tiles_m, tiles_n, kflat, kt_total, kt_per_split; unsigned kinv;
+  int xgm, xnb;                    // batched GEMM with a SHARED A: m-tiles per group / batches per XCD (0: plain order)
   const char* A; long lda, a_bs, a_kbs; int a_vec;
   const char* B; long ldb, b_bs, b_kbs; int b_vec;
   char* D; int ddt; long ldd, dbs;
@@ -329,15 +332,31 @@ void gemm_kernel(const GemmK p) {
 
   // XCD-aware tile order: hardware round-robins consecutive workgroup ids over the 8 XCDs; give each XCD a
   // contiguous run of tiles so operand panels shared by neighbouring tiles stay in ONE private L2 (bijective).
-  const int ntile = p.tiles_m * p.tiles_n;
-  int t = blockIdx.x;
-  {
-    const int q = ntile >> 3, r = ntile & 7, x = t & 7, y = t >> 3;
-    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  int tm, tn, b;
+  if (p.xgm > 0) {
+    // Batched product with ONE A for every batch (the remap: Wn . Y_b): the 8 XCDs split the BATCHES (workgroup id mod
+    // 8 is the XCD), and an XCD walks its batches m-group by m-group, so the workgroups resident on it at any time are
+    // xgm m-panels of A x (resident / xgm) batches of B -- the mix that minimises what its private L2 has to fetch
+    // (in plain launch order every XCD streams ALL of A once per ~3 batches: 7-13x the algorithmic bytes, measured).
+    const int L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int c = L & 7, sl = L >> 3;
+    const int G = p.xgm * p.xnb;
+    const int mg = sl / G, rem = sl - mg * G;
+    int gs = p.tiles_m - mg * p.xgm; gs = gs < p.xgm ? gs : p.xgm;
+    const int bb = rem / gs;
+    tm = __builtin_amdgcn_readfirstlane(mg * p.xgm + (rem - bb * gs)); tn = 0;      // (the divisions run on the VALU:
+    b = __builtin_amdgcn_readfirstlane(c * p.xnb + bb);                              //  back to scalar registers)
+  } else {
+    const int ntile = p.tiles_m * p.tiles_n;
+    int t = blockIdx.x;
+    {
+      const int q = ntile >> 3, r = ntile & 7, x = t & 7, y = t >> 3;
+      t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    tm = t % p.tiles_m; tn = t / p.tiles_m;
+    b = blockIdx.y;
   }
-  const int tm = t % p.tiles_m, tn = t / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int b = blockIdx.y;
   const int kt_begin = blockIdx.z * p.kt_per_split;
   int kt_end = kt_begin + p.kt_per_split;
   if (kt_end > p.kt_total) kt_end = p.kt_total;
@@ -829,6 +848,18 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   k.kt_per_split = (k.kt_total + splitk - 1) / splitk;
   splitk = (k.kt_total + k.kt_per_split - 1) / k.kt_per_split;
   dim3 grid(k.tiles_m * k.tiles_n, g.batch, splitk);
+  k.xgm = k.xnb = 0;
+  static const bool no_xgroup = getenv("DGSCT_GEMM_NOXGROUP") != nullptr;
+  if (!no_xgroup && g.A.bs == 0 && g.B.bs != 0 && g.batch >= 16 && g.batch % 8 == 0 && k.tiles_n == 1 && k.tiles_m >= 2 && splitk == 1 &&
+      kflat >= 512) {
+    const int resident = (cfg == 5 ? 1 : (cfg == 0 && ak != bk) ? 2 : 3) * 32;          // workgroups per XCD (launch bounds)
+    int gm = (int)(sqrt((double)resident * g.N / BMs[cfg]) + 0.5);
+    if (gm < 1) gm = 1;
+    if (gm > k.tiles_m) gm = k.tiles_m;
+    const int ngroups = (k.tiles_m + gm - 1) / gm;
+    k.xgm = (k.tiles_m + ngroups - 1) / ngroups;
+    k.xnb = g.batch / 8;
+  }
   hipStream_t s = (hipStream_t)ctx.stream;
   ProfRec shp{};
   shp.M = g.M; shp.N = g.N; shp.K = g.K; shp.KB = g.KB; shp.batch = g.batch; shp.splitk = splitk; shp.cfg = cfg;

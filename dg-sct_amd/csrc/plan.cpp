@@ -733,16 +733,9 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B1 ---- remap
   {
     const bool conv = d.remap == DGSCT_REMAP_CONV;
-    // gradients only -> aux stream: the remap's bias gradients and whichever weight gradient needs nothing but dYp
-    defer([=, &side, &b] {
-      if (conv) {
-        rowdot_batched(side, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
-        sum_batch(side, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                            // dbn
-        colsum_batched(side, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);   // d rowsum(Wc)
-      } else {
-        colsum_batched(side, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);
-      }
-    });
+    // The two weight gradients go to the aux stream as soon as their operands exist; the remap's BIAS gradients (three
+    // small reductions over dYp) stay on the main stream, after dY: the tail of the call is then ~balanced between the
+    // two streams (they used to queue behind each other on aux while main sat in the final join).
     if (orderA) {
       Gemm g2 = mk(C, Co, (int)R);                               // dWc = dYp^T . T1
       g2.A = mn(dYp, C); g2.B = mn(b.S(s.T), Co);
@@ -799,11 +792,18 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       outE(g3, dY, E, Co, (long)No * Co);
       gemm(ctx, g3);
     }
-    if (conv)   // + d rowsum(Wc)[c] broadcast over co
-      ew(side, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
+    if (conv) {
+      rowdot_batched(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
+      sum_batch(ctx, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                            // dbn
+      colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);   // d rowsum(Wc)
+    } else {
+      colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);
+    }
   }
   side_flush();
   stream_join(ctx);
+  if (d.remap == DGSCT_REMAP_CONV)   // + d rowsum(Wc)[c] broadcast over co (after the join: dWc is accumulated on aux)
+    ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
   return has_error() ? 1 : 0;
 }
 

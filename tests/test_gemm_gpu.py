@@ -158,6 +158,16 @@ def test_gemm_deep_tiles_and_shared_operand():
     run_case(1, 256, 256, 96, 1, 0, batch=1, KB=40, atomic=True, splitk=0)       # dWn-style: two-level K, 128 x 128, split-K
 
 
+@pytest.mark.parametrize("ak", [1, 0])
+def test_gemm_shared_a_xcd_grouped_order(ak):
+    """Shared A, batch a multiple of 8, one column of tiles, deep K: the launch order is regrouped per XCD (m-groups x
+    batches); every (tile, batch) must still be computed exactly once -- 256 x 96 tiles (5 of them: a partial last
+    group), 128 x 96 tiles (9), and 64 x 64 fp32."""
+    run_case(1, 1280, 96, 640, ak, 1, batch=16, shared_a=True, out_bf16=True)
+    run_case(1, 1100, 96, 576, ak, 0, batch=24, shared_a=True, out_bf16=True)
+    run_case(0, 200, 40, 512, ak, 1, batch=16, shared_a=True)
+
+
 @pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("tk", [32, 12, 4])
 def test_gemm_softmax_epilogues(mode, tk):
