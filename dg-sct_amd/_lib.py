@@ -58,7 +58,7 @@ class GemmArgs(C.Structure):
 
 EXPORTS = ["dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
            "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect",
-           "dgsct_stream_create", "dgsct_stream_destroy"]
+           "dgsct_stream_create", "dgsct_stream_destroy", "dgsct_map_pool_forward", "dgsct_map_pool_backward"]
 
 _PP = C.POINTER(C.c_void_p)
 
@@ -94,6 +94,8 @@ class Lib:
         c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
         c.dgsct_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         c.dgsct_stream_destroy.argtypes = [C.c_void_p]
+        c.dgsct_map_pool_forward.argtypes = [C.c_int] * 4 + [C.c_void_p] * 4
+        c.dgsct_map_pool_backward.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6
         if c.dgsct_version() != 100:
             raise RuntimeError("dg-sct_amd: libdgsct version mismatch")
 
@@ -142,6 +144,12 @@ class Lib:
         out = C.c_void_p()
         self._check(self.c.dgsct_stream_create(int(priority_class), C.byref(out)), "dgsct_stream_create")
         return int(out.value or 0)
+
+    def map_pool_forward(self, dtype: int, BT: int, N: int, C_: int, F: int, amap: int, pooled: int, stream: int):
+        self._check(self.c.dgsct_map_pool_forward(dtype, BT, N, C_, F, amap, pooled, stream), "dgsct_map_pool_forward")
+
+    def map_pool_backward(self, dtype: int, BT: int, N: int, C_: int, F: int, amap: int, dpooled: int, dF, dmap, stream: int):
+        self._check(self.c.dgsct_map_pool_backward(dtype, BT, N, C_, F, amap, dpooled, dF, dmap, stream), "dgsct_map_pool_backward")
 
     def prof_enable(self, on: bool):
         self.c.dgsct_prof_enable(int(on))

@@ -114,6 +114,33 @@ int dgsct_stream_destroy(void* stream) {
   return has_error() ? 1 : 0;
 }
 
+static int pool_args_ok(int dtype, int BT, int N, int C, const void* F, const float* map) {
+  if ((dtype != DGSCT_F32 && dtype != DGSCT_BF16) || BT <= 0 || N <= 0 || C <= 0 || C % 4 != 0 || !F || !map) {
+    set_error("map_pool: dtype must be DGSCT_F32 / DGSCT_BF16, BT, N, C positive, C a multiple of 4, F and map non-null");
+    return 0;
+  }
+  return 1;
+}
+
+int dgsct_map_pool_forward(int dtype, int BT, int N, int C, const void* F, const float* map, float* pooled, void* stream) {
+  clear_error();
+  if (!pool_args_ok(dtype, BT, N, C, F, map) || !pooled) { if (!has_error()) set_error("map_pool: pooled is null"); return 2; }
+  Ctx ctx{stream, dtype};
+  zero(ctx, pooled, (size_t)BT * C * sizeof(float));
+  colsum_batched(ctx, F, C, (long)N * C, BT, N, C, map, N, 1.f, pooled, C);
+  return has_error() ? 1 : 0;
+}
+
+int dgsct_map_pool_backward(int dtype, int BT, int N, int C, const void* F, const float* map, const float* dPooled,
+                            void* dF, float* dMap, void* stream) {
+  clear_error();
+  if (!pool_args_ok(dtype, BT, N, C, F, map) || !dPooled) { if (!has_error()) set_error("map_pool: dPooled is null"); return 2; }
+  Ctx ctx{stream, dtype};
+  if (dF) outer_rows(ctx, map, dPooled, BT, N, C, dF);
+  if (dMap) rowdot_batched(ctx, F, C, (long)N * C, BT, N, C, dPooled, DT_F32, C, nullptr, nullptr, dMap);
+  return has_error() ? 1 : 0;
+}
+
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
   clear_error();
   if (!a) return 2;

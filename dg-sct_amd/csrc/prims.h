@@ -92,6 +92,8 @@ void rowdot_batched(const Ctx&, const void* x, long ld, long bs, int B, int N, i
 void sum_batch(const Ctx&, const float* in, long bs, int B, long n, float* out, float scale, int accumulate);
 // y[b][n][c] = x[b][n][c] * (add + colw[b][c])         x,y are E (may alias)
 void scale_cols(const Ctx&, const void* x, void* y, int B, int N, int C, const float* colw, float add);
+// y[b][n][c] = roww[b][n] * colw[b][c]                       y is E (the backward of a map-weighted token pooling)
+void outer_rows(const Ctx&, const float* roww, const float* colw, int B, int N, int C, void* y);
 // y[b][n][c] = (x[b][n][c] > 0) * (roww ? roww[b][n] : 1) * colw[b][c] * (colw2 ? colw2[c] : 1) * scale     x,y E (may alias)
 // If colsum_out: colsum_out[c] += sum_{b,n} y[b][n][c]  (the bias gradient of the layer whose pre-activation x masks).
 void relu_bwd_scale(const Ctx&, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,

@@ -429,6 +429,33 @@ void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, con
   COL_DISPATCH(ctx, ve, scale_cols_k, dim3(g.chunks, B), 0, x, y, N, C, g.tpr, g.rpp, g.rpc, colw, add);
 }
 
+// ---- outer_rows: y[b][n][c] = roww[b][n] * colw[b][c] (write-only stream) ----------------------------------
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void outer_rows_k(void* y, int N, int C, int tpr, int rpp, int rpc, const float* roww,
+                                                    const float* colw) {
+  const int b = blockIdx.y;
+  STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    if (!(tr < rpp && vc < nvr)) continue;
+    float cw[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) cw[e] = colw[(long)b * C + vc * VE + e];
+    for (long n = r_begin + tr; n < r_end; n += rpp) {
+      const float w = roww[(long)b * N + n];
+      float t[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) t[e] = w * cw[e];
+      stv<DT, VE>(y, ((long)b * N + n) * C + vc * VE, t);
+    }
+  }
+}
+void outer_rows(const Ctx& ctx, const float* roww, const float* colw, int B, int N, int C, void* y) {
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(UNR1, C, ve, N, B);
+  COL_DISPATCH(ctx, ve, outer_rows_k, dim3(g.chunks, B), 0, y, N, C, g.tpr, g.rpp, g.rpc, roww, colw);
+}
+
 // ---- relu_bwd_scale: y = (x > 0) * roww[b][n] * colw[b][c] * colw2[c] * scale; optional colsum_out[c] += sum y ------
 template <int DT, int VE>
 __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, int N, int C, int tpr, int rpp, int rpc,

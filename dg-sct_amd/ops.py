@@ -352,3 +352,45 @@ def adapter_apply(lib: Lib, spec: AdapterSpec, training: bool, prep: torch.Tenso
     else:
         out, amap, tmap = _AdapterFn.apply(lib, spec, training, prep, skip, residual, X, Y, *params)
     return out, amap, (tmap if spec.temporal else None)
+
+
+# ---- spatial-map pooling of the task heads ------------------------------------------------------
+class _MapPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lib, f, amap):
+        BT, N, C_ = f.shape
+        pooled = torch.empty(BT, C_, dtype=torch.float32, device=f.device)
+        lib.map_pool_forward(0 if f.dtype == torch.float32 else 1, BT, N, C_, f.data_ptr(), amap.data_ptr(), pooled.data_ptr(),
+                             _stream_of(f))
+        ctx.lib = lib
+        ctx.save_for_backward(f, amap)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        f, amap = ctx.saved_tensors
+        BT, N, C_ = f.shape
+        dpooled = dpooled.contiguous().float()
+        _mark_stream_use(f, amap, dpooled)
+        df = torch.empty_like(f) if ctx.needs_input_grad[1] else None
+        dmap = torch.empty_like(amap) if ctx.needs_input_grad[2] else None
+        ctx.lib.map_pool_backward(0 if f.dtype == torch.float32 else 1, BT, N, C_, f.data_ptr(), amap.data_ptr(),
+                                  dpooled.data_ptr(), df.data_ptr() if df is not None else None,
+                                  dmap.data_ptr() if dmap is not None else None, _stream_of(f))
+        return None, df, dmap
+
+
+def map_pool(f: torch.Tensor, spatial_att_maps: torch.Tensor, lib: Optional[Lib] = None) -> torch.Tensor:
+    """Drop-in for `torch.bmm(spatial_att_maps, f)` at the end of the reference's layer loop
+    (DG-SCT/AVE/nets/net_trans.py:922-924): f [BT,N,C] (fp32 | bf16), spatial_att_maps [BT,1,N] (the second output of the
+    last p2 adapter) -> [BT,1,C] in f's dtype.  One HIP reduction forward, two kernels backward (dgsct_map_pool_*)."""
+    if not f.is_cuda:
+        raise RuntimeError("dg-sct_amd: map_pool needs CUDA/HIP tensors (no CPU fallback)")
+    BT, N, C_ = f.shape
+    if spatial_att_maps.shape not in ((BT, 1, N), (BT, N)):
+        raise RuntimeError(f"dg-sct_amd: spatial_att_maps must be [BT,1,N] = [{BT},1,{N}], got {tuple(spatial_att_maps.shape)}")
+    if f.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("dg-sct_amd: map_pool supports float32 and bfloat16 maps")
+    from ._lib import default_lib
+    pooled = _MapPoolFn.apply(lib or default_lib(), f.contiguous(), spatial_att_maps.reshape(BT, N).contiguous().float())
+    return pooled.to(f.dtype).unsqueeze(1)

@@ -152,6 +152,18 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
                               void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream,
                               int skip_into_dx);
 
+/* ---- spatial-map pooling of the task heads ----------------------------------
+ * Replaces `f_v = torch.bmm(f_v_spatial_att_maps, f_v)` / `f_a = torch.bmm(f_a_spatial_att_maps, f_a)`
+ * (DG-SCT/AVE/nets/net_trans.py:922-924; same lines in AVVP/nets/mgn.py and pretrain/nets/net_trans.py): the maps
+ * returned by the LAST p2 adapters pool the final token maps into one feature vector per frame.
+ *   forward : pooled[b][c] = sum_n map[b][n] * F[b][n][c]
+ *   backward: dF[b][n][c]  = map[b][n] * dPooled[b][c];   dMap[b][n] = sum_c F[b][n][c] * dPooled[b][c]
+ * F, dF: [BT][N][C] contiguous, dtype DGSCT_F32 | DGSCT_BF16; map, dMap: fp32 [BT][N]; pooled, dPooled: fp32 [BT][C].
+ * C must be a multiple of 4 (every backbone width is).  Sums are fp32.  dF / dMap may be NULL (not needed).  Asynchronous on `stream`; returns 0 or an error code. */
+int dgsct_map_pool_forward(int dtype, int BT, int N, int C, const void* F, const float* map, float* pooled, void* stream);
+int dgsct_map_pool_backward(int dtype, int BT, int N, int C, const void* F, const float* map, const float* dPooled,
+                            void* dF, float* dMap, void* stream);
+
 /* ---- introspection / test hooks (used by tests/ only) ------------------------------------------ */
 /* i-th named region of the `saved` buffer; returns 0 and fills name/offset/bytes, or 1 past the end. */
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes);

@@ -586,3 +586,16 @@ def forward_autograd(p: Dict[str, Tensor], X: Tensor, Y: Tensor, cfg: AdapterCon
     if not cfg.gate_before_ln_post and gate is not None:
         o = o * gate
     return o, amap, tg
+
+
+def map_pool(F: Tensor, amap: Tensor) -> Tensor:
+    """Spatial-map pooling after the layer loop, DG-SCT/AVE/nets/net_trans.py:922-924 (`f_v = torch.bmm(f_v_spatial_att_maps,
+    f_v)`): F [BT,N,C], amap [BT,1,N] -> [BT,1,C].  Restated as the explicit weighted sum (float64 accumulation)."""
+    return (amap.reshape(F.shape[0], -1, 1).double() * F.double()).sum(dim=1, keepdim=True)
+
+
+def map_pool_bwd(F: Tensor, amap: Tensor, dP: Tensor):
+    """Cotangents of map_pool: dF = amap^T (x) dP, damap[b,0,n] = <F[b,n,:], dP[b,0,:]>."""
+    dF = amap.reshape(F.shape[0], -1, 1).double() * dP.reshape(F.shape[0], 1, -1).double()
+    dmap = (F.double() * dP.reshape(F.shape[0], 1, -1).double()).sum(dim=2).unsqueeze(1)
+    return dF, dmap

@@ -169,6 +169,12 @@ void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, con
       }
 }
 
+void outer_rows(const Ctx& ctx, const float* roww, const float* colw, int B, int N, int C, void* y) {
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < C; ++c) st(y, ctx.mode, ((long)b * N + n) * C + c, roww[(long)b * N + n] * colw[(long)b * C + c]);
+}
+
 void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
                     const float* colw2, float scale, float* colsum_out) {
   for (int b = 0; b < B; ++b)

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu
 from build_emu import build_emu  # noqa: E402
 
 from dgsct_amd._lib import Lib  # noqa: E402
+from oracle import dgsct_oracle as O  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -84,3 +85,24 @@ def test_fused_residual_and_skip(emu, name):
     assert rel_err(r["dY"], fx["dY"]) < tol
     for k, g in fx["grads"].items():
         assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
+
+
+@pytest.mark.parametrize("shape", [(4, 9, 16), (3, 7, 36), (2, 36, 64)])
+def test_map_pool_c_abi_host_loops(emu, shape):
+    """dgsct_map_pool_forward / _backward (net_trans.py:922-924) through the C ABI on the host-loop
+    primitives: argument order, strides and the fp32 [BT,N] / [BT,C] layouts against the oracle restatement."""
+    BT, N, C = shape
+    g = torch.Generator().manual_seed(5)
+    F = torch.randn(BT, N, C, generator=g)
+    amap = torch.softmax(torch.randn(BT, 1, N, generator=g), dim=-1)
+    dP = torch.randn(BT, 1, C, generator=g)
+    m2, dp2 = amap.reshape(BT, N).contiguous(), dP.reshape(BT, C).contiguous()
+    pooled, dF, dmap = torch.empty(BT, C), torch.empty(BT, N, C), torch.empty(BT, N)
+    emu.map_pool_forward(0, BT, N, C, F.data_ptr(), m2.data_ptr(), pooled.data_ptr(), None)
+    emu.map_pool_backward(0, BT, N, C, F.data_ptr(), m2.data_ptr(), dp2.data_ptr(), dF.data_ptr(), dmap.data_ptr(), None)
+    rdF, rdmap = O.map_pool_bwd(F, amap, dP)
+    assert torch.allclose(pooled.double(), O.map_pool(F, amap)[:, 0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dF.double(), rdF, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(dmap.double(), rdmap[:, 0], rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        emu.map_pool_forward(7, BT, N, C, F.data_ptr(), m2.data_ptr(), pooled.data_ptr(), None)
