@@ -147,11 +147,38 @@ __device__ __forceinline__ void ldf(const float* p, long i, float (&v)[VE]) {
 }
 
 // sum over a power-of-two group of GS lanes (GS <= 64) that is aligned inside the wavefront
+// Reductions over aligned groups of gs = 2^k lanes (result in every lane of the group).  Within a 16-lane row the
+// exchange is DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: operand modifiers of the add itself); only the
+// 16 / 32 steps go through ds_bpermute.  The all-bpermute loop cost 6 LDS-crossbar round trips (each followed by
+// s_waitcnt lgkmcnt(0)) per sum, twice per row of the LayerNorm kernels.  Every lane of a quad / half-row / row holds
+// bit-identical partial sums after each step, so the result equals the xor butterfly's.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float group_sum(float x, int gs) {
+  if (gs >= 16) {
+    x += dpp_f<0xB1>(x);      // quad_perm [1,0,3,2]
+    x += dpp_f<0x4E>(x);      // quad_perm [2,3,0,1]
+    x += dpp_f<0x141>(x);     // row_half_mirror
+    x += dpp_f<0x140>(x);     // row_mirror
+    if (gs >= 32) x += __shfl_xor(x, 16, 64);
+    if (gs >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+  }
   for (int o = gs >> 1; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
   return x;
 }
 __device__ __forceinline__ float group_max(float x, int gs) {
+  if (gs >= 16) {
+    x = fmaxf(x, dpp_f<0xB1>(x));
+    x = fmaxf(x, dpp_f<0x4E>(x));
+    x = fmaxf(x, dpp_f<0x141>(x));
+    x = fmaxf(x, dpp_f<0x140>(x));
+    if (gs >= 32) x = fmaxf(x, __shfl_xor(x, 16, 64));
+    if (gs >= 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
+    return x;
+  }
   for (int o = gs >> 1; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
   return x;
 }
