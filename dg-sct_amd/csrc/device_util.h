@@ -169,6 +169,19 @@ __device__ __forceinline__ float group_sum(float x, int gs) {
   for (int o = gs >> 1; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
   return x;
 }
+// two independent sums at once: the exchanges of one overlap the adds of the other, and the bpermute pair shares a wait
+__device__ __forceinline__ void group_sum2(float& a, float& b, int gs) {
+  if (gs >= 16) {
+    a += dpp_f<0xB1>(a);  b += dpp_f<0xB1>(b);
+    a += dpp_f<0x4E>(a);  b += dpp_f<0x4E>(b);
+    a += dpp_f<0x141>(a); b += dpp_f<0x141>(b);
+    a += dpp_f<0x140>(a); b += dpp_f<0x140>(b);
+    if (gs >= 32) { const float ta = __shfl_xor(a, 16, 64), tb = __shfl_xor(b, 16, 64); a += ta; b += tb; }
+    if (gs >= 64) { const float ta = __shfl_xor(a, 32, 64), tb = __shfl_xor(b, 32, 64); a += ta; b += tb; }
+    return;
+  }
+  for (int o = gs >> 1; o > 0; o >>= 1) { const float ta = __shfl_xor(a, o, 64), tb = __shfl_xor(b, o, 64); a += ta; b += tb; }
+}
 __device__ __forceinline__ float group_max(float x, int gs) {
   if (gs >= 16) {
     x = fmaxf(x, dpp_f<0xB1>(x));

@@ -262,9 +262,8 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
     }
   }
   float tsum = 0.f;
-  uint4 pg[MAXNV], px[MAXNV];
-  float psg = 0.f, pmean = 0.f, prs = 1.f;              // per-row scalars travel with the row prefetch (see tail_bwd_k)
-  auto fetch = [&](long row) {
+  // per-row scalars travel with the row prefetch (see tail_bwd_k); two prefetch slots, as there
+  auto fetch = [&](long row, uint4 (&pg)[MAXNV], uint4 (&px)[MAXNV], float& psg, float& pmean, float& prs) {
     psg = sg[row];
     if (lnw) { pmean = mu[row]; prs = rstd[row]; }
 #pragma unroll
@@ -273,13 +272,10 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
       if (v < nv && col < C) { pg[v] = ldraw<DT, VE>(dX3, row * C + col); px[v] = ldraw<DT, VE>(X1, row * C + col); }
     }
   };
-  if (blockIdx.x * rpc + sub < n_end) fetch((long)b * N + blockIdx.x * rpc + sub);
-  for (int n = blockIdx.x * rpc + sub; n < n_end; n += rpp) {
-    const long row = (long)b * N + n;
+  auto body = [&](long row, const uint4 (&pg)[MAXNV], const uint4 (&px)[MAXNV], float psg, float mean, float rs) {
     const float sgv = beta * psg;
     float g[MAXNV][VE], x1[MAXNV][VE], xh[MAXNV][VE];
     float s1 = 0.f, s2 = 0.f;
-    const float mean = pmean, rs = prs;
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
@@ -299,11 +295,7 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
         }
       }
     }
-    if (n + rpp < n_end) fetch(row + rpp);
-    if (lnw) {
-      s1 = group_sum(s1, gs) / C;
-      s2 = group_sum(s2, gs) / C;
-    }
+    if (lnw) { group_sum2(s1, s2, gs); s1 /= C; s2 /= C; }
     float rsum = 0.f;
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
@@ -323,6 +315,28 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
     }
     rsum = group_sum(rsum, gs);
     if (gl == 0) { dsg[row] = beta * rsum; tsum += rsum; }
+  };
+  {
+    uint4 pgA[MAXNV], pxA[MAXNV], pgB[MAXNV], pxB[MAXNV], cg[MAXNV], cx[MAXNV];
+    float sA = 0.f, mA = 0.f, rA = 1.f, sB = 0.f, mB = 0.f, rB = 1.f;
+    const long base = (long)b * N;
+    int n = blockIdx.x * rpc + sub;
+    if (n < n_end) fetch(base + n, pgA, pxA, sA, mA, rA);
+    if (n + rpp < n_end) fetch(base + n + rpp, pgB, pxB, sB, mB, rB);
+    for (; n < n_end; n += 2 * rpp) {
+      float cs = sA, cm_ = mA, cr = rA;
+#pragma unroll
+      for (int v = 0; v < MAXNV; ++v) { cg[v] = pgA[v]; cx[v] = pxA[v]; }
+      if (n + 2 * rpp < n_end) fetch(base + n + 2 * rpp, pgA, pxA, sA, mA, rA);
+      body(base + n, cg, cx, cs, cm_, cr);
+      if (n + rpp < n_end) {
+        cs = sB; cm_ = mB; cr = rB;
+#pragma unroll
+        for (int v = 0; v < MAXNV; ++v) { cg[v] = pgB[v]; cx[v] = pxB[v]; }
+        if (n + 3 * rpp < n_end) fetch(base + n + 3 * rpp, pgB, pxB, sB, mB, rB);
+        body(base + n + rpp, cg, cx, cs, cm_, cr);
+      }
+    }
   }
 #pragma unroll
   for (int v = 0; v < MAXNV; ++v)
@@ -443,16 +457,21 @@ void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2
                out, mu, rstd, residual);
 }
 
-template <int DT, int VE, int MAXNV>
-__global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void* dOut, const void* Op, const float* sc2, const float* sh2,
-                                                  const float* mean2, const float* rstd2, const float* lnw,
-                                                  const float* lnb, const float* gate, int gate_first, const float* mu,
-                                                  const float* rstd, long rows, int C, int gs, int nv, int rpc, void* dO,
-                                                  float* dlnw, float* dlnb, float* dgate, float* bnsums) {
+// AVE = the flag set of the AVE / AVVP / AVQA-visual / pretrain flavours (BN2 on, ln_post on, gate present, LN before
+// gate) as compile-time constants: with runtime flags the per-element body compiled to ~70 scalar branches per row
+// (hipcc does not unswitch a loop this size) in a kernel whose row iteration is latency-bound.
+template <int DT, int VE, int MAXNV, bool AVE>
+__device__ __forceinline__ void tail_bwd_body(const void* dOut, const void* Op, const float* sc2_, const float* sh2,
+                                              const float* mean2, const float* rstd2, const float* lnw_,
+                                              const float* lnb, const float* gate_, int gate_first_, const float* mu,
+                                              const float* rstd, long rows, int C, int gs, int nv, int rpc, void* dO,
+                                              float* dlnw, float* dlnb, float* dgate, float* bnsums) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const bool sc2 = AVE || sc2_ != nullptr, lnw = AVE || lnw_ != nullptr, gate = AVE || gate_ != nullptr;
+  const bool gate_first = AVE ? false : gate_first_ != 0;
   const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
   const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
-  const float gv = gate ? *gate : 1.f;
+  const float gv = gate ? *gate_ : 1.f;
   float sc[MAXNV][VE], sh[MAXNV][VE], w[MAXNV][VE], bb[MAXNV][VE];
   float acc[4][MAXNV][VE];   // 0: dlnw 1: dlnb 2: sum dO 3: sum dO*Op (turned into sum dO*xh2 at the end)
 #pragma unroll
@@ -461,8 +480,8 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
 #pragma unroll
     for (int e = 0; e < VE; ++e) { acc[0][v][e] = acc[1][v][e] = acc[2][v][e] = acc[3][v][e] = 0.f; }
     if (v < nv && col < C) {
-      if (sc2) { ldf<VE>(sc2, col, sc[v]); ldf<VE>(sh2, col, sh[v]); }
-      if (lnw) { ldf<VE>(lnw, col, w[v]); ldf<VE>(lnb, col, bb[v]); }
+      if (sc2) { ldf<VE>(sc2_, col, sc[v]); ldf<VE>(sh2, col, sh[v]); }
+      if (lnw) { ldf<VE>(lnw_, col, w[v]); ldf<VE>(lnb, col, bb[v]); }
     }
   }
   float gsum = 0.f;
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
         }
       }
     }
-    if (lnw) { s1 = group_sum(s1, gs) / C; s2 = group_sum(s2, gs) / C; }
+    if (lnw) { group_sum2(s1, s2, gs); s1 /= C; s2 /= C; }
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
@@ -585,6 +604,21 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(const void
     if (threadIdx.x == 0) unsafeAtomicAdd(dgate, t);
   }
 }
+#define TAIL_BWD_ARGS_                                                                                                  \
+  const void *dOut, const void *Op, const float *sc2, const float *sh2, const float *mean2, const float *rstd2,         \
+      const float *lnw, const float *lnb, const float *gate, int gate_first, const float *mu, const float *rstd,       \
+      long rows, int C, int gs, int nv, int rpc, void *dO, float *dlnw, float *dlnb, float *dgate, float *bnsums
+#define TAIL_BWD_PASS_                                                                                                  \
+  dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu, rstd, rows, C, gs, nv, rpc, dO, dlnw, dlnb, dgate, bnsums
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(TAIL_BWD_ARGS_) {
+  tail_bwd_body<DT, VE, MAXNV, false>(TAIL_BWD_PASS_);
+}
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_ave_k(TAIL_BWD_ARGS_) {
+  tail_bwd_body<DT, VE, MAXNV, true>(TAIL_BWD_PASS_);
+}
+
 
 void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
@@ -598,8 +632,12 @@ void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2
     ROW_CAPACITY(cap, ctx, C, g.nv, tail_bwd_k, sh);
     g = row_geom(C, row_ve(ctx, C), (int)rows, 1, cap, mi, true);
   }
-  ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu,
-                  rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums);
+  if (sc2 && lnw && gate && !gate_first)
+    ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_ave_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first,
+                    mu, rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums);
+  else
+    ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu,
+                    rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums);
 }
 
 // ================================================================================================
