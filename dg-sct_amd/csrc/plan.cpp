@@ -171,6 +171,7 @@ void Plan::layout() {
     wb.dYp = a.take("dYp", R * C * es);
     wb.dT = a.take("dT", orderA ? R * Co * es : (int64_t)B * No * C * es);
     wb.rowtmp = a.take("rowtmp", R * 4);
+    wb.rowpart = a.take("rowpart", row_part_floats(B, C) * 4);
     ws_bwd_bytes = a.off;
   }
   // ---- gradients (flat fp32)
@@ -493,7 +494,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   tail_bwd(ctx, dOut, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr, bn2, bn2 + C,
            d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
            d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, b.S<float>(s.mu_p), b.S<float>(s.rstd_p), R, C,
-           dO, G(DGSCT_P_LNP_W), G(DGSCT_P_LNP_B), G(DGSCT_P_GATE), d.use_bn ? G(DGSCT_P_BN2_B) : nullptr);
+           dO, G(DGSCT_P_LNP_W), G(DGSCT_P_LNP_B), G(DGSCT_P_GATE), d.use_bn ? G(DGSCT_P_BN2_B) : nullptr,
+           b.Wk<float>(wb.rowpart), row_part_floats(B, C));
   // B10 ---- BN2 backward, up projection
   if (d.use_bn) {
     bn_bwd_apply(ctx, dO, b.S(s.Op), dO, R, C, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C, G(DGSCT_P_BN2_B), 0, 1, d.training);
@@ -545,7 +547,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   void* dX1 = b.Wk(wb.dX1);
   modln_bwd(ctx, b.Wk(wb.dX3), b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), tg, d.alpha, d.beta, d.gamma,
             d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, b.S<float>(s.mu_b), b.S<float>(s.rstd_b), B, N, C, dX1,
-            G(DGSCT_P_LNB_W), G(DGSCT_P_LNB_B), b.Wk<float>(wb.dch), b.Wk<float>(wb.dsg), b.Wk<float>(wb.dtg));
+            G(DGSCT_P_LNB_W), G(DGSCT_P_LNB_B), b.Wk<float>(wb.dch), b.Wk<float>(wb.dsg), b.Wk<float>(wb.dtg),
+            b.Wk<float>(wb.rowpart), row_part_floats(B, C));
   // B7 ---- spatial gate
   {
     spatial_bwd(ctx, b.S<float>(s.sl), b.S<float>(s.sg), b.S<float>(s.map), b.Wk<float>(wb.dsg), dMap, B, N,

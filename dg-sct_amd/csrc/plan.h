@@ -34,7 +34,7 @@ struct Plan {
   struct {
     int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, zero_end;
     int64_t dO, dZ, dX3, dX1, dXc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, daN, dpre_t, U, dS2, dtokF,
-        dtokE, dP1, dS1, dYp, dT, rowtmp;
+        dtokE, dP1, dS1, dYp, dT, rowtmp, rowpart;
   } wb;
   int64_t ws_fwd_bytes, ws_bwd_bytes;
   // gradients

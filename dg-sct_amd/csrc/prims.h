@@ -114,7 +114,12 @@ void modln_fwd(const Ctx&, const void* X1, const float* ch, const float* sg, con
 // dsg[b][n] = beta * sum_c dX2*X1; dtg[b] += gamma * sum_{n,c} dX2*X1 (if tg)
 void modln_bwd(const Ctx&, const void* dX3, const void* X1, const float* ch, const float* sg, const float* tg, float alpha,
                float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N, int C,
-               void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg);
+               void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg, float* part = nullptr,
+               long part_floats = 0);
+// part / part_floats (modln_bwd, tail_bwd): optional scratch, >= row_part_floats(B, C).  When given, the per-channel sums
+// leave each workgroup as plain stores of its partial sums and a small second kernel adds them up, instead of one global
+// atomic per (workgroup, channel): ~1.5 M atomics on 2048 addresses cost 55 of the 62 us of tail_bwd at C = 512.
+long row_part_floats(int B, int C);
 
 // Grouped projections with a tiny per-group narrow width dg = ds/g <= 8 (early-stage bottlenecks), on the vector units:
 //   narrow: y[r][gi*dg + jl] = sum_cl x[r][gi*cg + cl] * W(gi, jl, cl)      x E [rows][C]  -> y E [rows][ds]
@@ -150,7 +155,8 @@ void tail_fwd(const Ctx&, const void* Op, const float* sc2, const float* sh2, co
 // bnsums[1][c] += sum dO * (Op - mean2)*rstd2.
 void tail_bwd(const Ctx&, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
-              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums);
+              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums,
+              float* part = nullptr, long part_floats = 0);
 
 // Small fp32/E elementwise helpers on [n]-sized vectors (n <= a few 100k).
 enum EwOp : int {

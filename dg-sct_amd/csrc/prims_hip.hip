@@ -132,29 +132,69 @@ static RowGeom row_geom(int C, int VE, int N, int B, long target_wgs = 2048, int
   } while (0)
 static inline int row_ve(const Ctx& ctx, int C) { return ctx.mode == DT_BF16 ? (C % 8 == 0 ? 8 : 4) : 4; }
 
-// flush per-lane channel accumulators: LDS combine across the row-groups of the workgroup, then one
-// global atomic per channel.  lds: NQ*C floats (zeroed here).
+// flush per-lane channel accumulators: combine across the row-groups of the workgroup through LDS, then one global
+// atomic per channel -- or, with `part`, one plain store per channel of this workgroup's partial sums (finished by
+// part_reduce_k).  lds: (256 / gs) * C floats.  The combine is store / barrier / column-sum per quantity: LDS float
+// atomics (the first version) cost 31 of the 52 us of tail_bwd at C = 512 (8192 ds atomics per workgroup, 4-way
+// contended).
 template <int NQ, int VE, int MAXNV>
 __device__ __forceinline__ void flush_cols(float (&acc)[NQ][MAXNV][VE], float* lds, int C, int gs, int nv, int gl,
-                                           float* const (&dst)[NQ]) {
-  for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.f;
-  __syncthreads();
+                                           float* const (&dst)[NQ], float* part = nullptr) {
+  const int sub = threadIdx.x / gs, rpp = 256 / gs;
+  float* p = part ? part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (NQ * C) : nullptr;
 #pragma unroll
-  for (int v = 0; v < MAXNV; ++v) {
-    const int col = (v * gs + gl) * VE;
-    if (v < nv && col < C) {
+  for (int q = 0; q < NQ; ++q) {
+    __syncthreads();
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
+    for (int v = 0; v < MAXNV; ++v) {
+      const int col = (v * gs + gl) * VE;
+      if (v < nv && col < C) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) atomicAdd(&lds[q * C + col + e], acc[q][v][e]);
+        for (int e = 0; e < VE; e += 4)
+          *reinterpret_cast<float4*>(&lds[sub * C + col + e]) = make_float4(acc[q][v][e], acc[q][v][e + 1], acc[q][v][e + 2], acc[q][v][e + 3]);
+      }
+    }
+    __syncthreads();
+    if (p || dst[q]) {
+      for (int i = threadIdx.x; i < C; i += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += lds[r * C + i];
+        if (p) p[q * C + i] = s;
+        else unsafeAtomicAdd(dst[q] + i, s);
+      }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NQ * C; i += 256) {
-    const int q = i / C;
-    if (dst[q]) unsafeAtomicAdd(dst[q] + (i - q * C), lds[i]);
-  }
 }
+
+// ---- second stage of the per-channel sums: dst[j][c] += scale * sum_{k<K} part[(j*K + k)][q][c] ---------------------
+struct PartDesc { int q, J, K, S; float* dst; long dst_stride; float scale; };
+struct PartTable { PartDesc d[4]; int NQ, C; };
+__global__ __launch_bounds__(256) void part_reduce_k(const float* part, PartTable t) {
+  const PartDesc d = t.d[blockIdx.z];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.y >= d.J * d.S || c >= t.C) return;
+  const int j = blockIdx.y / d.S, sp = blockIdx.y - j * d.S;
+  const int kb = (d.K + d.S - 1) / d.S, k0 = sp * kb, k1 = k0 + kb < d.K ? k0 + kb : d.K;
+  const long rs = (long)t.NQ * t.C;
+  const float* p = part + ((long)j * d.K) * rs + (long)d.q * t.C + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = k0;
+  for (; k + 3 < k1; k += 4) { s0 += p[k * rs]; s1 += p[(k + 1) * rs]; s2 += p[(k + 2) * rs]; s3 += p[(k + 3) * rs]; }
+  for (; k < k1; ++k) s0 += p[k * rs];
+  if (k1 > k0) unsafeAtomicAdd(d.dst + (long)j * d.dst_stride + c, d.scale * ((s0 + s1) + (s2 + s3)));
+}
+static void part_reduce(const Ctx& ctx, const float* part, PartTable& t, int n) {
+  if (n == 0) return;
+  int ymax = 1;
+  for (int i = 0; i < n; ++i) {
+    PartDesc& d = t.d[i];
+    d.S = d.K / 16; if (d.S < 1) d.S = 1; if (d.S > 32) d.S = 32;
+    if (d.J * d.S > ymax) ymax = d.J * d.S;
+  }
+  hipLaunchKernelGGL(part_reduce_k, dim3((t.C + 255) / 256, ymax, n), dim3(256), 0, STREAM(ctx), part, t);
+}
+long row_part_floats(int B, int C) { return ((long)1024 + B) * 4 * C; }
 
 // ================================================================================================
 // modulation + ln_before                                   (reference net_trans.py:611-627)
@@ -241,7 +281,7 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
                                                    const float* tg, float alpha, float beta, float gamma,
                                                    const float* lnw, const float* mu, const float* rstd, int N, int C,
                                                    int gs, int nv, int rpc, void* dX1, float* dlnw, float* dlnb,
-                                                   float* dch, float* dsg, float* dtg) {
+                                                   float* dch, float* dsg, float* dtg, float* part) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y, gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
   const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
@@ -343,7 +383,7 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[2][v][e] *= alpha;
   float* const dst[3] = {dlnw, dlnb, dch + (long)b * C};
-  flush_cols<3, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst);
+  flush_cols<3, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst, part);
   if (dtg) {
     const float t = block_sum(tsum, lds);
     if (threadIdx.x == 0) unsafeAtomicAdd(dtg + b, gamma * t);
@@ -352,18 +392,28 @@ __global__ __launch_bounds__(256) void modln_bwd_k(const void* dX3, const void* 
 
 void modln_bwd(const Ctx& ctx, const void* dX3, const void* X1, const float* ch, const float* sg, const float* tg,
                float alpha, float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N,
-               int C, void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg) {
+               int C, void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg, float* part, long part_floats) {
   static const int mi = env_int("DGSCT_ROW_MIN_ITERS", 8);
   static const int use_cap = env_int("DGSCT_ROW_CAP", 1);
-  const size_t sh = (size_t)3 * C * sizeof(float);
   RowGeom g = row_geom(C, row_ve(ctx, C), N, B, 1024, mi);
+  const size_t sh = (size_t)(256 / g.gs) * C * sizeof(float);      // flush_cols: one row of C floats per row-group
   if (use_cap) {
     int cap = 1024;
     ROW_CAPACITY(cap, ctx, C, g.nv, modln_bwd_k, sh);
     g = row_geom(C, row_ve(ctx, C), N, B, cap, mi, true);
   }
+  static const int use_part = env_int("DGSCT_ROW_PART", 1);
+  if (!use_part || (long)g.chunks * B * 3 * C > part_floats) part = nullptr;
   ROW_DISPATCH_SH(ctx, C, g.nv, modln_bwd_k, dim3(g.chunks, B), sh, dX3, X1, ch, sg, tg, alpha, beta, gamma, lnw, mu, rstd, N, C,
-                  g.gs, g.nv, g.rpc, dX1, dlnw, dlnb, dch, dsg, tg ? dtg : nullptr);
+                  g.gs, g.nv, g.rpc, dX1, dlnw, dlnb, dch, dsg, tg ? dtg : nullptr, part);
+  if (part) {
+    PartTable t; t.NQ = 3; t.C = C;
+    int n = 0;
+    if (dlnw) t.d[n++] = PartDesc{0, 1, g.chunks * B, 1, dlnw, 0, 1.f};
+    if (dlnb) t.d[n++] = PartDesc{1, 1, g.chunks * B, 1, dlnb, 0, 1.f};
+    if (dch) t.d[n++] = PartDesc{2, B, g.chunks, 1, dch, C, 1.f};
+    part_reduce(ctx, part, t, n);
+  }
 }
 
 // ================================================================================================
@@ -465,7 +515,7 @@ __device__ __forceinline__ void tail_bwd_body(const void* dOut, const void* Op, 
                                               const float* mean2, const float* rstd2, const float* lnw_,
                                               const float* lnb, const float* gate_, int gate_first_, const float* mu,
                                               const float* rstd, long rows, int C, int gs, int nv, int rpc, void* dO,
-                                              float* dlnw, float* dlnb, float* dgate, float* bnsums) {
+                                              float* dlnw, float* dlnb, float* dgate, float* bnsums, float* part) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bool sc2 = AVE || sc2_ != nullptr, lnw = AVE || lnw_ != nullptr, gate = AVE || gate_ != nullptr;
   const bool gate_first = AVE ? false : gate_first_ != 0;
@@ -598,7 +648,7 @@ __device__ __forceinline__ void tail_bwd_body(const void* dOut, const void* Op, 
     }
   }
   float* const dst[4] = {dlnw, dlnb, bnsums, bnsums ? bnsums + C : nullptr};
-  flush_cols<4, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst);
+  flush_cols<4, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst, part);
   if (gate) {
     const float t = block_sum(gsum, lds);
     if (threadIdx.x == 0) unsafeAtomicAdd(dgate, t);
@@ -607,9 +657,9 @@ __device__ __forceinline__ void tail_bwd_body(const void* dOut, const void* Op, 
 #define TAIL_BWD_ARGS_                                                                                                  \
   const void *dOut, const void *Op, const float *sc2, const float *sh2, const float *mean2, const float *rstd2,         \
       const float *lnw, const float *lnb, const float *gate, int gate_first, const float *mu, const float *rstd,       \
-      long rows, int C, int gs, int nv, int rpc, void *dO, float *dlnw, float *dlnb, float *dgate, float *bnsums
+      long rows, int C, int gs, int nv, int rpc, void *dO, float *dlnw, float *dlnb, float *dgate, float *bnsums, float *part
 #define TAIL_BWD_PASS_                                                                                                  \
-  dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu, rstd, rows, C, gs, nv, rpc, dO, dlnw, dlnb, dgate, bnsums
+  dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu, rstd, rows, C, gs, nv, rpc, dO, dlnw, dlnb, dgate, bnsums, part
 template <int DT, int VE, int MAXNV>
 __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(TAIL_BWD_ARGS_) {
   tail_bwd_body<DT, VE, MAXNV, false>(TAIL_BWD_PASS_);
@@ -622,22 +672,33 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_ave_k(TAIL_B
 
 void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
-              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums) {
+              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums,
+              float* part, long part_floats) {
   static const int mi = env_int("DGSCT_ROW_MIN_ITERS", 8);
   static const int use_cap = env_int("DGSCT_ROW_CAP", 1);
-  const size_t sh = (size_t)4 * C * sizeof(float);
   RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1, 1024, mi);
+  const size_t sh = (size_t)(256 / g.gs) * C * sizeof(float);      // flush_cols: one row of C floats per row-group
   if (use_cap) {
     int cap = 1024;
     ROW_CAPACITY(cap, ctx, C, g.nv, tail_bwd_k, sh);
     g = row_geom(C, row_ve(ctx, C), (int)rows, 1, cap, mi, true);
   }
+  static const int use_part = env_int("DGSCT_ROW_PART", 1);
+  if (!use_part || (long)g.chunks * 4 * C > part_floats) part = nullptr;
   if (sc2 && lnw && gate && !gate_first)
     ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_ave_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first,
-                    mu, rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums);
+                    mu, rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums, part);
   else
     ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu,
-                    rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums);
+                    rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums, part);
+  if (part) {
+    PartTable t; t.NQ = 4; t.C = C;
+    int n = 0;
+    if (dlnw) t.d[n++] = PartDesc{0, 1, g.chunks, 1, dlnw, 0, 1.f};
+    if (dlnb) t.d[n++] = PartDesc{1, 1, g.chunks, 1, dlnb, 0, 1.f};
+    if (bnsums) { t.d[n++] = PartDesc{2, 1, g.chunks, 1, bnsums, 0, 1.f}; t.d[n++] = PartDesc{3, 1, g.chunks, 1, bnsums + C, 0, 1.f}; }
+    part_reduce(ctx, part, t, n);
+  }
 }
 
 // ================================================================================================

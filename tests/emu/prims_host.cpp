@@ -169,6 +169,8 @@ void scale_cols(const Ctx& ctx, const void* x, void* y, int B, int N, int C, con
       }
 }
 
+long row_part_floats(int B, int C) { return 0 * (long)B * C; }
+
 void outer_rows(const Ctx& ctx, const float* roww, const float* colw, int B, int N, int C, void* y) {
   for (int b = 0; b < B; ++b)
     for (int n = 0; n < N; ++n)
@@ -261,7 +263,7 @@ void modln_fwd(const Ctx& ctx, const void* X1, const float* ch, const float* sg,
 
 void modln_bwd(const Ctx& ctx, const void* dX3, const void* X1, const float* ch, const float* sg, const float* tg, float alpha,
                float beta, float gamma, const float* lnw, const float* mu, const float* rstd, int B, int N, int C,
-               void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg) {
+               void* dX1, float* dlnw, float* dlnb, float* dch, float* dsg, float* dtg, float*, long) {
   std::vector<float> g(C), xh(C), md(C), x1(C);
   for (int b = 0; b < B; ++b)
     for (int n = 0; n < N; ++n) {
@@ -410,7 +412,7 @@ void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2
 
 void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
-              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums) {
+              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums, float*, long) {
   std::vector<float> g(C), o(C), xh(C), op(C);
   const float gv = gate ? *gate : 1.f;
   double gsum = 0;
