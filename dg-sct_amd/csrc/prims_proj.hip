@@ -241,17 +241,22 @@ __global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void gproj_wide_k(const v
       }
     }
   }
-  if (stats) {          // combine the row slots of the workgroup in LDS, then one atomic per channel
-    for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
-    __syncthreads();
-    if (valid) {
+  if (stats) {          // combine the row slots of the workgroup in LDS (store / barrier / column sum), one atomic per channel
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+      __syncthreads();
+      if (valid) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) atomicAdd(&lds[q * C + col + e], acc[q][e]);
+        for (int e = 0; e < VE; e += 4)
+          *reinterpret_cast<float4*>(&lds[sub * C + col + e]) = make_float4(acc[q][e], acc[q][e + 1], acc[q][e + 2], acc[q][e + 3]);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < C; i += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += lds[r * C + i];
+        unsafeAtomicAdd(stats + C + q * C + i, s);
+      }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) unsafeAtomicAdd(stats + C + i, lds[i]);
   }
 }
 

@@ -78,24 +78,40 @@ static inline int col_ve(const Ctx& ctx, int C) {
     }                                                                                                       \
   } while (0)
 
-// combine NQ per-thread channel accumulators across the row-slots of the workgroup; one atomic per channel
+// combine NQ per-thread channel accumulators across the row-slots of the workgroup; one global atomic per channel.
+// Per quantity: every row-slot stores its vector to lds[tr][col..], barrier, 256 threads sum the rpp rows of a column
+// (LDS float atomics here cost more than the streaming loop of the late-stage shapes).  lds: rpp * C floats
+// (strip_lds).  [c_lo, c_hi): the columns of the current column super-block.
 template <int NQ, int VE>
 __device__ __forceinline__ void flush_strip(float (&acc)[NQ][VE], float* lds, int C, int col, bool active,
-                                            float* const (&dst)[NQ]) {
-  __syncthreads();
-  for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.f;
-  __syncthreads();
-  if (active) {
+                                            float* const (&dst)[NQ], int tr, int rpp, int c_lo, int c_hi) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+  for (int q = 0; q < NQ; ++q) {
+    __syncthreads();
+    if (active) {
+      if constexpr (VE % 4 == 0) {
 #pragma unroll
-      for (int e = 0; e < VE; ++e) atomicAdd(&lds[q * C + col + e], acc[q][e]);
+        for (int e = 0; e < VE; e += 4)
+          *reinterpret_cast<float4*>(&lds[tr * C + col + e]) = make_float4(acc[q][e], acc[q][e + 1], acc[q][e + 2], acc[q][e + 3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) lds[tr * C + col + e] = acc[q][e];
+      }
+    }
+    __syncthreads();
+    if (dst[q]) {
+      for (int i = c_lo + threadIdx.x; i < c_hi; i += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += lds[r * C + i];
+        unsafeAtomicAdd(dst[q] + i, s);
+      }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NQ * C; i += 256) {
-    const int q = i / C;
-    if (dst[q]) unsafeAtomicAdd(dst[q] + (i - q * C), lds[i]);
-  }
+}
+static inline size_t strip_lds(int C, int ve) {
+  const int nvr = C / ve, tpr = nvr < 256 ? nvr : 256;
+  return (size_t)(256 / tpr) * C * sizeof(float);
 }
 
 // Strip iteration skeleton used by every kernel below:
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(256) void colsum_k(const void* x, long ld, long bs,
       for (int e = 0; e < VE; ++e) acc[0][e] *= scale;
     }
     float* const dst[1] = {out + (long)b * out_bs};
-    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
+    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE));
   }
 }
 
@@ -152,10 +168,10 @@ void colsum_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int 
   int ve = col_ve(ctx, C);
   if (ld % ve != 0 || bs % ve != 0) ve = 1;
   int cap = 768;
-  COL_CAPACITY(cap, ctx, ve, colsum_k, (size_t)C * sizeof(float));
+  COL_CAPACITY(cap, ctx, ve, colsum_k, strip_lds(C, ve));
   if (cap > 800) cap = 800;            // light kernel (5 resident/CU): beyond ~3 per CU the extra atomics cost more than they hide
   ColGeom g = col_geom(UNR1, C, ve, N, B, cap, true);
-  COL_DISPATCH(ctx, ve, colsum_k, dim3(g.chunks, B), (size_t)C * sizeof(float), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr,
+  COL_DISPATCH(ctx, ve, colsum_k, dim3(g.chunks, B), strip_lds(C, ve), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr,
                g.rpp, g.rpc, out, out_bs);
 }
 
@@ -199,14 +215,14 @@ __global__ __launch_bounds__(256) void bn_stats_k(const void* x, long rows, int 
       }
     }
     float* const dst[2] = {acc3 + C, acc3 + 2 * C};
-    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst);
+    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE));
   }
 }
 
 void bn_stats(const Ctx& ctx, const void* x, long rows, int C, float* acc) {
   const int ve = col_ve(ctx, C);
   ColGeom g = col_geom(UNR1, C, ve, rows, 1, 768);
-  COL_DISPATCH(ctx, ve, bn_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), x, rows, C, g.tpr, g.rpp, g.rpc, acc);
+  COL_DISPATCH(ctx, ve, bn_stats_k, dim3(g.chunks), strip_lds(C, ve), x, rows, C, g.tpr, g.rpp, g.rpc, acc);
 }
 
 __global__ void bn_finalize_k(const float* acc, long rows, int C, const float* w, const float* b, float* run_mean,
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void
       }
     }
     float* const dst[2] = {sums, sums + C};
-    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst);
+    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE));
   }
 }
 
@@ -331,7 +347,7 @@ void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int 
                   const float* sc, const float* sh, int relu, float* sums) {
   const int ve = col_ve(ctx, C);
   ColGeom g = col_geom(UNR2, C, ve, rows, 1, 768);
-  COL_DISPATCH(ctx, ve, bn_bwd_stats_k, dim3(g.chunks), (size_t)2 * C * sizeof(float), dy, x, rows, C, mean, rstd, sc, sh, relu,
+  COL_DISPATCH(ctx, ve, bn_bwd_stats_k, dim3(g.chunks), strip_lds(C, ve), dy, x, rows, C, mean, rstd, sc, sh, relu,
                g.tpr, g.rpp, g.rpc, sums);
 }
 
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, 
     }
     if (colsum_out) {
       float* const dst[1] = {colsum_out};
-      flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
+      flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE));
     }
   }
 }
@@ -512,9 +528,9 @@ void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C,
                     const float* colw2, float scale, float* colsum_out) {
   const int ve = col_ve(ctx, C);
   int cap = 4096;
-  if (colsum_out) COL_CAPACITY(cap, ctx, ve, relu_bwd_scale_k, (size_t)C * sizeof(float));
+  if (colsum_out) COL_CAPACITY(cap, ctx, ve, relu_bwd_scale_k, strip_lds(C, ve));
   ColGeom g = col_geom(UNR1, C, ve, N, B, cap, colsum_out != nullptr);
-  COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), (size_t)C * sizeof(float), x, y, N, C, g.tpr, g.rpp, g.rpc, roww,
+  COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), strip_lds(C, ve), x, y, N, C, g.tpr, g.rpp, g.rpc, roww,
                colw, cdt, colw2, scale, colsum_out);
 }
 
@@ -556,15 +572,15 @@ __global__ __launch_bounds__(256) void xc_bwd_k(const void* dXc, const void* X1,
       }
     }
     float* const dst[1] = {dch + (long)b * C};
-    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst);
+    flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE));
   }
 }
 void xc_bwd(const Ctx& ctx, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch) {
   const int ve = col_ve(ctx, C);
   int cap = 768;
-  COL_CAPACITY(cap, ctx, ve, xc_bwd_k, (size_t)C * sizeof(float));
+  COL_CAPACITY(cap, ctx, ve, xc_bwd_k, strip_lds(C, ve));
   ColGeom g = col_geom(UNR3, C, ve, N, B, cap, true);
-  COL_DISPATCH(ctx, ve, xc_bwd_k, dim3(g.chunks, B), (size_t)C * sizeof(float), dXc, X1, dX1, N, C, ch, g.tpr, g.rpp, g.rpc, dch);
+  COL_DISPATCH(ctx, ve, xc_bwd_k, dim3(g.chunks, B), strip_lds(C, ve), dXc, X1, dX1, N, C, ch, g.tpr, g.rpp, g.rpc, dch);
 }
 
 // ---- sum over the batch axis of small fp32 tensors: out[i] (+)= scale * sum_b in[b*bs + i] ---------------
