@@ -790,7 +790,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   //  * shallow ones (most of this workload: K = 32..768) are bound by per-workgroup latency and by wave
   //    quantisation over the 256 CUs x 3 resident 128x128 workgroups: 64x64 tiles (6 resident) win unless the 128x128
   //    grid fills its last round well and K is not tiny.
-  int cfg;
+  int cfg, force_split = 0;
   const long kflat = (long)g.K * g.KB;
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.batch; };
   if (g.N <= 32) cfg = 2;                                       // 128 x 32
@@ -803,6 +803,13 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     if (tiles(128, 128) < 64) cfg = 4;                          // B x C gate GEMMs (M = 160): 8-16 big tiles leave the chip idle
     else if (g.M >= 96 && g.N >= 96) cfg = 0;                   // 128 x 128
     else cfg = 4;
+  } else if (g.atomic && g.batch == 1 && g.M > 64 && g.M <= 128 && g.N > 64 && g.N <= 128 && kflat >= 131072) {
+    // stage-0 weight gradients (C x C over 370-650 k token rows): ONE tile spanning the whole output, split-K over one
+    // workgroup per CU.  Four 64 x 64 tiles read every operand panel twice (425 MB fetched for 189 MB of operands) and
+    // 32-row tiles three times: 98.6 -> 67.2 us at 96 x 96 x 655 360, 67.5 -> 60.8 at 128 x 128 x 368 640
+    // (tools/gemm_wgrad_probe.py).
+    cfg = g.N <= 96 ? 1 : 0;
+    force_split = 256;
   } else if (g.atomic && g.M >= 1024 && g.N >= 1024 && kflat >= 8192) cfg = 0;   // dWn: a plain big GEMM
   else if (g.atomic && g.M <= 128 && g.M % 64 != 0 && g.M % 32 == 0) cfg = 3;     // 96-row weight gradients: 3 x 32 rows
   else {
@@ -840,7 +847,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   if (!g.atomic) splitk = 1;
   else if (splitk <= 0) {                                       // auto: aim for >= 1024 workgroups, >= 4 k-tiles each
     long wg = (long)k.tiles_m * k.tiles_n * g.batch;
-    splitk = (int)((1024 + wg - 1) / wg);
+    splitk = force_split ? force_split : (int)((1024 + wg - 1) / wg);
     int maxs = k.kt_total / 4; if (maxs < 1) maxs = 1;
     if (splitk > maxs) splitk = maxs;
     if (splitk < 1) splitk = 1;

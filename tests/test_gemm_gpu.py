@@ -152,6 +152,14 @@ def test_gemm_deep_one_level_contraction(ak, bk):
     run_case(1, 64, 48, 200000, ak, bk, batch=1, atomic=True, splitk=0)
 
 
+@pytest.mark.parametrize("M,N", [(96, 96), (128, 128), (128, 96), (96, 128), (72, 120)])
+def test_gemm_single_tile_deep_weight_gradient(M, N):
+    """stage-0 weight-gradient shapes (64 < M, N <= 128, K >= 131 072 token rows): one tile over the whole output, 256-way
+    split-K with atomics"""
+    run_case(1, M, N, 140000, 0, 0, batch=1, atomic=True, splitk=0)
+    run_case(1, M, N, 960, 1, 1 if M == N else 0, batch=1, KB=160, atomic=True, splitk=0)      # two-level K, kflat = 153 600
+
+
 def test_gemm_deep_tiles_and_shared_operand():
     run_case(1, 512, 96, 2048, 1, 1, batch=3, shared_a=True, out_bf16=True)      # 256 x 96 tile (remap forward)
     run_case(1, 512, 96, 2048, 1, 0, batch=3, shared_a=True, out_bf16=True)
