@@ -109,6 +109,12 @@ __device__ __forceinline__ void flush_strip(float (&acc)[NQ][VE], float* lds, in
   }
   __syncthreads();
 }
+// un-batched pure streams too are launched as ONE round of resident workgroups (bn_bwd_apply at 368 640 x 128: 2880
+// workgroups on 768 slots, 102 -> 70 us; per-frame grids (scale_cols) gain nothing: the frame count quantises them).  DGSCT_COL_STREAM_CAP=0 restores the fixed ~4096-workgroup target.
+static inline bool stream_cap() {
+  static const bool on = !(getenv("DGSCT_COL_STREAM_CAP") && atoi(getenv("DGSCT_COL_STREAM_CAP")) == 0);
+  return on;
+}
 static inline size_t strip_lds(int C, int ve) {
   const int nvr = C / ve, tpr = nvr < 256 ? nvr : 256;
   return (size_t)(256 / tpr) * C * sizeof(float);
@@ -291,6 +297,7 @@ __global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long
 void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu) {
   const int ve = col_ve(ctx, C);
   ColGeom g = col_geom(UNR1, C, ve, rows, 1);
+  if (stream_cap()) { int cap = 4096; COL_CAPACITY(cap, ctx, ve, affine_act_k, 0); g = col_geom(UNR1, C, ve, rows, 1, cap, true); }
   COL_DISPATCH(ctx, ve, affine_act_k, dim3(g.chunks), 0, x, y, rows, C, g.tpr, g.rpp, g.rpc, sc, sh, relu);
 }
 
@@ -403,6 +410,7 @@ void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long 
                   const float* rstd, const float* sc, const float* sh, const float* sums, int relu, int has_bn, int training) {
   const int ve = col_ve(ctx, C);
   ColGeom g = col_geom(UNR2, C, ve, rows, 1);
+  if (stream_cap()) { int cap = 4096; COL_CAPACITY(cap, ctx, ve, bn_bwd_apply_k, 0); g = col_geom(UNR2, C, ve, rows, 1, cap, true); }
   COL_DISPATCH(ctx, ve, bn_bwd_apply_k, dim3(g.chunks), 0, dy, x, dx, rows, C, g.tpr, g.rpp, g.rpc, mean, rstd, sc, sh, sums,
                relu, has_bn, training);
 }
