@@ -788,6 +788,86 @@ __global__ __launch_bounds__(256) void softmax_long_k(const float* in, long ld_i
     ste_rt(out, odt, r * ld_out + c, o);
   }
 }
+// Row in registers: one float4 pass over the logits (the scalar version read the row three times through L2 with 4-byte
+// loads and wrote 2-byte elements behind a run-time dtype branch), 8-byte bf16 / 16-byte fp32 stores.  L <= 1024 * NCH.
+template <int NCH, bool OBF>
+__global__ __launch_bounds__(256) void softmax_long_vec_k(const float* in, long ld_in, void* out, long ld_out, int L, int pre_tanh) {
+  __shared__ float red[4];
+  const long r = blockIdx.x;
+  const float4* x = reinterpret_cast<const float4*>(in + r * ld_in);
+  float4 v[NCH];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c4 = threadIdx.x + i * 256;
+    v[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (c4 * 4 < L) {
+      v[i] = x[c4];
+      if (pre_tanh) { v[i].x = tanhf(v[i].x); v[i].y = tanhf(v[i].y); v[i].z = tanhf(v[i].z); v[i].w = tanhf(v[i].w); }
+    }
+    m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+  }
+  m = block_max(m, red);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    v[i].x = __expf(v[i].x - m); v[i].y = __expf(v[i].y - m); v[i].z = __expf(v[i].z - m); v[i].w = __expf(v[i].w - m);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  s = block_sum(s, red);
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c4 = threadIdx.x + i * 256;
+    if (c4 * 4 >= ld_out) continue;
+    const float4 o = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);   // exp(-inf) = 0 beyond L
+    if (OBF) {
+      uint2 w;
+      w.x = (unsigned)f2bf(o.x) | ((unsigned)f2bf(o.y) << 16);
+      w.y = (unsigned)f2bf(o.z) | ((unsigned)f2bf(o.w) << 16);
+      reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + r * ld_out)[c4] = w;
+    } else {
+      reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * ld_out)[c4] = o;
+    }
+  }
+}
+// backward, bf16 P and output: out = s * P * (dP - sum P*dP)
+template <int NCH>
+__global__ __launch_bounds__(256) void softmax_bwd_long_vec_k(const void* P, long ldp, const float* dP, long lddp, void* out, long ldo,
+                                                              int L, const float* scale_ptr, float* dot_accum) {
+  __shared__ float red[4];
+  const long r = blockIdx.x;
+  const float sc = scale_ptr ? *scale_ptr : 1.f;
+  const uint2* pp = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(P) + r * ldp);
+  const float4* gp = reinterpret_cast<const float4*>(dP + r * lddp);
+  float4 p[NCH], g[NCH];
+  float pd = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c4 = threadIdx.x + i * 256;
+    p[i] = make_float4(0.f, 0.f, 0.f, 0.f); g[i] = p[i];
+    if (c4 * 4 < L) {
+      const uint2 w = pp[c4];
+      g[i] = gp[c4];
+      p[i] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                         __uint_as_float(w.y & 0xffff0000u));
+    }
+    pd += (p[i].x * g[i].x + p[i].y * g[i].y) + (p[i].z * g[i].z + p[i].w * g[i].w);
+  }
+  pd = block_sum(pd, red);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c4 = threadIdx.x + i * 256;
+    if (c4 * 4 >= ldo) continue;
+    uint2 w;
+    w.x = (unsigned)f2bf(sc * p[i].x * (g[i].x - pd)) | ((unsigned)f2bf(sc * p[i].y * (g[i].y - pd)) << 16);
+    w.y = (unsigned)f2bf(sc * p[i].z * (g[i].z - pd)) | ((unsigned)f2bf(sc * p[i].w * (g[i].w - pd)) << 16);
+    reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + r * ldo)[c4] = w;
+  }
+  if (dot_accum && threadIdx.x == 0) unsafeAtomicAdd(dot_accum, pd);
+}
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static inline int flat_grid(long nvec) { long g = cdiv(nvec, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
@@ -798,6 +878,15 @@ void softmax_rows(const Ctx& ctx, const float* in, long ld_in, void* out, int od
     const long nb = cdiv(rows, 256 / gs);
     hipLaunchKernelGGL(softmax_short_k, dim3((int)(nb > 8192 ? 8192 : nb)), dim3(256), 0, STREAM(ctx), in, ld_in, out, odt, ld_out,
                        rows, L, gs, pre_tanh);
+  } else if (L % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_out <= 4096 && al16(in) && al16(out)) {
+    const int nch = (int)cdiv(ld_out, 1024);
+#define SMV_(N_)                                                                                                        \
+  do {                                                                                                                  \
+    if (odt == DT_BF16) hipLaunchKernelGGL((softmax_long_vec_k<N_, true>), dim3((int)rows), dim3(256), 0, STREAM(ctx), in, ld_in, out, ld_out, L, pre_tanh); \
+    else hipLaunchKernelGGL((softmax_long_vec_k<N_, false>), dim3((int)rows), dim3(256), 0, STREAM(ctx), in, ld_in, out, ld_out, L, pre_tanh); \
+  } while (0)
+    if (nch <= 1) SMV_(1); else if (nch == 2) SMV_(2); else if (nch == 3) SMV_(3); else SMV_(4);
+#undef SMV_
   } else {
     hipLaunchKernelGGL(softmax_long_k, dim3((int)rows), dim3(256), 0, STREAM(ctx), in, ld_in, out, odt, ld_out, L, pre_tanh);
   }
@@ -847,6 +936,12 @@ void softmax_bwd_rows(const Ctx& ctx, const void* P, long ldp, const float* dP, 
     const long nb = cdiv(rows, 256 / gs);
     hipLaunchKernelGGL(softmax_bwd_short_k, dim3((int)(nb > 2048 ? 2048 : nb)), dim3(256), 0, STREAM(ctx), P, pdt, ldp, dP, lddp,
                        out, odt, ldo, rows, L, gs, scale_ptr, dot_accum);
+  } else if (pdt == DT_BF16 && odt == DT_BF16 && L % 4 == 0 && ldp % 4 == 0 && lddp % 4 == 0 && ldo % 4 == 0 && ldo <= 4096 &&
+             al8(P) && al16(dP) && al8(out)) {
+    const int nch = (int)cdiv(ldo, 1024);
+#define SMB_(N_) hipLaunchKernelGGL((softmax_bwd_long_vec_k<N_>), dim3((int)rows), dim3(256), 0, STREAM(ctx), P, ldp, dP, lddp, out, ldo, L, scale_ptr, dot_accum)
+    if (nch <= 1) SMB_(1); else if (nch == 2) SMB_(2); else if (nch == 3) SMB_(3); else SMB_(4);
+#undef SMB_
   } else {
     hipLaunchKernelGGL(softmax_bwd_long_k, dim3((int)rows), dim3(256), 0, STREAM(ctx), P, pdt, ldp, dP, lddp, out, odt, ldo, L,
                        scale_ptr, dot_accum);
