@@ -598,14 +598,19 @@ __global__ __launch_bounds__(256) void sum_batch_k(const float* in, long bs, int
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int b0 = blockIdx.y * bper, b1 = imin_d(B, b0 + bper);
-  float s = 0.f;
-  for (int b = b0; b < b1; ++b) s += in[(long)b * bs + i];
-  unsafeAtomicAdd(out + i, s * scale);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent loads in flight (the loop is pure latency)
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    s0 += in[(long)b * bs + i]; s1 += in[(long)(b + 1) * bs + i]; s2 += in[(long)(b + 2) * bs + i]; s3 += in[(long)(b + 3) * bs + i];
+  }
+  for (; b < b1; ++b) s0 += in[(long)b * bs + i];
+  unsafeAtomicAdd(out + i, ((s0 + s1) + (s2 + s3)) * scale);
 }
 void sum_batch(const Ctx& ctx, const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
   if (!accumulate) (void)hipMemsetAsync(out, 0, (size_t)n * sizeof(float), STREAM(ctx));
   const int bx = (int)cdiv(n, 256);
   int slices = (int)cdiv(1024, bx);
+  if (slices > 128) slices = 128;      // every slice ends in one atomic per element: > ~128 per address costs more than the loop
   if (slices > B) slices = B;
   if (slices < 1) slices = 1;
   const int bper = (int)cdiv(B, slices);
