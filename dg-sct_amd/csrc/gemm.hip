@@ -809,7 +809,8 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     // 32-row tiles three times: 98.6 -> 67.2 us at 96 x 96 x 655 360, 67.5 -> 60.8 at 128 x 128 x 368 640
     // (tools/gemm_wgrad_probe.py).
     cfg = g.N <= 96 ? 1 : 0;
-    force_split = 256;
+    static const int fs = getenv("DGSCT_GEMM_FORCESPLIT") ? atoi(getenv("DGSCT_GEMM_FORCESPLIT")) : 256;
+    force_split = fs;
   } else if (g.atomic && g.M >= 1024 && g.N >= 1024 && kflat >= 8192) cfg = 0;   // dWn: a plain big GEMM
   else if (g.atomic && g.M <= 128 && g.M % 64 != 0 && g.M % 32 == 0) cfg = 3;     // 96-row weight gradients: 3 x 32 rows
   else {
@@ -848,6 +849,11 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   else if (splitk <= 0) {                                       // auto: aim for >= 1024 workgroups, >= 4 k-tiles each
     long wg = (long)k.tiles_m * k.tiles_n * g.batch;
     splitk = force_split ? force_split : (int)((1024 + wg - 1) / wg);
+    // Every split ends in one fp32 atomic per output element, and atomics on one address serialise at the memory side
+    // (~0.1 us each): 480 splits of a 36 x 64 weight gradient spent 50 of 58 us there.  Step time vs cap (B=16): none 67.5,
+    // 64: 67.0, 40: 66.6, 32: 66.7, 24: 67.7, 16: 72.2 ms.  DGSCT_GEMM_MAXSPLIT=0 removes the cap.
+    static const int max_split = getenv("DGSCT_GEMM_MAXSPLIT") ? atoi(getenv("DGSCT_GEMM_MAXSPLIT")) : 40;
+    if (max_split > 0 && !force_split && splitk > max_split) splitk = max_split;
     int maxs = k.kt_total / 4; if (maxs < 1) maxs = 1;
     if (splitk > maxs) splitk = maxs;
     if (splitk < 1) splitk = 1;
