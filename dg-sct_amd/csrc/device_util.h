@@ -214,4 +214,32 @@ __device__ __forceinline__ int imin_d(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ long lmin_d(long a, long b) { return a < b ? a : b; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// ---- second stage of the per-channel sums: dst[j][c] += scale * sum_{k<K} part[(j*K + k)][q][c] ---------------------
+struct PartDesc { int q, J, K, S; float* dst; long dst_stride; float scale; };
+struct PartTable { PartDesc d[4]; int NQ, C; };
+static __global__ __launch_bounds__(256) void part_reduce_k(const float* part, PartTable t) {
+  const PartDesc d = t.d[blockIdx.z];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.y >= d.J * d.S || c >= t.C) return;
+  const int j = blockIdx.y / d.S, sp = blockIdx.y - j * d.S;
+  const int kb = (d.K + d.S - 1) / d.S, k0 = sp * kb, k1 = k0 + kb < d.K ? k0 + kb : d.K;
+  const long rs = (long)t.NQ * t.C;
+  const float* p = part + ((long)j * d.K) * rs + (long)d.q * t.C + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = k0;
+  for (; k + 3 < k1; k += 4) { s0 += p[k * rs]; s1 += p[(k + 1) * rs]; s2 += p[(k + 2) * rs]; s3 += p[(k + 3) * rs]; }
+  for (; k < k1; ++k) s0 += p[k * rs];
+  if (k1 > k0) unsafeAtomicAdd(d.dst + (long)j * d.dst_stride + c, d.scale * ((s0 + s1) + (s2 + s3)));
+}
+static inline void part_reduce(void* stream, const float* part, PartTable& t, int n) {
+  if (n == 0) return;
+  int ymax = 1;
+  for (int i = 0; i < n; ++i) {
+    PartDesc& d = t.d[i];
+    d.S = d.K / 16; if (d.S < 1) d.S = 1; if (d.S > 32) d.S = 32;
+    if (d.J * d.S > ymax) ymax = d.J * d.S;
+  }
+  hipLaunchKernelGGL(part_reduce_k, dim3((t.C + 255) / 256, ymax, n), dim3(256), 0, (hipStream_t)stream, part, t);
+}
+
 }  // namespace dgsct

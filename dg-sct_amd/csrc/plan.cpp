@@ -520,7 +520,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B9 ---- relu, BN1 backward, down projection
   void* dZ = b.Wk(wb.dZ);
   if (d.use_bn) {
-    bn_bwd_stats(ctx, dZ, b.S(s.Zp), R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, 1, G(DGSCT_P_BN1_B));
+    bn_bwd_stats(ctx, dZ, b.S(s.Zp), R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, 1, G(DGSCT_P_BN1_B), b.Wk<float>(wb.rowpart),
+                 row_part_floats(B, C));
     bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, G(DGSCT_P_BN1_B), 1, 1, d.training);
   } else {
     bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0);
@@ -559,7 +560,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     ew(ctx, EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd);
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
     relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
-                   G(DGSCT_P_BV2));
+                   G(DGSCT_P_BV2), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
     Gemm g1 = mk((int)R, C, dd);                                 // dXc = dvq2 . Wv2
     g1.A = km(b.S(s.vq2), dd);
     g1.B = mn(b.W(DGSCT_P_WV2), C);
@@ -606,7 +607,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B5 ---- video query 1
   {
     relu_bwd_scale(ctx, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N,
-                   G(DGSCT_P_BV1));
+                   G(DGSCT_P_BV1), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
     Gemm g1 = mk((int)R, C, C);                                  // dX1 += dvq1 . Wv1
     g1.A = km(b.S(s.vq1), C); g1.B = mn(b.W(DGSCT_P_WV1), C);
     resid(g1, dX1, E, C);

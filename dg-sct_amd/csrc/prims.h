@@ -97,7 +97,7 @@ void outer_rows(const Ctx&, const float* roww, const float* colw, int B, int N, 
 // y[b][n][c] = (x[b][n][c] > 0) * (roww ? roww[b][n] : 1) * colw[b][c] * (colw2 ? colw2[c] : 1) * scale     x,y E (may alias)
 // If colsum_out: colsum_out[c] += sum_{b,n} y[b][n][c]  (the bias gradient of the layer whose pre-activation x masks).
 void relu_bwd_scale(const Ctx&, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
-                    const float* colw2, float scale, float* colsum_out);
+                    const float* colw2, float scale, float* colsum_out, float* part = nullptr, long part_floats = 0);
 // dX1[b][n][c] += dXc[b][n][c] * (1 + ch[b][c]);  dch[b][c] += sum_n dXc * X1        (all big tensors E, dch pre-initialised)
 void xc_bwd(const Ctx&, const void* dXc, const void* X1, void* dX1, int B, int N, int C, const float* ch, float* dch);
 
@@ -141,7 +141,7 @@ void bn_finalize(const Ctx&, const float* acc, long rows, int C, const float* w,
 void affine_act(const Ctx&, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu);
 // sums[0][c] += sum dyb, sums[1][c] += sum dyb*xh with dyb = dy * (relu ? (x*sc+sh > 0) : 1), xh = (x-mean)*rstd
 void bn_bwd_stats(const Ctx&, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
-                  const float* sc, const float* sh, int relu, float* sums);
+                  const float* sc, const float* sh, int relu, float* sums, float* part = nullptr, long part_floats = 0);
 // dx = training ? sc*(dyb - sums0/rows - xh*sums1/rows) : sc*dyb ;  has_bn == 0: dx = dyb.   in place allowed
 void bn_bwd_apply(const Ctx&, const void* dy, const void* x, void* dx, long rows, int C, const float* mean, const float* rstd,
                   const float* sc, const float* sh, const float* sums, int relu, int has_bn, int training);

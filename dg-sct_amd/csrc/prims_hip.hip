@@ -167,33 +167,6 @@ __device__ __forceinline__ void flush_cols(float (&acc)[NQ][MAXNV][VE], float* l
   __syncthreads();
 }
 
-// ---- second stage of the per-channel sums: dst[j][c] += scale * sum_{k<K} part[(j*K + k)][q][c] ---------------------
-struct PartDesc { int q, J, K, S; float* dst; long dst_stride; float scale; };
-struct PartTable { PartDesc d[4]; int NQ, C; };
-__global__ __launch_bounds__(256) void part_reduce_k(const float* part, PartTable t) {
-  const PartDesc d = t.d[blockIdx.z];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if ((int)blockIdx.y >= d.J * d.S || c >= t.C) return;
-  const int j = blockIdx.y / d.S, sp = blockIdx.y - j * d.S;
-  const int kb = (d.K + d.S - 1) / d.S, k0 = sp * kb, k1 = k0 + kb < d.K ? k0 + kb : d.K;
-  const long rs = (long)t.NQ * t.C;
-  const float* p = part + ((long)j * d.K) * rs + (long)d.q * t.C + c;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = k0;
-  for (; k + 3 < k1; k += 4) { s0 += p[k * rs]; s1 += p[(k + 1) * rs]; s2 += p[(k + 2) * rs]; s3 += p[(k + 3) * rs]; }
-  for (; k < k1; ++k) s0 += p[k * rs];
-  if (k1 > k0) unsafeAtomicAdd(d.dst + (long)j * d.dst_stride + c, d.scale * ((s0 + s1) + (s2 + s3)));
-}
-static void part_reduce(const Ctx& ctx, const float* part, PartTable& t, int n) {
-  if (n == 0) return;
-  int ymax = 1;
-  for (int i = 0; i < n; ++i) {
-    PartDesc& d = t.d[i];
-    d.S = d.K / 16; if (d.S < 1) d.S = 1; if (d.S > 32) d.S = 32;
-    if (d.J * d.S > ymax) ymax = d.J * d.S;
-  }
-  hipLaunchKernelGGL(part_reduce_k, dim3((t.C + 255) / 256, ymax, n), dim3(256), 0, STREAM(ctx), part, t);
-}
 long row_part_floats(int B, int C) { return ((long)1024 + B) * 4 * C; }
 
 // ================================================================================================
@@ -412,7 +385,7 @@ void modln_bwd(const Ctx& ctx, const void* dX3, const void* X1, const float* ch,
     if (dlnw) t.d[n++] = PartDesc{0, 1, g.chunks * B, 1, dlnw, 0, 1.f};
     if (dlnb) t.d[n++] = PartDesc{1, 1, g.chunks * B, 1, dlnb, 0, 1.f};
     if (dch) t.d[n++] = PartDesc{2, B, g.chunks, 1, dch, C, 1.f};
-    part_reduce(ctx, part, t, n);
+    part_reduce(ctx.stream, part, t, n);
   }
 }
 
@@ -697,7 +670,7 @@ void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2
     if (dlnw) t.d[n++] = PartDesc{0, 1, g.chunks, 1, dlnw, 0, 1.f};
     if (dlnb) t.d[n++] = PartDesc{1, 1, g.chunks, 1, dlnb, 0, 1.f};
     if (bnsums) { t.d[n++] = PartDesc{2, 1, g.chunks, 1, bnsums, 0, 1.f}; t.d[n++] = PartDesc{3, 1, g.chunks, 1, bnsums + C, 0, 1.f}; }
-    part_reduce(ctx, part, t, n);
+    part_reduce(ctx.stream, part, t, n);
   }
 }
 

@@ -84,7 +84,9 @@ static inline int col_ve(const Ctx& ctx, int C) {
 // (strip_lds).  [c_lo, c_hi): the columns of the current column super-block.
 template <int NQ, int VE>
 __device__ __forceinline__ void flush_strip(float (&acc)[NQ][VE], float* lds, int C, int col, bool active,
-                                            float* const (&dst)[NQ], int tr, int rpp, int c_lo, int c_hi) {
+                                            float* const (&dst)[NQ], int tr, int rpp, int c_lo, int c_hi,
+                                            float* part = nullptr) {
+  float* pw = part ? part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (NQ * C) : nullptr;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     __syncthreads();
@@ -103,7 +105,8 @@ __device__ __forceinline__ void flush_strip(float (&acc)[NQ][VE], float* lds, in
       for (int i = c_lo + threadIdx.x; i < c_hi; i += 256) {
         float s = 0.f;
         for (int r = 0; r < rpp; ++r) s += lds[r * C + i];
-        unsafeAtomicAdd(dst[q] + i, s);
+        if (pw) pw[q * C + i] = s;          // partial sums, finished by part_reduce_k (device_util.h)
+        else unsafeAtomicAdd(dst[q] + i, s);
       }
     }
   }
@@ -305,7 +308,7 @@ void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const 
 template <int DT, int VE>
 __global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void* x, long rows, int C, const float* mean,
                                                       const float* rstd, const float* sc, const float* sh, int relu,
-                                                      int tpr, int rpp, int rpc, float* sums) {
+                                                      int tpr, int rpp, int rpc, float* sums, float* part) {
   constexpr int UNR = UNR2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
@@ -346,16 +349,28 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void
       }
     }
     float* const dst[2] = {sums, sums + C};
-    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE));
+    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE), part);
   }
 }
 
+static inline bool strip_part() {
+  static const bool on = !(getenv("DGSCT_ROW_PART") && atoi(getenv("DGSCT_ROW_PART")) == 0);
+  return on;
+}
 void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
-                  const float* sc, const float* sh, int relu, float* sums) {
+                  const float* sc, const float* sh, int relu, float* sums, float* part, long part_floats) {
   const int ve = col_ve(ctx, C);
   ColGeom g = col_geom(UNR2, C, ve, rows, 1, 768);
+  // (workgroups x channels of atomics below ~150 k cost less than the finishing launch: measured 9.9 -> 9.0 + 4.7 us)
+  if (!strip_part() || (long)g.chunks * 2 * C > part_floats || (long)g.chunks * 2 * C < 150000) part = nullptr;
   COL_DISPATCH(ctx, ve, bn_bwd_stats_k, dim3(g.chunks), strip_lds(C, ve), dy, x, rows, C, mean, rstd, sc, sh, relu,
-               g.tpr, g.rpp, g.rpc, sums);
+               g.tpr, g.rpp, g.rpc, sums, part);
+  if (part) {
+    PartTable t; t.NQ = 2; t.C = C;
+    t.d[0] = PartDesc{0, 1, g.chunks, 1, sums, 0, 1.f};
+    t.d[1] = PartDesc{1, 1, g.chunks, 1, sums + C, 0, 1.f};
+    part_reduce(ctx.stream, part, t, 2);
+  }
 }
 
 // dx = k1*gg - k2 - x*k3 with k1 = sc, k3 = sc*rstd*s1/R, k2 = sc*s0/R - mean*k3      (training)
@@ -484,7 +499,7 @@ void outer_rows(const Ctx& ctx, const float* roww, const float* colw, int B, int
 template <int DT, int VE>
 __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, int N, int C, int tpr, int rpp, int rpc,
                                                         const float* roww, const void* colw, int cdt,
-                                                        const float* colw2, float scale, float* colsum_out) {
+                                                        const float* colw2, float scale, float* colsum_out, float* part) {
   constexpr int UNR = UNR1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y;
@@ -528,18 +543,25 @@ __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, 
     }
     if (colsum_out) {
       float* const dst[1] = {colsum_out};
-      flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE));
+      flush_strip<1, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE), part);
     }
   }
 }
 void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
-                    const float* colw2, float scale, float* colsum_out) {
+                    const float* colw2, float scale, float* colsum_out, float* part, long part_floats) {
   const int ve = col_ve(ctx, C);
   int cap = 4096;
   if (colsum_out) COL_CAPACITY(cap, ctx, ve, relu_bwd_scale_k, strip_lds(C, ve));
   ColGeom g = col_geom(UNR1, C, ve, N, B, cap, colsum_out != nullptr);
+  // partial sums pay from ~150 k atomics up (480 workgroups x 512 channels: 26.1 -> 16.4 + 4.7 us; x 128 channels: no gain)
+  if (!colsum_out || !strip_part() || (long)g.chunks * B * C > part_floats || (long)g.chunks * B * C < 150000) part = nullptr;
   COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), strip_lds(C, ve), x, y, N, C, g.tpr, g.rpp, g.rpc, roww,
-               colw, cdt, colw2, scale, colsum_out);
+               colw, cdt, colw2, scale, colsum_out, part);
+  if (part) {
+    PartTable t; t.NQ = 1; t.C = C;
+    t.d[0] = PartDesc{0, 1, g.chunks * B, 1, colsum_out, 0, 1.f};
+    part_reduce(ctx.stream, part, t, 1);
+  }
 }
 
 // ---- xc_bwd: dX1 += dXc*(1+ch); dch += sum_n dXc*X1 ------------------------------------------------------

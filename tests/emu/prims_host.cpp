@@ -178,7 +178,7 @@ void outer_rows(const Ctx& ctx, const float* roww, const float* colw, int B, int
 }
 
 void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C, const float* roww, const void* colw, int cdt,
-                    const float* colw2, float scale, float* colsum_out) {
+                    const float* colw2, float scale, float* colsum_out, float*, long) {
   for (int b = 0; b < B; ++b)
     for (int n = 0; n < N; ++n)
       for (int c = 0; c < C; ++c) {
@@ -364,7 +364,7 @@ void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const 
 }
 
 void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
-                  const float* sc, const float* sh, int relu, float* sums) {
+                  const float* sc, const float* sh, int relu, float* sums, float*, long) {
   for (int c = 0; c < C; ++c) {
     double s0 = 0, s1 = 0;
     for (long r = 0; r < rows; ++r) {
