@@ -853,7 +853,12 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     // (~0.1 us each): 480 splits of a 36 x 64 weight gradient spent 50 of 58 us there.  Step time vs cap (B=16): none 67.5,
     // 64: 67.0, 40: 66.6, 32: 66.7, 24: 67.7, 16: 72.2 ms.  DGSCT_GEMM_MAXSPLIT=0 removes the cap.
     static const int max_split = getenv("DGSCT_GEMM_MAXSPLIT") ? atoi(getenv("DGSCT_GEMM_MAXSPLIT")) : 40;
-    if (max_split > 0 && !force_split && splitk > max_split) splitk = max_split;
+    {   // ... but a workgroup should not walk more than ~32 k-tiles either (655 360-row contractions: 40 splits = 256 k-tiles
+        // each, 414 us for a 48 x 6 weight gradient that took 126 us at 512 splits)
+      const int deep = k.kt_total / 32;
+      const int cap = max_split > deep ? max_split : deep;
+      if (max_split > 0 && !force_split && splitk > cap) splitk = cap;
+    }
     int maxs = k.kt_total / 4; if (maxs < 1) maxs = 1;
     if (splitk > maxs) splitk = maxs;
     if (splitk < 1) splitk = 1;
