@@ -521,11 +521,29 @@ void gemm_kernel(const GemmK p) {
         const char* prow = Mb + (long)(nok ? n : 0) * p.ldmask * ES;
         float pv[16];
         float dot = 0.f;
+        if (MODE == DT_BF16 && (p.ldmask & 3) == 0 && p.ldmask >= 32) {
+          // the lane's 16 probabilities are 4 runs of 4 consecutive latent tokens: four 8-byte loads issued together
+          // (the per-element lde_rt compiled to 16 load + s_waitcnt vmcnt(0) pairs, i.e. 16 serial round trips)
+          uint2 w[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int t = (r & 3) + 8 * (r >> 2) + 4 * h;
-          pv[r] = (t < p.M) ? lde_rt(prow, MODE, t) : 0.f;
-          dot += pv[r] * v[r];
+          for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const uint2*>(prow + (8 * q + 4 * h) * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t0 = 8 * q + 4 * h;
+            pv[4 * q] = t0 < p.M ? __uint_as_float(w[q].x << 16) : 0.f;
+            pv[4 * q + 1] = t0 + 1 < p.M ? __uint_as_float(w[q].x & 0xffff0000u) : 0.f;
+            pv[4 * q + 2] = t0 + 2 < p.M ? __uint_as_float(w[q].y << 16) : 0.f;
+            pv[4 * q + 3] = t0 + 3 < p.M ? __uint_as_float(w[q].y & 0xffff0000u) : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dot += pv[r] * v[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = (r & 3) + 8 * (r >> 2) + 4 * h;
+            pv[r] = (t < p.M) ? lde_rt(prow, MODE, t) : 0.f;
+            dot += pv[r] * v[r];
+          }
         }
         dot += __shfl_xor(dot, 32, 64);
         const float sc = p.sm_scale ? *p.sm_scale : 1.f;
