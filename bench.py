@@ -58,11 +58,14 @@ def build_stack(backbone, dtype, device, concurrent=True):
     torch.manual_seed(0)
     stages = ave_stage_shapes(backbone)
     stack = AdapterStack(stages, compute_dtype=dtype, concurrent=concurrent).to(device)
-    stack.flatten_parameters()         # one flat fp32 parameter (and one flat gradient) per adapter: 48 tensors, not ~1900
-    with torch.no_grad():
+    with torch.no_grad():              # BEFORE flattening: afterwards the per-name tensors are views, not parameters
         for n, p in stack.named_parameters():
             if n.endswith("gate") or n.endswith("gate_av"):
                 p.fill_(0.5)                       # default 0 makes the path degenerate
+    stack.flatten_parameters()         # one flat fp32 parameter (and one flat gradient) per adapter: 48 tensors, not ~1900
+    for m in stack.modules():
+        if hasattr(m, "_flat_views"):
+            assert float(m._flat_views["gate_av"]) == 0.5 and float(m._flat_views["gate"]) == 0.5
     return stages, stack
 
 

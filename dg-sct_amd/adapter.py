@@ -234,10 +234,22 @@ class VisualAdapter(nn.Module):
         state_dict[prefix + "flat_param"] = self.flat_param.detach()
 
     def _prepared(self, lib, params, dtype, device):
+        """MFMA-operand weight copies + derived bias vectors (dgsct_prepare), re-made whenever a parameter changed.
+        The key holds every tensor's (address, version counter).  In flat mode the per-name tensors are views of
+        ``flat_param.data`` -- an alias with its OWN version counter that an optimizer step on ``flat_param`` never
+        bumps -- so the flat parameter's own (address, version) is part of the key."""
         key = (dtype, device, tuple((p.data_ptr(), p._version) for p in params if p is not None))
+        flat = self._parameters.get("flat_param") if "_flat_views" in self.__dict__ else None
+        if flat is not None:
+            key = key + ((flat.data_ptr(), flat._version),)
         if self._prep_cache is None or self._prep_cache[0] != key:
             self._prep_cache = (key, ops.prepare(lib, self.spec, params, dtype, device))
         return self._prep_cache[1]
+
+    def invalidate_prep(self):
+        """Force dgsct_prepare on the next forward (for parameter updates that bypass autograd's version counters,
+        e.g. writes through raw pointers)."""
+        self._prep_cache = None
 
     def forward(self, x, vis_token=None, caption=None, is_temporal=False, residual=None, skip=False):
         """x [BT,C,N,1], vis_token [BT,Co,No,1] (views of token-major maps) ->

@@ -277,6 +277,7 @@ int Plan::prepare(float* const* params, void* prep, void* stream) const {
     rowsum_f32(ctx, params[DGSCT_P_WN], N, No, rowb);
     zero(ctx, colb2, (size_t)C * 4);
   }
+  check_async("dgsct_prepare");
   return has_error() ? 1 : 0;
 }
 
@@ -454,6 +455,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
            d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
            d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, d.eps, R, C, out, b.S<float>(s.mu_p),
            b.S<float>(s.rstd_p), residual);        // f2: out = residual + adapter(X, Y)
+  check_async("dgsct_adapter_forward");
   return has_error() ? 1 : 0;
 }
 
@@ -808,6 +810,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   stream_join(ctx);
   if (d.remap == DGSCT_REMAP_CONV)   // + d rowsum(Wc)[c] broadcast over co (after the join: dWc is accumulated on aux)
     ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
+  check_async("dgsct_adapter_backward");
   return has_error() ? 1 : 0;
 }
 

@@ -28,13 +28,36 @@ static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 // wait has long been submitted) and separate per direction (a fork event is never reused as a join event), so the
 // ordering does not depend on how lazily the runtime resolves a pending wait.
 static hipEvent_t next_event(int dir) {
-  constexpr int RING = 1024;
-  static thread_local hipEvent_t ring[2][RING];
-  static thread_local int n[2] = {0, 0}, made[2] = {0, 0};
-  if (made[dir] < RING) { (void)hipEventCreateWithFlags(&ring[dir][made[dir]], hipEventDisableTiming); return ring[dir][made[dir]++]; }
-  hipEvent_t e = ring[dir][n[dir]];
-  n[dir] = (n[dir] + 1) % RING;
+  // one ring per (thread, device, direction): an event belongs to the device that was current when it was created, and a
+  // forward thread may serve several GPUs (nn.DataParallel replicas, AVS/AVQA call sites)
+  constexpr int RING = 1024, MAXDEV = 16;
+  struct Ring { hipEvent_t ev[RING]; int n = 0, made = 0; };
+  static thread_local Ring* rings[MAXDEV][2] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { set_error("dgsct: cannot resolve the current HIP device for a stream fork/join"); return nullptr; }
+  Ring*& r = rings[dev][dir];
+  if (!r) r = new Ring();
+  if (r->made < RING) {
+    hipError_t e = hipEventCreateWithFlags(&r->ev[r->made], hipEventDisableTiming);
+    if (e != hipSuccess) { set_error("hipEventCreateWithFlags: %s", hipGetErrorString(e)); return nullptr; }
+    return r->ev[r->made++];
+  }
+  hipEvent_t e = r->ev[r->n];
+  r->n = (r->n + 1) % RING;
   return e;
+}
+static void order_after(hipStream_t waiter, hipStream_t producer, int dir) {
+  hipEvent_t e = next_event(dir);
+  if (!e) return;
+  hipError_t r = hipEventRecord(e, producer);
+  if (r == hipSuccess) r = hipStreamWaitEvent(waiter, e, 0);
+  if (r != hipSuccess) set_error("dgsct: cross-stream ordering failed (%s) -- are both streams on the current device?", hipGetErrorString(r));
+}
+// Launch errors are sticky per thread: one check at the end of an entry point reports the first failed launch of the call
+// (a wrong current device, an invalid configuration) instead of returning 0 with uninitialised outputs.
+void check_async(const char* where) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) set_error("%s: HIP error '%s' (is the current device the one that owns the buffers and streams?)", where, hipGetErrorString(e));
 }
 void* stream_create(int priority_class) {
   int least = 0, greatest = 0;                       // numerically: the greatest priority is the SMALLER number
@@ -53,15 +76,11 @@ void stream_destroy(void* stream) {
 
 void stream_fork(const Ctx& ctx) {
   if (!ctx.aux) return;
-  hipEvent_t e = next_event(0);
-  (void)hipEventRecord(e, (hipStream_t)ctx.stream);
-  (void)hipStreamWaitEvent((hipStream_t)ctx.aux, e, 0);
+  order_after((hipStream_t)ctx.aux, (hipStream_t)ctx.stream, 0);
 }
 void stream_join(const Ctx& ctx) {
   if (!ctx.aux) return;
-  hipEvent_t e = next_event(1);
-  (void)hipEventRecord(e, (hipStream_t)ctx.aux);
-  (void)hipStreamWaitEvent((hipStream_t)ctx.stream, e, 0);
+  order_after((hipStream_t)ctx.stream, (hipStream_t)ctx.aux, 1);
 }
 
 void zero(const Ctx& ctx, void* p, size_t bytes) {

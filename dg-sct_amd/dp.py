@@ -58,6 +58,13 @@ class GradAllReducer:
         self.buckets = [b for b in self.buckets if b]
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        # Gradients a bucket must have seen before it may launch.  Not len(bucket): some parameters never receive one
+        # (`gate_tk` in the ave/avvp/pretrain flavours, `conv_adapter.*` with the bicubic remap, `fc_caption.*`, ... --
+        # SURVEY.md 8c), so their post-accumulate hooks never fire.  The first step counts who does (every rank runs the
+        # same graph, so every rank learns the same numbers); from the second step on the hooks launch each bucket as
+        # soon as its last gradient exists.
+        self._expected: List[Optional[int]] = [None] * len(self.buckets)
+        self.hook_launches = 0                          # buckets launched from hooks (before finish()) in the last step
         self._work: List[object] = []
         self._reduced: List[torch.Tensor] = []          # tensors to scale by 1/world after the wait
         self._copy_back: List[tuple] = []               # (flat, params) of the fallback path
@@ -77,7 +84,8 @@ class GradAllReducer:
                 # stream of AdapterStack): the communication stream must order after every producer of the bucket
                 self._comm_stream(param.grad.device).wait_stream(torch.cuda.current_stream(param.grad.device))
             self._pending[bi] += 1
-            if self._pending[bi] == len(self.buckets[bi]):
+            if self._expected[bi] is not None and self._pending[bi] == self._expected[bi]:
+                self.hook_launches += 1
                 self._launch(bi)
         return hook
 
@@ -141,6 +149,9 @@ class GradAllReducer:
         if not self.active:
             return
         for bi in range(len(self.buckets)):
+            n_grad = sum(1 for p in self.buckets[bi] if p.grad is not None)
+            if self._hooks and self._expected[bi] != n_grad:
+                self._expected[bi] = n_grad             # first step (or the set of used parameters changed)
             self._launch(bi)
         for w in self._work:
             w.wait()
@@ -157,6 +168,7 @@ class GradAllReducer:
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._work, self._reduced, self._copy_back = [], [], []
+        self.last_hook_launches, self.hook_launches = self.hook_launches, 0
 
     @staticmethod
     def stage_buckets(stack) -> List[List[torch.nn.Parameter]]:

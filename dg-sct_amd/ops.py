@@ -3,6 +3,7 @@ stream selection, and the autograd.Function that replaces the reference's ~45-op
 (DG-SCT/AVE/nets/net_trans.py:552-674) by one forward and one backward library call."""
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import os
 import threading
@@ -142,6 +143,12 @@ def release_workspaces():
         _WS.clear()
 
 
+def _dev_guard(t: torch.Tensor):
+    """The library launches on the CURRENT HIP device (kernel launches, occupancy queries, event creation): make it the
+    device that owns the tensors and streams of this call (a module on cuda:1 called while cuda:0 is current)."""
+    return torch.cuda.device(t.device) if t.is_cuda else contextlib.nullcontext()
+
+
 def _ptrs(params: List[Optional[torch.Tensor]]):
     return Lib.ptr_table([p.data_ptr() if p is not None else None for p in params])
 
@@ -162,7 +169,8 @@ def prepare(lib: Lib, spec: AdapterSpec, params: List[Optional[torch.Tensor]], d
     if os.environ.get("DGSCT_POISON", "0") == "1":
         prep.fill_(0xFF)
     some = next(p for p in params if p is not None)
-    lib.prepare(d, _ptrs(params), prep.data_ptr(), _stream_of(some))
+    with _dev_guard(some):
+        lib.prepare(d, _ptrs(params), prep.data_ptr(), _stream_of(some))
     return prep
 
 
@@ -211,9 +219,10 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
     ws = _workspace(dev, stream, int(sz.ws_fwd_bytes))
     if _POISON:
         _poison(out, amap, tmap, saved, ws)
-    lib.forward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), out.data_ptr(), amap.data_ptr(),
-                tmap.data_ptr() if tmap is not None else None, saved.data_ptr(), ws.data_ptr(), stream,
-                residual.data_ptr() if residual is not None else None, _aux_stream(lib, X, stream))
+    with _dev_guard(X):
+        lib.forward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), out.data_ptr(), amap.data_ptr(),
+                    tmap.data_ptr() if tmap is not None else None, saved.data_ptr(), ws.data_ptr(), stream,
+                    residual.data_ptr() if residual is not None else None, _aux_stream(lib, X, stream))
     return out, amap, tmap, saved, d
 
 
@@ -229,10 +238,11 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     ws = _workspace(dev, stream, int(sz.ws_bwd_bytes))
     if _POISON:
         _poison(dX, dY, grads, ws)
-    lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
-                 dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
-                 dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(lib, X, stream),
-                 skip_into_dx)
+    with _dev_guard(X):
+        lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
+                     dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
+                     dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(lib, X, stream),
+                     skip_into_dx)
     if flat_out:
         return dX, dY, grads
     lay = grad_layout(lib, d)
@@ -360,8 +370,9 @@ class _MapPoolFn(torch.autograd.Function):
     def forward(ctx, lib, f, amap):
         BT, N, C_ = f.shape
         pooled = torch.empty(BT, C_, dtype=torch.float32, device=f.device)
-        lib.map_pool_forward(0 if f.dtype == torch.float32 else 1, BT, N, C_, f.data_ptr(), amap.data_ptr(), pooled.data_ptr(),
-                             _stream_of(f))
+        with _dev_guard(f):
+            lib.map_pool_forward(0 if f.dtype == torch.float32 else 1, BT, N, C_, f.data_ptr(), amap.data_ptr(),
+                                 pooled.data_ptr(), _stream_of(f))
         ctx.lib = lib
         ctx.save_for_backward(f, amap)
         return pooled
@@ -374,9 +385,10 @@ class _MapPoolFn(torch.autograd.Function):
         _mark_stream_use(f, amap, dpooled)
         df = torch.empty_like(f) if ctx.needs_input_grad[1] else None
         dmap = torch.empty_like(amap) if ctx.needs_input_grad[2] else None
-        ctx.lib.map_pool_backward(0 if f.dtype == torch.float32 else 1, BT, N, C_, f.data_ptr(), amap.data_ptr(),
-                                  dpooled.data_ptr(), df.data_ptr() if df is not None else None,
-                                  dmap.data_ptr() if dmap is not None else None, _stream_of(f))
+        with _dev_guard(f):
+            ctx.lib.map_pool_backward(0 if f.dtype == torch.float32 else 1, BT, N, C_, f.data_ptr(), amap.data_ptr(),
+                                      dpooled.data_ptr(), df.data_ptr() if df is not None else None,
+                                      dmap.data_ptr() if dmap is not None else None, _stream_of(f))
         return None, df, dmap
 
 

@@ -33,6 +33,7 @@ void* stream_create(int) { return nullptr; }
 void stream_destroy(void*) {}
 void stream_fork(const Ctx&) {}
 void stream_join(const Ctx&) {}
+void check_async(const char*) {}
 
 void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
 

@@ -1,0 +1,142 @@
+"""GPU parity at the shapes of the BASELINE configs that round 1 never exercised:
+
+* Swin-V2-L widths -- what the reference code actually builds (`swinv2_large_window12_192_22k`, net_trans.py:693):
+  C = 192 / 384 / 768 / 1536 (1536 is the upper bound of Plan::validate) -- all four stages, both directions;
+* configs[3] AVS-S4: bicubic token remap 64x64 <-> 48x48 and 32x32 <-> 24x24 grids, T = 5, gate before ln_post, no ln_before
+  (avs_s4/model/PVT_AVSModel.py:190-197, 239, 272, 308-313);
+* configs[4] AVQA: tk = 2, g = 4, no BatchNorm, audio adapters without the output gate (AVQA/net_grd_avst/base_options.py:67-87);
+* configs[2] AVVP at its per-GPU batch (B = 32 over DP = 4 -> BT = 80);
+* one oracle comparison at the benchmark's BT = 160 (fp32 and bf16) so that the full-size property tests do not hang on
+  an unpinned link (fp32@160 frames).
+
+All through the C ABI, against the CPU oracle on identical (bf16-representable for the bf16 runs) inputs."""
+import pytest
+import torch
+
+from helpers import nrm_err, param_table, rel_err, spec_of
+from dgsct_amd import ops
+from dgsct_amd._lib import PARAM_NAMES, default_lib
+from oracle import dgsct_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL_F32 = 1e-3
+
+
+def _l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def run_case(N, C, No, Co, BT, dtype, flavour="ave", seed=0, over=None):
+    kw = {**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour], **(over or {})}
+    cfg = O.AdapterConfig(**kw)
+    p = O.random_params(cfg, flavour, seed=seed, scale=0.577)
+    if cfg.remap == "bicubic":
+        p["_bicubic"] = O.bicubic_matrix(No, N)
+    gen = torch.Generator().manual_seed(seed + 1)
+    X = torch.randn(BT, N, C, generator=gen)
+    Y = torch.randn(BT, No, Co, generator=gen)
+    dOut = torch.randn(BT, N, C, generator=gen)
+    dMap = torch.randn(BT, N, generator=gen)
+    if dtype == torch.bfloat16:
+        X, Y, dOut = X.bfloat16().float(), Y.bfloat16().float(), dOut.bfloat16().float()
+    po = {k: v.clone() for k, v in p.items()}
+    out_o, map_o, _, s = O.forward(po, X, Y, cfg, training=True)
+    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, None, training=True)
+    spec = spec_of(cfg)
+    params = param_table(p, spec, DEV)
+    lib = default_lib()
+    Xd, Yd = X.to(DEV, dtype).contiguous(), Y.to(DEV, dtype).contiguous()
+    prep = ops.prepare(lib, spec, params, dtype, DEV)
+    out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
+    dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(DEV, dtype).contiguous(),
+                                     dMap.to(DEV), None)
+    torch.cuda.synchronize()
+    return dict(out=(out, out_o), map=(amap, map_o), dX=(dX, dX_o), dY=(dY, dY_o),
+                grads={PARAM_NAMES[i]: (g, g_o[PARAM_NAMES[i]]) for i, g in enumerate(grads)
+                       if g is not None and PARAM_NAMES[i] in g_o},
+                extra=[PARAM_NAMES[i] for i, g in enumerate(grads) if g is not None and PARAM_NAMES[i] not in g_o],
+                missing=[k for k in g_o if k in PARAM_NAMES and grads[PARAM_NAMES.index(k)] is None])
+
+
+def check_fp32(r):
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(*r[k]) < TOL_F32, (k, rel_err(*r[k]))
+    assert not r["extra"] and not r["missing"], (r["extra"], r["missing"])
+    assert r["grads"]
+    for k, (g, go) in r["grads"].items():
+        assert rel_err(g, go.reshape(-1)) < TOL_F32, (k, rel_err(g, go.reshape(-1)))
+
+
+def check_bf16(r, grad_l2=0.1):
+    """outputs: BASELINE's 1e-2 (relative L2; worst element 3e-2 of max|ref|); gradients: see DESIGN.md section 7 (the
+    ReLU-mask / un-scaled-logit sensitivity bounds what ANY bf16-operand evaluation can reach against fp32)."""
+    for k in ("out", "map"):
+        assert torch.isfinite(r[k][0].float()).all(), k
+        assert _l2(*r[k]) < 1e-2, (k, _l2(*r[k]))
+        assert nrm_err(*r[k]) < 3e-2, (k, nrm_err(*r[k]))
+    for k in ("dX", "dY"):
+        assert _l2(*r[k]) < grad_l2, (k, _l2(*r[k]))
+    for k, (g, go) in r["grads"].items():
+        assert torch.isfinite(g).all(), k
+        if go.dim() >= 2 and go.numel() > go.shape[0] and k != "ln_before.bias":
+            assert _l2(g, go.reshape(-1)) < 1.5 * grad_l2, (k, _l2(g, go.reshape(-1)))
+
+
+# (N, C, No, Co): Swin-V2-L visual widths 192/384/768/1536 against HTS-AT 96/192/384/768, visual and audio direction
+SWIN_L = [(2304, 192, 4096, 96), (4096, 96, 2304, 192), (576, 384, 1024, 192), (1024, 192, 576, 384),
+          (144, 768, 256, 384), (256, 384, 144, 768), (36, 1536, 64, 768), (64, 768, 36, 1536)]
+
+
+@pytest.mark.parametrize("shape", SWIN_L)
+def test_swin_large_widths_fp32(shape):
+    check_fp32(run_case(*shape, BT=10, dtype=torch.float32))
+
+
+@pytest.mark.parametrize("shape", SWIN_L)
+def test_swin_large_widths_bf16(shape):
+    check_bf16(run_case(*shape, BT=10, dtype=torch.bfloat16))
+
+
+# configs[3] AVS-S4 (T = 5 frames per clip): the bicubic resize is a dense [N, No] operator between square token grids
+AVS = [(2304, 192, 4096, 96), (4096, 96, 2304, 192), (576, 384, 1024, 192), (1024, 192, 576, 384), (36, 1536, 64, 768)]
+
+
+@pytest.mark.parametrize("shape", AVS)
+def test_avs_s4_swin_large_fp32(shape):
+    check_fp32(run_case(*shape, BT=5, dtype=torch.float32, flavour="avs_s4"))
+
+
+@pytest.mark.parametrize("shape", [AVS[0], AVS[3], AVS[4]])
+def test_avs_s4_swin_large_bf16(shape):
+    check_bf16(run_case(*shape, BT=10, dtype=torch.bfloat16, flavour="avs_s4"))
+
+
+# configs[4] AVQA: tk = 2, g = 4, no BN; the audio adapters are built with use_gate = 0 (AVQA/train.sh)
+@pytest.mark.parametrize("shape,use_gate", [((2304, 192, 4096, 96), True), ((4096, 96, 2304, 192), False),
+                                            ((144, 768, 256, 384), True), ((256, 384, 144, 768), False),
+                                            ((36, 1536, 64, 768), True), ((64, 768, 36, 1536), False)])
+def test_avqa_swin_large_fp32(shape, use_gate):
+    check_fp32(run_case(*shape, BT=10, dtype=torch.float32, flavour="avqa", over=dict(use_gate=use_gate)))
+
+
+@pytest.mark.parametrize("shape,use_gate", [((2304, 192, 4096, 96), True), ((256, 384, 144, 768), False),
+                                            ((36, 1536, 64, 768), True)])
+def test_avqa_swin_large_bf16(shape, use_gate):
+    check_bf16(run_case(*shape, BT=10, dtype=torch.bfloat16, flavour="avqa", over=dict(use_gate=use_gate)))
+
+
+# configs[2] AVVP: B = 32 clips over DP = 4 -> 80 frames per GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_avvp_per_gpu_batch(dtype):
+    r = run_case(144, 512, 256, 384, BT=80, dtype=dtype, flavour="avvp")
+    (check_fp32 if dtype == torch.float32 else check_bf16)(r)
+
+
+# the benchmark's BT = 160 against the oracle (stage-2 and stage-3 shapes of BASELINE configs[1]: seconds on the CPU)
+@pytest.mark.parametrize("shape", [(144, 512, 256, 384), (64, 768, 36, 1024)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_batch_against_oracle(shape, dtype):
+    r = run_case(*shape, BT=160, dtype=dtype)
+    (check_fp32 if dtype == torch.float32 else check_bf16)(r)

@@ -190,11 +190,17 @@ def _dp_worker(rank, world, port, emu_path, q, flat):
     BT = fx["feats"][0][0].shape[0]
     lo, hi = rank * BT // world, (rank + 1) * BT // world
     feats = [(a[lo:hi].clone(), b[lo:hi].clone()) for a, b in fx["feats"]]
-    outs, maps = st(feats)
-    tensors = [t for pr in outs for t in pr]
-    grads = [g[lo:hi] for pr in fx["cots"] for g in pr]
-    torch.autograd.backward(tensors, grads)
-    red.finish()
+    for it in range(2):
+        # two steps: the first learns how many gradients each bucket really receives (gate_tk & co never get one), from
+        # the second on the hooks launch every bucket DURING backward (the overlap SURVEY.md 8e asks for)
+        for p in st.parameters():
+            p.grad = None
+        outs, maps = st(feats)
+        tensors = [t for pr in outs for t in pr]
+        grads = [g[lo:hi] for pr in fx["cots"] for g in pr]
+        torch.autograd.backward(tensors, grads)
+        red.finish()
+        assert red.last_hook_launches == (0 if it == 0 else len(red.buckets)), (it, red.last_hook_launches)
     if rank == 0:
         if flat:
             out = {}
@@ -237,3 +243,36 @@ def test_dp_allreduce_gloo_world2(flat):
     assert set(full) <= set(got)
     for k in full:
         assert rel_err(torch.from_numpy(got[k]), full[k] / 2) < 1e-4, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flat_parameters_refresh_prepared_weights_after_optimizer_step(dtype):
+    """the per-name tensors of a flattened adapter are views of `flat_param.data`, whose version counter an
+    optimizer step never bumps -- the prepare cache must key on the flat parameter itself, or training silently keeps
+    using the initial MFMA-operand weight copies / derived bias vectors."""
+    emu = Lib(build_emu())
+    fx = load_golden("ave_orderA")
+    c = fx["cfg"]
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=c["g"], is_before_layernorm=1, is_post_layernorm=1, num_tokens=c["tk"])
+
+    def make():
+        m = VisualAdapter(c["C"], c["C"], "bottleneck", reduction_factor=c["r"], opt=opt, use_bn=c["use_bn"], use_gate=c["use_gate"],
+                          num_tk=c["tk"], conv_dim_in=c["No"], conv_dim_out=c["N"], linear_in=c["Co"], linear_out=c["C"],
+                          flavour="ave", lib=emu, compute_dtype=dtype)
+        m.load_state_dict(fx["state0"])
+        return m.train()
+
+    X = fx["X"].permute(0, 2, 1).unsqueeze(-1)
+    Y = fx["Y"].permute(0, 2, 1).unsqueeze(-1)
+    m = make().flatten_parameters()
+    sgd = torch.optim.SGD(m.parameters(), lr=0.5)
+    out0 = m(X, Y)[0]
+    out0.backward(fx["dOut"].permute(0, 2, 1).unsqueeze(-1))
+    sgd.step()
+    out1 = m(X, Y)[0].detach()                 # must see the stepped weights
+    ref = make()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    ref.load_state_dict(sd)
+    out_ref = ref(X, Y)[0].detach()
+    assert rel_err(out1, out_ref) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert rel_err(out1, out0.detach()) > 1e-2, "the step did not change the output: stale prepared weights?"
