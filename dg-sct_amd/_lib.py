@@ -56,7 +56,13 @@ class GemmArgs(C.Structure):
                 ("R2", C.c_void_p), ("sm_scale", C.c_void_p), ("sm_dot", C.c_void_p)]
 
 
-EXPORTS = ["dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
+class AttnArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("mode", "B", "N", "C", "tk")] + \
+               [(n, C.c_void_p) for n in ("X", "Yp", "dX1", "R2", "out", "T0", "tok", "lse", "a", "aE", "gate_av", "dtok", "dgate",
+                                          "da")] + [("invN", C.c_float), ("dT0b", C.c_void_p), ("scratch", C.c_void_p)]
+
+
+EXPORTS = ["dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
            "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect",
            "dgsct_stream_create", "dgsct_stream_destroy", "dgsct_map_pool_forward", "dgsct_map_pool_backward"]
 
@@ -92,6 +98,9 @@ class Lib:
         c.dgsct_saved_region.argtypes = [C.POINTER(AdapterDesc), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]
         c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        c.dgsct_test_attn.argtypes = [C.c_int, C.POINTER(AttnArgs), C.c_void_p]
+        c.dgsct_test_attn_scratch_floats.argtypes = [C.c_int] * 4
+        c.dgsct_test_attn_scratch_floats.restype = C.c_int64
         c.dgsct_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         c.dgsct_stream_destroy.argtypes = [C.c_void_p]
         c.dgsct_map_pool_forward.argtypes = [C.c_int] * 4 + [C.c_void_p] * 4
@@ -158,6 +167,9 @@ class Lib:
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         self.c.dgsct_prof_collect(C.byref(n), C.byref(ms), C.byref(fl))
         return n.value, ms.value, fl.value
+
+    def test_attn(self, op: int, args: "AttnArgs", stream: int):
+        self._check(self.c.dgsct_test_attn(int(op), C.byref(args), stream), "dgsct_test_attn")
 
     def test_gemm(self, args: GemmArgs, stream: int):
         self._check(self.c.dgsct_test_gemm(C.byref(args), stream), "dgsct_test_gemm")

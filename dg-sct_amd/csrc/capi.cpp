@@ -160,6 +160,25 @@ int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
   return has_error() ? 1 : 0;
 }
 
+int64_t dgsct_test_attn_scratch_floats(int B, int N, int C, int tk) {
+  return tokattn_scratch_floats(B, N, C) + (int64_t)B * tk + 64;
+}
+int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream) {
+  clear_error();
+  if (!a) return 2;
+  Ctx ctx{stream, a->mode};
+  switch (op) {
+    case 0: tokattn_fwd(ctx, a->Yp, a->T0, a->B, a->N, a->C, a->tk, a->tok, a->lse, a->a, a->aE, a->scratch); break;
+    case 1: xattn_fwd(ctx, a->X, a->tok, a->gate_av, a->B, a->N, a->C, a->tk, a->out); break;
+    case 2: xattn_bwd(ctx, a->X, a->dX1, a->tok, a->gate_av, a->B, a->N, a->C, a->tk, a->out, a->R2, a->dtok, a->dgate); break;
+    case 3: tokattn_bwd(ctx, a->Yp, a->T0, a->tok, a->lse, a->dtok, a->da, a->invN, a->B, a->N, a->C, a->tk, a->out, a->dT0b,
+                        a->scratch); break;
+    default: set_error("dgsct_test_attn: unknown op %d", op); return 2;
+  }
+  check_async("dgsct_test_attn");
+  return has_error() ? 1 : 0;
+}
+
 int dgsct_prof_enable(int on) { gemm_prof_enable(on); return 0; }
 int dgsct_prof_collect(int64_t* launches, double* total_ms, double* total_flops) {
   long n = 0;

@@ -56,7 +56,9 @@ bool Plan::validate() {
   if (d.r <= 0 || g <= 0 || C % d.r || ds % g || C % g) return bad("C must be divisible by r and g, C/r by g");
   if (C % 4 || C > 1536) return bad("C must be a multiple of 4 and <= 1536");
   if (dd % 4) return bad("C/2 must be a multiple of 4");
-  if (tk > 64) return bad("tk must be <= 64");
+  if (tk > 32) return bad("tk must be <= 32 (the latent tokens of one frame are one 32-row MFMA tile)");
+  if (d.dtype == DT_BF16 && C % 8) return bad("C must be a multiple of 8 in bf16 mode (16-byte rows)");
+  if (N > 8192) return bad("N must be <= 8192");
   if (d.temporal && d.T > 0 && B % d.T) return bad("BT must be a multiple of T (temporal gate)");
   if (E != DT_F32 && E != DT_BF16) return bad("dtype");
   if (d.remap != DGSCT_REMAP_CONV && d.remap != DGSCT_REMAP_FIXED) return bad("remap");
@@ -72,7 +74,6 @@ void Plan::layout() {
       prep_w[id] = (E == DT_BF16) ? a.take("w", numel * es) : -1;
     };
     for (int i = 0; i < DGSCT_P_COUNT; ++i) { prep_w[i] = -1; wnumel[i] = 0; }
-    wcopy(DGSCT_P_TOKENS, (int64_t)tk * C);
     wcopy(DGSCT_P_WN, (int64_t)N * No);
     wcopy(DGSCT_P_WC, (int64_t)C * Co);
     wcopy(DGSCT_P_WA1, (int64_t)C * C);
@@ -99,10 +100,9 @@ void Plan::layout() {
     s.zero_end = a.off;
     s.Yp = a.take("Yp", R * C * es);
     s.T = a.take("T", orderA ? R * Co * es : (int64_t)B * C * Nop * es);
-    s.P1 = a.take("P1", (int64_t)B * tk * Np * es);
-    s.tok = a.take("tok", (int64_t)B * tk * C * es);
+    s.tok = a.take("tok", (int64_t)B * tk * C * 4);          // fp32: the un-scaled logits X . tok^T amplify its rounding
+    s.lse = a.take("lse", (int64_t)B * tk * 4);
     s.aE = a.take("aE", (int64_t)B * C * es);
-    s.P2 = a.take("P2", R * tkp * es);
     s.X1 = a.take("X1", R * C * es);
     s.aq1 = a.take("aq1", (int64_t)B * C * es);
     s.aq2 = a.take("aq2", (int64_t)B * dd * es);
@@ -131,8 +131,7 @@ void Plan::layout() {
   // ---- forward scratch
   {
     Arena a;
-    wf.S1 = a.take("S1", (int64_t)B * tk * Np * 4);
-    wf.S2 = a.take("S2", R * tkp * 4);
+    wf.tokscr = a.take("tokscr", tokattn_scratch_floats(B, N, C) * 4);
     ws_fwd_bytes = a.off;
   }
   // ---- backward scratch
@@ -144,6 +143,8 @@ void Plan::layout() {
     wb.dtg = a.take("dtg", (int64_t)B * 4);
     wb.u = a.take("u", (int64_t)B * dd * 4);
     wb.dwcsum = a.take("dwcsum", (int64_t)C * 4);
+    wb.dtokF = a.take("dtokF", (int64_t)B * tk * C * 4);
+    wb.dT0b = a.take("dT0b", (int64_t)B * tk * C * 4);
     wb.zero_end = a.off;
     wb.dO = a.take("dO", R * C * es);
     wb.dZ = a.take("dZ", R * ds * es);
@@ -160,14 +161,8 @@ void Plan::layout() {
     wb.dpa2 = a.take("dpa2", (int64_t)B * dd * es);
     wb.coef = a.take("coef", (int64_t)B * C * 4);
     wb.da = a.take("da", (int64_t)B * C * 4);
-    wb.daN = a.take("daN", (int64_t)B * C * 4);
     wb.dpre_t = a.take("dpre_t", (int64_t)B * 4);
-    wb.U = a.take("U", R * tkp * 4);
-    wb.dS2 = a.take("dS2", R * tkp * es);
-    wb.dtokF = a.take("dtokF", (int64_t)B * tk * C * 4);
-    wb.dtokE = a.take("dtokE", (int64_t)B * tk * C * es);
-    wb.dP1 = a.take("dP1", (int64_t)B * tk * Np * 4);
-    wb.dS1 = a.take("dS1", (int64_t)B * tk * Np * es);
+    wb.Dtok = a.take("Dtok", (int64_t)B * tk * 4);
     wb.dYp = a.take("dYp", R * C * es);
     wb.dT = a.take("dT", orderA ? R * Co * es : (int64_t)B * No * C * es);
     wb.rowtmp = a.take("rowtmp", R * 4);
@@ -321,10 +316,11 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     outE(g2, Yp, E, C, (long)N * C);
     gemm(ctx, g2);
   }
+  // F2 ---- latent tokens attend to the remapped tokens (one pass over Yp)   :572-580, :592
+  tokattn_fwd(ctx, Yp, b.F(DGSCT_P_TOKENS), B, N, C, tk, b.S<float>(s.tok), b.S<float>(s.lse), b.S<float>(s.a), b.S(s.aE),
+              b.Wk<float>(wf.tokscr));
   {
-    stream_fork(ctx);                                            // Yp is complete on the main stream
-    colsum_batched(side, Yp, C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.a), C);  // a = mean_N(Yp)
-    cvt(side, b.S<float>(s.a), b.S(s.aE), E, (long)B * C);
+    stream_fork(ctx);                                            // a = mean_N(Yp) is complete on the main stream
     Gemm g1 = mk(B, C, C);                                       // aq1 = relu(a Wa1^T + b)
     g1.A = km(b.S(s.aE), C); g1.B = km(b.W(DGSCT_P_WA1), C); g1.bias_n = b.F(DGSCT_P_BA1); g1.act = ACT_RELU;
     outE(g1, b.S(s.aq1), E, C);
@@ -334,46 +330,8 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     outE(g2, b.S(s.aq2), E, dd);
     gemm(side, g2);
   }
-  // F2 ---- latent tokens attend to the remapped tokens                  :572-580, :592
-  {
-    Gemm g1 = mk(tk, N, C, B);                                   // S1 = T0 . Yp^T
-    g1.A = km(b.W(DGSCT_P_TOKENS), C);
-    g1.B = km(Yp, C, (long)N * C);
-    outF(g1, b.Wk<float>(wf.S1), Np, (long)tk * Np);
-    gemm(ctx, g1);
-    softmax_rows(ctx, b.Wk<float>(wf.S1), Np, b.S(s.P1), E, Np, (long)B * tk, N, 0);
-    Gemm g2 = mk(tk, C, N, B);                                   // tok = T0 + P1 . Yp
-    g2.A = km(b.S(s.P1), Np, (long)tk * Np);
-    g2.B = mn(Yp, C, (long)N * C);
-    resid(g2, b.W(DGSCT_P_TOKENS), E, C, 0);
-    outE(g2, b.S(s.tok), E, C, (long)tk * C);
-    gemm(ctx, g2);
-  }
-  // F3 ---- X attends to the latent tokens                               :583-589
-  {
-    Gemm g1 = mk(N, tk, C, B);                                   // S2 = X . tok^T
-    g1.A = km(X, C, (long)N * C);
-    g1.B = km(b.S(s.tok), C, (long)tk * C);
-    if (tk <= 32) {                                              // P2 = softmax_tk(X . tok^T) in one launch: the GEMM runs
-      Gemm gt = mk(tk, N, C, B);                                 // transposed (tok . X^T) and its epilogue does the softmax
-      gt.A = km(b.S(s.tok), C, (long)tk * C);
-      gt.B = km(X, C, (long)N * C);
-      gt.act = ACT_SOFTMAX;
-      outE(gt, b.S(s.P2), E, tkp, (long)N * tkp);
-      gemm(ctx, gt);
-    } else {
-      outF(g1, b.Wk<float>(wf.S2), tkp, (long)N * tkp);
-      gemm(ctx, g1);
-      softmax_rows(ctx, b.Wk<float>(wf.S2), tkp, b.S(s.P2), E, tkp, R, tk, 0);
-    }
-    Gemm g2 = mk(N, C, tk, B);                                   // X1 = X + gate_av * P2 . tok
-    g2.A = km(b.S(s.P2), tkp, (long)N * tkp);
-    g2.B = mn(b.S(s.tok), C, (long)tk * C);
-    g2.alpha_ptr = b.F(DGSCT_P_GATE_AV);
-    resid(g2, X, E, C, (long)N * C);
-    outE(g2, b.S(s.X1), E, C, (long)N * C);
-    gemm(ctx, g2);
-  }
+  // F3 ---- X attends to the latent tokens (one pass over X)             :583-589
+  xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1));
   // F4-F6 ---- channel gate                                              :593-598
   {
     Gemm g3 = mk((int)R, C, C);                                  // vq1 = relu(X1 Wv1^T + b)
@@ -489,6 +447,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   const float* bn2 = b.S<float>(s.bn2);
   const float* tg = d.temporal ? b.S<float>(s.tg) : nullptr;
   const int cg = C / g, dg = ds / g;
+  const float invN = 1.f / (float)N;
   const bool vproj = gproj_supported(ctx.mode, C, ds, g);
 
   // B11 ---- ln_post / gate, BN2 sums
@@ -656,47 +615,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       ew(ctx, EW_OUTER_ACC, b.Wk(wb.da), DT_F32, F32(b.Wk(wb.dpre_t)), F32(b.F(DGSCT_P_WT)), NOARG, (long)B * C, 0.f, C);
     }
   }
-  // B3 ---- X <- tokens attention
+  // B3 ---- X <- tokens attention: dX (output), dtok, d gate_av in one pass over X and dX1 (P2 recomputed)
   {
-    Gemm g1 = mk(N, tk, C, B);                                   // U = dX1 . tok^T
-    g1.A = km(dX1, C, (long)N * C);
-    g1.B = km(b.S(s.tok), C, (long)tk * C);
-    if (tk <= 32) {                                              // dS2 = softmax'(U) fused: U^T = tok . dX1^T, epilogue
-      Gemm gt = mk(tk, N, C, B);
-      gt.A = km(b.S(s.tok), C, (long)tk * C);
-      gt.B = km(dX1, C, (long)N * C);
-      gt.act = ACT_SOFTMAX_BWD;
-      gt.mask = b.S(s.P2); gt.ldmask = tkp; gt.maskbs = (long)N * tkp;
-      gt.sm_scale = b.F(DGSCT_P_GATE_AV); gt.sm_dot = G(DGSCT_P_GATE_AV);
-      outE(gt, b.Wk(wb.dS2), E, tkp, (long)N * tkp);
-      gemm(ctx, gt);
-    } else {
-      outF(g1, b.Wk<float>(wb.U), tkp, (long)N * tkp);
-      gemm(ctx, g1);
-      softmax_bwd_rows(ctx, b.S(s.P2), tkp, b.Wk<float>(wb.U), tkp, b.Wk(wb.dS2), E, tkp, R, tk, b.F(DGSCT_P_GATE_AV),
-                       G(DGSCT_P_GATE_AV));
-    }
-    Gemm g2 = mk(N, C, tk, B);                                   // dX = dX1 + dS2 . tok
-    g2.A = km(b.Wk(wb.dS2), tkp, (long)N * tkp);
-    g2.B = mn(b.S(s.tok), C, (long)tk * C);
-    resid(g2, dX1, E, C, (long)N * C);
-    if (skip_into_dx) g2.R2 = dOut;                              // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
-    outE(g2, dX, E, C, (long)N * C);
-    defer([=, &side] { gemm(side, g2); });                       // dX is an OUTPUT: nothing below reads it, and dX1 / dS2 /
-    side_flush();                                                // tok are not written again -> aux stream, off the chain
-    Gemm g3 = mk(tk, C, N, B);                                   // dtok = gate_av * P2^T . dX1
-    g3.A = mn(b.S(s.P2), tkp, (long)N * tkp);
-    g3.B = mn(dX1, C, (long)N * C);
-    g3.alpha_ptr = b.F(DGSCT_P_GATE_AV);
-    outF(g3, b.Wk<float>(wb.dtokF), C, (long)tk * C);
-    gemm(ctx, g3);
-    Gemm g4 = mk(tk, C, N, B);                                   //      + dS2^T . X
-    g4.A = mn(b.Wk(wb.dS2), tkp, (long)N * tkp);
-    g4.B = mn(X, C, (long)N * C);
-    resid(g4, b.Wk(wb.dtokF), DT_F32, C, (long)tk * C);
-    outF(g4, b.Wk<float>(wb.dtokF), C, (long)tk * C);
-    gemm(ctx, g4);
-    cvt(ctx, b.Wk<float>(wb.dtokF), b.Wk(wb.dtokE), E, (long)B * tk * C);
+    xattn_bwd(ctx, X, dX1, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX, skip_into_dx ? dOut : nullptr,
+              b.Wk<float>(wb.dtokF), G(DGSCT_P_GATE_AV));     // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
     if (d.remap == DGSCT_REMAP_CONV) {
       // d fc.bias = sum_{b,n} dYp[b,n,:].  Softmax rows sum to 1 and dS1 rows sum to 0, so this equals
       // sum_b (sum_t dtok[b,t,:] + da[b,:]) exactly -- computed from these two small fp32 tensors instead of
@@ -705,36 +627,15 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       sum_batch(ctx, b.Wk<float>(wb.da), C, B, C, G(DGSCT_P_BC), 1.f, 1);
     }
   }
-  // B2 ---- tokens <- remapped tokens attention
+  // B2 ---- tokens <- remapped tokens attention: dYp and d my_tokens in one pass over Yp (P1 recomputed from lse)
   void* dYp = b.Wk(wb.dYp);
   {
-    const void* Yp = b.S(s.Yp);
-    Gemm g1 = mk(tk, N, C, B);                                   // dP1 = dtok . Yp^T
-    g1.A = km(b.Wk(wb.dtokE), C, (long)tk * C);
-    g1.B = km(Yp, C, (long)N * C);
-    outF(g1, b.Wk<float>(wb.dP1), Np, (long)tk * Np);
-    gemm(ctx, g1);
-    softmax_bwd_rows(ctx, b.S(s.P1), Np, b.Wk<float>(wb.dP1), Np, b.Wk(wb.dS1), E, Np, (long)B * tk, N, nullptr, nullptr);
-    Gemm g2 = mk(tk, C, N, B);                                   // dtokF += dS1 . Yp      (then summed over b -> dT0)
-    g2.A = km(b.Wk(wb.dS1), Np, (long)tk * Np);
-    g2.B = mn(Yp, C, (long)N * C);
-    resid(g2, b.Wk(wb.dtokF), DT_F32, C, (long)tk * C);
-    outF(g2, b.Wk<float>(wb.dtokF), C, (long)tk * C);
-    gemm(ctx, g2);
-    defer([=, &side, &b] { sum_batch(side, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1); });
-    ew(ctx, EW_SCALE, b.Wk(wb.daN), DT_F32, F32(b.Wk(wb.da)), NOARG, NOARG, (long)B * C, 1.f / (float)N, 1);
-    Gemm g3 = mk(N, C, tk, B);                                   // dYp = P1^T . dtok + da/N
-    g3.A = mn(b.S(s.P1), Np, (long)tk * Np);
-    g3.B = mn(b.Wk(wb.dtokE), C, (long)tk * C);
-    g3.bias_n = b.Wk<float>(wb.daN); g3.bias_n_bs = C;
-    outE(g3, dYp, E, C, (long)N * C);
-    gemm(ctx, g3);
-    Gemm g4 = mk(N, C, tk, B);                                   //      + dS1^T . T0
-    g4.A = mn(b.Wk(wb.dS1), Np, (long)tk * Np);
-    g4.B = mn(b.W(DGSCT_P_TOKENS), C, 0);
-    resid(g4, dYp, E, C, (long)N * C);
-    outE(g4, dYp, E, C, (long)N * C);
-    gemm(ctx, g4);
+    tokattn_bwd(ctx, b.S(s.Yp), b.F(DGSCT_P_TOKENS), b.S<float>(s.tok), b.S<float>(s.lse), b.Wk<float>(wb.dtokF),
+                b.Wk<float>(wb.da), invN, B, N, C, tk, dYp, b.Wk<float>(wb.dT0b), b.Wk<float>(wb.Dtok));
+    defer([=, &side, &b] {                                       // d my_tokens = sum_b (dtok + dS1 . Yp)
+      sum_batch(side, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
+      sum_batch(side, b.Wk<float>(wb.dT0b), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
+    });
   }
   // B1 ---- remap
   {

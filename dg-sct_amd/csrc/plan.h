@@ -24,17 +24,16 @@ struct Plan {
   // saved
   struct {
     int64_t a, mvq1, bnacc1, bnacc2, zero_end;
-    int64_t Yp, T, P1, tok, aE, P2, X1, aq1, aq2, vq1, m1, q, ch, Xc, vq2, sl, sg, map, tg, X3, mu_b, rstd_b, Zp, Z, Op,
+    int64_t Yp, T, tok, lse, aE, X1, aq1, aq2, vq1, m1, q, ch, Xc, vq2, sl, sg, map, tg, X3, mu_b, rstd_b, Zp, Z, Op,
         bn1, bn2, mu_p, rstd_p;
   } s;
   std::vector<Region> saved_regions;
   int64_t saved_bytes;
   // forward / backward scratch
-  struct { int64_t S1, S2; } wf;
+  struct { int64_t tokscr; } wf;
   struct {
-    int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, zero_end;
-    int64_t dO, dZ, dX3, dX1, dXc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, daN, dpre_t, U, dS2, dtokF,
-        dtokE, dP1, dS1, dYp, dT, rowtmp, rowpart;
+    int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, dtokF, dT0b, zero_end;
+    int64_t dO, dZ, dX3, dX1, dXc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dYp, dT, rowtmp, rowpart;
   } wb;
   int64_t ws_fwd_bytes, ws_bwd_bytes;
   // gradients

@@ -160,6 +160,23 @@ void tail_bwd(const Ctx&, const void* dOut, const void* Op, const float* sc2, co
               const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums,
               float* part = nullptr, long part_floats = 0);
 
+// ---- fused latent-token attention (attn.hip; reference net_trans.py:572-589 and its autograd) ------------------------
+// tok fp32 [B][tk][C] = T0 + softmax_N(T0 Yp^T) Yp;  lse fp32 [B][tk] = log sum_n exp(logit);  a fp32 [B][C] = mean_N Yp
+// (a must be pre-zeroed; aE: optional copy of a in E);  scratch: tokattn_scratch_floats(B, N, C) floats.  tk <= 32.
+long tokattn_scratch_floats(int B, int N, int C);
+void tokattn_fwd(const Ctx&, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
+                 void* aE, float* scratch);
+// X1 (E) = X + gate_av * softmax_tk(X tok^T) tok
+void xattn_fwd(const Ctx&, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1);
+// backward of xattn_fwd w.r.t. X and tok given dX1 (E): dX (E) = dX1 + dS2 tok (+ R2, optional, E);
+// dtok fp32 [B][tk][C] += gate_av P2^T dX1 + dS2^T X  (pre-zeroed);  *dgate += sum P2 (dX1 tok^T)  (optional)
+void xattn_bwd(const Ctx&, const void* X, const void* dX1, const float* tok, const float* gate_av, int B, int N, int C, int tk,
+               void* dX, const void* R2, float* dtok, float* dgate);
+// backward of tokattn_fwd given dtok: dYp (E) = P1^T dtok + dS1^T T0 + invN * da[b];  dT0b fp32 [B][tk][C] += dS1 Yp
+// (pre-zeroed; the my_tokens gradient is sum_b (dtok + dT0b));  Dscratch: B*tk floats.
+void tokattn_bwd(const Ctx&, const void* Yp, const float* T0, const float* tok, const float* lse, const float* dtok,
+                 const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float* Dscratch);
+
 // Small fp32/E elementwise helpers on [n]-sized vectors (n <= a few 100k).
 enum EwOp : int {
   EW_MUL = 0,          // o = a*b

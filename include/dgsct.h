@@ -186,6 +186,20 @@ typedef struct dgsct_gemm_args {
 } dgsct_gemm_args;
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream);
 
+/* One fused latent-token attention kernel (csrc/attn.hip; reference net_trans.py:572-589 and its autograd), for unit
+ * tests against torch and for tools/attn_bench.py.  op: 0 tokattn_fwd, 1 xattn_fwd, 2 xattn_bwd, 3 tokattn_bwd.
+ * Activations X / Yp / dX1 / out / R2: [B][N][C] in `mode`'s element type; T0 [tk][C], tok / dtok / dT0b [B][tk][C], lse [B][tk],
+ * a / da [B][C]: fp32.  Accumulated outputs (a, dtok, dT0b, dgate) must be zeroed by the caller.  scratch: at least
+ * dgsct_test_attn_scratch_floats(B, N, C, tk) floats. */
+typedef struct dgsct_attn_args {
+  int32_t mode, B, N, C, tk;
+  const void* X; const void* Yp; const void* dX1; const void* R2; void* out;
+  const float* T0; float* tok; float* lse; float* a; void* aE; const float* gate_av;
+  float* dtok; float* dgate; const float* da; float invN; float* dT0b; float* scratch;
+} dgsct_attn_args;
+int64_t dgsct_test_attn_scratch_floats(int B, int N, int C, int tk);
+int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream);
+
 /* ---- measurement hook (bench.py roofline leg) ---------------------------------------------------
  * While enabled, every launch of the MFMA GEMM family issued from the calling thread is bracketed by
  * HIP events on its own stream; collect() synchronises them and returns the number of launches, the sum

@@ -480,3 +480,134 @@ void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out) {
 }
 
 }  // namespace dgsct
+
+// ---- fused latent-token attention (host loops; same rounding points as csrc/attn.hip: probabilities / dS stored in E,
+// fp32 latent tokens enter the logit products as hi + lo (here: exactly), hi only where attn.hip uses the hi part) ------
+namespace dgsct {
+static inline float rnd(float v, int dt) { return dt == DT_F32 ? v : bf2f(f2bf(v)); }
+long tokattn_scratch_floats(int, int, int) { return 64; }
+void tokattn_fwd(const Ctx& ctx, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
+                 void* aE, float*) {
+  const int E = ctx.mode;
+  std::vector<double> S(N);
+  for (int b = 0; b < B; ++b) {
+    for (int t = 0; t < tk; ++t) {
+      double mx = -INFINITY;
+      for (int n = 0; n < N; ++n) {
+        double s = 0;
+        for (int c = 0; c < C; ++c) s += (double)T0[(long)t * C + c] * ld(Yp, E, ((long)b * N + n) * C + c);
+        S[n] = s; mx = std::max(mx, s);
+      }
+      double l = 0;
+      for (int n = 0; n < N; ++n) l += std::exp(S[n] - mx);
+      lse[(long)b * tk + t] = (float)(mx + std::log(l));
+      for (int c = 0; c < C; ++c) {
+        double o = 0;
+        for (int n = 0; n < N; ++n) o += (double)rnd((float)std::exp(S[n] - mx), E) * ld(Yp, E, ((long)b * N + n) * C + c);
+        tok[((long)b * tk + t) * C + c] = T0[(long)t * C + c] + (float)(o / l);
+      }
+    }
+    for (int c = 0; c < C; ++c) {
+      double s = 0;
+      for (int n = 0; n < N; ++n) s += ld(Yp, E, ((long)b * N + n) * C + c);
+      const float av = (float)(s / N);
+      a[(long)b * C + c] = av;
+      if (aE) st(aE, E, (long)b * C + c, av);
+    }
+  }
+}
+static void p2_row(const void* X, int E, const float* tokb, long xo, int C, int tk, std::vector<double>& P) {
+  double mx = -INFINITY;
+  for (int t = 0; t < tk; ++t) {
+    double s = 0;
+    for (int c = 0; c < C; ++c) s += (double)ld(X, E, xo + c) * tokb[(long)t * C + c];
+    P[t] = s; mx = std::max(mx, s);
+  }
+  double l = 0;
+  for (int t = 0; t < tk; ++t) { P[t] = std::exp(P[t] - mx); l += P[t]; }
+  for (int t = 0; t < tk; ++t) P[t] /= l;
+}
+void xattn_fwd(const Ctx& ctx, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1) {
+  const int E = ctx.mode;
+  std::vector<double> P(tk);
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      const long xo = ((long)b * N + n) * C;
+      const float* tokb = tok + (long)b * tk * C;
+      p2_row(X, E, tokb, xo, C, tk, P);
+      for (int c = 0; c < C; ++c) {
+        double o = 0;
+        for (int t = 0; t < tk; ++t) o += (double)rnd((float)P[t], E) * tokb[(long)t * C + c];
+        st(X1, E, xo + c, ld(X, E, xo + c) + *gate_av * (float)o);
+      }
+    }
+}
+void xattn_bwd(const Ctx& ctx, const void* X, const void* dX1, const float* tok, const float* gate_av, int B, int N, int C, int tk,
+               void* dX, const void* R2, float* dtok, float* dgate) {
+  const int E = ctx.mode;
+  const float g = *gate_av;
+  std::vector<double> P(tk), U(tk);
+  std::vector<float> Pe(tk), dSe(tk);
+  double dg = 0;
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      const long xo = ((long)b * N + n) * C;
+      const float* tokb = tok + (long)b * tk * C;
+      p2_row(X, E, tokb, xo, C, tk, P);
+      double dot = 0;
+      for (int t = 0; t < tk; ++t) {
+        double u = 0;
+        for (int c = 0; c < C; ++c) u += (double)ld(dX1, E, xo + c) * tokb[(long)t * C + c];
+        U[t] = u; dot += P[t] * u;
+      }
+      dg += dot;
+      for (int t = 0; t < tk; ++t) { Pe[t] = rnd((float)P[t], E); dSe[t] = rnd((float)(g * P[t] * (U[t] - dot)), E); }
+      for (int c = 0; c < C; ++c) {
+        double o = 0;
+        for (int t = 0; t < tk; ++t) o += (double)dSe[t] * rnd(tokb[(long)t * C + c], E);
+        float v = rnd(ld(dX1, E, xo + c) + (float)o, E);
+        if (R2) v += ld(R2, E, xo + c);
+        st(dX, E, xo + c, v);
+      }
+      for (int t = 0; t < tk; ++t)
+        for (int c = 0; c < C; ++c)
+          dtok[((long)b * tk + t) * C + c] += g * Pe[t] * ld(dX1, E, xo + c) + dSe[t] * ld(X, E, xo + c);
+    }
+  if (dgate) *dgate += (float)dg;
+}
+void tokattn_bwd(const Ctx& ctx, const void* Yp, const float* T0, const float* tok, const float* lse, const float* dtok,
+                 const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float*) {
+  const int E = ctx.mode;
+  std::vector<float> P1((size_t)tk * N), dS1((size_t)tk * N);
+  for (int b = 0; b < B; ++b) {
+    for (int t = 0; t < tk; ++t) {
+      double D = 0;
+      for (int c = 0; c < C; ++c) D += (double)dtok[((long)b * tk + t) * C + c] * (tok[((long)b * tk + t) * C + c] - T0[(long)t * C + c]);
+      for (int n = 0; n < N; ++n) {
+        double s = 0, dp = 0;
+        for (int c = 0; c < C; ++c) {
+          const double y = ld(Yp, E, ((long)b * N + n) * C + c);
+          s += (double)T0[(long)t * C + c] * y;
+          dp += (double)rnd(dtok[((long)b * tk + t) * C + c], E) * y;
+        }
+        const double p = std::exp(s - lse[(long)b * tk + t]);
+        P1[(size_t)t * N + n] = rnd((float)p, E);
+        dS1[(size_t)t * N + n] = rnd((float)(p * (dp - D)), E);
+      }
+    }
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < C; ++c) {
+        double o = 0;
+        for (int t = 0; t < tk; ++t)
+          o += (double)P1[(size_t)t * N + n] * rnd(dtok[((long)b * tk + t) * C + c], E) + (double)dS1[(size_t)t * N + n] * rnd(T0[(long)t * C + c], E);
+        st(dYp, E, ((long)b * N + n) * C + c, (float)o + da[(long)b * C + c] * invN);
+      }
+    for (int t = 0; t < tk; ++t)
+      for (int c = 0; c < C; ++c) {
+        double o = 0;
+        for (int n = 0; n < N; ++n) o += (double)dS1[(size_t)t * N + n] * ld(Yp, E, ((long)b * N + n) * C + c);
+        dT0b[((long)b * tk + t) * C + c] += (float)o;
+      }
+  }
+}
+}  // namespace dgsct
