@@ -31,7 +31,7 @@ constexpr int MAX_CHUNKS = 64;     // chunks of one frame (N <= 8192)
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 // the fp32 mode is the parity path (1e-3 against the reference): accurate exp there, the hardware approximation in bf16
-template <int MODE> __device__ __forceinline__ float mexp(float x) { return MODE == DT_F32 ? expf(x) : mexp<MODE>(x); }
+template <int MODE> __device__ __forceinline__ float mexp(float x) { return MODE == DT_F32 ? expf(x) : __expf(x); }
 
 // wave-local copy of rows [row0, row0 + 32) x TC columns of an LDS image to a token-major global tensor (16-byte stores);
 // `add` (optional, same layout as dst) is added on the way out.
