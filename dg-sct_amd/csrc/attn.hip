@@ -18,6 +18,7 @@
 // 16-byte row stores.  Both arithmetic modes of the library share the code (mma_tile.h).
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdlib>
 #include "prims.h"
 #include "device_util.h"
 #include "mma_tile.h"
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void tokattn_combine_k(const TokCombArgs p) {
 // ====================================================================================================================
 // xattn_fwd: X1 = X + gate_av * softmax_t(X . tok^T) . tok
 // ====================================================================================================================
-struct XFwdArgs { const void* X; const float* tok; const float* gate_av; int N, C, tk; void* X1; };
+struct XFwdArgs { const void* X; const float* tok; const float* gate_av; int N, C, tk; void* X1; int dbg; };
 template <int MODE>
 __global__ __launch_bounds__(256) void xattn_fwd_k(const XFwdArgs p) {
   using M = MT<MODE>;
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_k(const XFwdArgs p) {
       stv<MODE, 4>(prow, 8 * q + 4 * (lane >> 5), v);
     }
   }
+  if (p.dbg == 1) return;
   {   // ---- phase B: X1[n][c] = X[n][c] + g * sum_t P[n][t] tok[t][c]
     char* sX = smem; char* sTh = smem + NCH_ROWS * PXB; char* sTl = sTh + 32 * PTB;
     for (int cs = 0; cs < p.C; cs += CSB) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_k(const XFwdArgs p) {
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < CSB / 32; ++j) {
-        if (cs + 32 * j >= p.C) break;
+        if (cs + 32 * j >= p.C || p.dbg == 2) break;
         mt_f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_k(const XFwdArgs p) {
           ste<MODE>(q, c, lde<MODE>(q, c) + g * o[r]);
         }
       }
+      if (p.dbg != 3)
       copy_out_rows<MODE, CSB>(sX, PXB, 32 * wave, p.X1, nullptr, p.C, (long)b * p.N + n0 + 32 * wave, p.N - n0 - 32 * wave, cs,
                                p.C, lane);
     }
@@ -520,8 +523,12 @@ long tokattn_scratch_floats(int B, int N, int C) {
   const long nch = (N + NCH_ROWS - 1) / NCH_ROWS;
   return (long)B * nch * (32L * C + 64);
 }
+// attn2.hip
+bool attn2_ok(const Ctx& ctx, int C);
+void xattn_fwd2(const Ctx& ctx, const void* X, const void* tokpk, const float* gate_av, int B, int N, int C, int tk, void* X1);
+
 void tokattn_fwd(const Ctx& ctx, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
-                 void* aE, float* scratch) {
+                 void* aE, float* scratch, void* tokpk) {
   if (!attn_shape_ok(ctx, N, C, tk)) return;
   const int nch = (N + NCH_ROWS - 1) / NCH_ROWS;
   TokFwdArgs p{Yp, T0, N, C, tk, nch, scratch, scratch + (long)B * nch * 32 * C, a};
@@ -530,10 +537,13 @@ void tokattn_fwd(const Ctx& ctx, const void* Yp, const float* T0, int B, int N, 
   else hipLaunchKernelGGL(tokattn_fwd_k<DT_F32>, dim3(nch, B), dim3(256), 0, s, p);
   TokCombArgs q{p.partO, p.partML, T0, C, tk, nch, 1.f / (float)N, tok, lse, a, aE, ctx.mode};
   hipLaunchKernelGGL(tokattn_combine_k, dim3((C + 255) / 256, B), dim3(256), 0, s, q);
+  if (tokpk && attn2_ok(ctx, C)) tok_pack(ctx, tok, B, tk, C, tokpk);
 }
-void xattn_fwd(const Ctx& ctx, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1) {
+void xattn_fwd(const Ctx& ctx, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1,
+               const void* tokpk) {
   if (!attn_shape_ok(ctx, N, C, tk)) return;
-  XFwdArgs p{X, tok, gate_av, N, C, tk, X1};
+  if (tokpk && attn2_ok(ctx, C)) { xattn_fwd2(ctx, X, tokpk, gate_av, B, N, C, tk, X1); return; }
+  XFwdArgs p{X, tok, gate_av, N, C, tk, X1, getenv("DGSCT_ATTN_DBG") ? atoi(getenv("DGSCT_ATTN_DBG")) : 0};
   const dim3 grid((N + NCH_ROWS - 1) / NCH_ROWS, B);
   if (ctx.mode == DT_BF16) hipLaunchKernelGGL(xattn_fwd_k<DT_BF16>, grid, dim3(256), 0, (hipStream_t)ctx.stream, p);
   else hipLaunchKernelGGL(xattn_fwd_k<DT_F32>, grid, dim3(256), 0, (hipStream_t)ctx.stream, p);

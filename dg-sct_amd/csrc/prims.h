@@ -164,10 +164,17 @@ void tail_bwd(const Ctx&, const void* dOut, const void* Op, const float* sc2, co
 // tok fp32 [B][tk][C] = T0 + softmax_N(T0 Yp^T) Yp;  lse fp32 [B][tk] = log sum_n exp(logit);  a fp32 [B][C] = mean_N Yp
 // (a must be pre-zeroed; aE: optional copy of a in E);  scratch: tokattn_scratch_floats(B, N, C) floats.  tk <= 32.
 long tokattn_scratch_floats(int B, int N, int C);
+// tokpk (optional, bf16 mode): the latent tokens PACKED for the wave-centric fast kernels (attn2.hip): per frame
+// [hi 32 x C | lo 32 x C | transposed C x 32] bf16 = tok_pack_elems(B, C) elements; consumers fall back to the generic
+// kernels when it is null.
+long tok_pack_elems(int nb, int C);
+void tok_pack(const Ctx&, const float* src, int nb, int tk, int C, void* pk, const float* other = nullptr, const float* base = nullptr,
+              float* D = nullptr);       // D[b][t] = sum_c src * (other - base)   (optional)
 void tokattn_fwd(const Ctx&, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
-                 void* aE, float* scratch);
+                 void* aE, float* scratch, void* tokpk = nullptr);
 // X1 (E) = X + gate_av * softmax_tk(X tok^T) tok
-void xattn_fwd(const Ctx&, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1);
+void xattn_fwd(const Ctx&, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1,
+               const void* tokpk = nullptr);
 // backward of xattn_fwd w.r.t. X and tok given dX1 (E): dX (E) = dX1 + dS2 tok (+ R2, optional, E);
 // dtok fp32 [B][tk][C] += gate_av P2^T dX1 + dS2^T X  (pre-zeroed);  *dgate += sum P2 (dX1 tok^T)  (optional)
 void xattn_bwd(const Ctx&, const void* X, const void* dX1, const float* tok, const float* gate_av, int B, int N, int C, int tk,

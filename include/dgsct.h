@@ -196,6 +196,7 @@ typedef struct dgsct_attn_args {
   const void* X; const void* Yp; const void* dX1; const void* R2; void* out;
   const float* T0; float* tok; float* lse; float* a; void* aE; const float* gate_av;
   float* dtok; float* dgate; const float* da; float invN; float* dT0b; float* scratch;
+  void* tokpk;         /* optional: 96 * B * C bf16 (packed latent tokens: written by op 0, read by ops 1-3) */
 } dgsct_attn_args;
 int64_t dgsct_test_attn_scratch_floats(int B, int N, int C, int tk);
 int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream);

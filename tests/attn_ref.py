@@ -50,7 +50,7 @@ class AttnCall:
         r = lambda *s: torch.randn(*s, generator=gen)
         self.lib, self.dtype, self.dims = lib, dtype, (B, N, C, tk)
         self.X, self.Yp, self.dX1, self.R2 = (r(B, N, C).to(dtype).float() for _ in range(4))
-        self.Yp = self.Yp * 0.4
+        self.Yp = (self.Yp * 0.4).to(dtype).float()
         self.T0 = torch.rand(tk, C, generator=gen)
         self.dtok_in = r(B, tk, C)
         self.da = r(B, C)
@@ -61,7 +61,8 @@ class AttnCall:
                       tok=torch.empty(B, tk, C, device=dev), lse=torch.empty(B, tk, device=dev), a=torch.zeros(B, C, device=dev),
                       aE=torch.empty(B, C, device=dev, dtype=dtype), dtok=torch.zeros(B, tk, C, device=dev),
                       dgate=torch.zeros(1, device=dev), dT0b=torch.zeros(B, tk, C, device=dev),
-                      scratch=torch.empty(int(lib.c.dgsct_test_attn_scratch_floats(B, N, C, tk)), device=dev))
+                      scratch=torch.empty(int(lib.c.dgsct_test_attn_scratch_floats(B, N, C, tk)), device=dev),
+                      tokpk=torch.zeros(96 * B * C, device=dev, dtype=torch.bfloat16))
         a = AttnArgs()
         a.mode = 1 if dtype == torch.bfloat16 else 0
         a.B, a.N, a.C, a.tk = B, N, C, tk

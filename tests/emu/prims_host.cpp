@@ -486,8 +486,10 @@ void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out) {
 namespace dgsct {
 static inline float rnd(float v, int dt) { return dt == DT_F32 ? v : bf2f(f2bf(v)); }
 long tokattn_scratch_floats(int, int, int) { return 64; }
+long tok_pack_elems(int nb, int C) { return (long)nb * 96 * C; }
+void tok_pack(const Ctx&, const float*, int, int, int, void*, const float*, const float*, float*) {}
 void tokattn_fwd(const Ctx& ctx, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
-                 void* aE, float*) {
+                 void* aE, float*, void*) {
   const int E = ctx.mode;
   std::vector<double> S(N);
   for (int b = 0; b < B; ++b) {
@@ -527,7 +529,8 @@ static void p2_row(const void* X, int E, const float* tokb, long xo, int C, int 
   for (int t = 0; t < tk; ++t) { P[t] = std::exp(P[t] - mx); l += P[t]; }
   for (int t = 0; t < tk; ++t) P[t] /= l;
 }
-void xattn_fwd(const Ctx& ctx, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1) {
+void xattn_fwd(const Ctx& ctx, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1,
+               const void*) {
   const int E = ctx.mode;
   std::vector<double> P(tk);
   for (int b = 0; b < B; ++b)
