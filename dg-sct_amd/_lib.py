@@ -59,7 +59,8 @@ class GemmArgs(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("mode", "B", "N", "C", "tk")] + \
                [(n, C.c_void_p) for n in ("X", "Yp", "dX1", "R2", "out", "T0", "tok", "lse", "a", "aE", "gate_av", "dtok", "dgate",
-                                          "da")] + [("invN", C.c_float), ("dT0b", C.c_void_p), ("scratch", C.c_void_p), ("tokpk", C.c_void_p)]
+                                          "da")] + [("invN", C.c_float), ("dT0b", C.c_void_p), ("scratch", C.c_void_p), ("tokpk", C.c_void_p), ("T0pk", C.c_void_p),
+                                                               ("dtokpk", C.c_void_p)]
 
 
 EXPORTS = ["dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",

@@ -526,6 +526,10 @@ long tokattn_scratch_floats(int B, int N, int C) {
 // attn2.hip
 bool attn2_ok(const Ctx& ctx, int C);
 void xattn_fwd2(const Ctx& ctx, const void* X, const void* tokpk, const float* gate_av, int B, int N, int C, int tk, void* X1);
+void xattn_bwd2(const Ctx& ctx, const void* X, const void* dX1, const void* tokpk, const float* gate_av, int B, int N, int C, int tk,
+                void* dX, const void* R2, float* dtok, float* dgate);
+void tokattn_bwd2(const Ctx& ctx, const void* Yp, const void* T0pk, const void* dtokpk, const float* lse, const float* D,
+                  const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b);
 
 void tokattn_fwd(const Ctx& ctx, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
                  void* aE, float* scratch, void* tokpk) {
@@ -549,16 +553,23 @@ void xattn_fwd(const Ctx& ctx, const void* X, const float* tok, const float* gat
   else hipLaunchKernelGGL(xattn_fwd_k<DT_F32>, grid, dim3(256), 0, (hipStream_t)ctx.stream, p);
 }
 void xattn_bwd(const Ctx& ctx, const void* X, const void* dX1, const float* tok, const float* gate_av, int B, int N, int C, int tk,
-               void* dX, const void* R2, float* dtok, float* dgate) {
+               void* dX, const void* R2, float* dtok, float* dgate, const void* tokpk) {
   if (!attn_shape_ok(ctx, N, C, tk)) return;
+  if (tokpk && attn2_ok(ctx, C)) { xattn_bwd2(ctx, X, dX1, tokpk, gate_av, B, N, C, tk, dX, R2, dtok, dgate); return; }
   XBwdArgs p{X, dX1, tok, gate_av, N, C, tk, dX, R2, dtok, dgate};
   const dim3 grid((N + NCH_ROWS - 1) / NCH_ROWS, B);
   if (ctx.mode == DT_BF16) hipLaunchKernelGGL(xattn_bwd_k<DT_BF16>, grid, dim3(256), 0, (hipStream_t)ctx.stream, p);
   else hipLaunchKernelGGL(xattn_bwd_k<DT_F32>, grid, dim3(256), 0, (hipStream_t)ctx.stream, p);
 }
 void tokattn_bwd(const Ctx& ctx, const void* Yp, const float* T0, const float* tok, const float* lse, const float* dtok,
-                 const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float* Dscratch) {
+                 const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float* Dscratch,
+                 const void* T0pk, void* dtokpk) {
   if (!attn_shape_ok(ctx, N, C, tk)) return;
+  if (T0pk && dtokpk && attn2_ok(ctx, C)) {
+    tok_pack(ctx, dtok, B, tk, C, dtokpk, tok, T0, Dscratch);       // packed dtok + D[b][t] = dtok . (tok - T0)
+    tokattn_bwd2(ctx, Yp, T0pk, dtokpk, lse, Dscratch, da, invN, B, N, C, tk, dYp, dT0b);
+    return;
+  }
   hipStream_t s = (hipStream_t)ctx.stream;
   hipLaunchKernelGGL(tok_rowdot_k, dim3((B * tk + 3) / 4), dim3(256), 0, s, dtok, tok, T0, B * tk, tk, C, Dscratch);
   TokBwdArgs p{Yp, T0, lse, Dscratch, dtok, da, invN, N, C, tk, dYp, dT0b};

@@ -8,8 +8,12 @@
 // long as both operands agree -- the packed transposed image is stored in exactly that order).  There is no
 // __syncthreads in the token loops: 16 independent wavefronts per CU overlap each other's loads and MFMAs.
 //
-// Packed latent tokens ("tokpk", per frame or per parameter): [hi 32 x C | lo 32 x C | T C x 32] bf16, rows >= tk zero,
-//   T[c][perm(t)] = hi[t][c] with perm(16k + 4h + 8q + e) = 16k + 8h + 4q + e   (k, h, q in {0,1}, e < 4).
+// Packed latent tokens ("tokpk", per frame or per parameter): three bf16 images of 32 x C elements each, rows >= tk zero,
+// stored in MFMA-FRAGMENT ORDER so that one operand load of a wave is 64 lanes x 16 B = 1 KiB contiguous (a row-major
+// image costs 32 cache lines per load -- one per latent token -- and the L1 transaction rate, not HBM, bounds the kernel):
+//   hiF / loF [C/16][2][32][8] : element ((kk*2 + h)*32 + t)*8 + e            = hi / lo of tok[t][16 kk + 8 h + e]
+//   TF [C/32][2][2][32][8]     : element (((j*2 + kk)*2 + h)*32 + c)*8 + e    = hi of tok[16 kk + 4 h + (e&3) + 8 (e>>2)][32 j + c]
+// (TF's latent-token order is the order in which a lane holds the probabilities of its token row after the first product).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "prims.h"
@@ -26,7 +30,6 @@ constexpr int CS2 = 128;                       // channels per slab
 constexpr int PX2 = CS2 * 2 + 16;              // pitch of a private [32][CS2] bf16 image (272 B: conflict-free b128 rows)
 constexpr int IMG2 = 32 * PX2;                 // 8704 B per image
 
-__host__ __device__ inline int perm_pos(int t) { return (t & 16) | (((t >> 2) & 1) << 3) | (((t >> 3) & 1) << 2) | (t & 3); }
 __device__ __forceinline__ float xor32b(float v) { return __shfl_xor(v, 32, 64); }
 // LDS traffic between lanes of ONE wavefront: the hardware executes a wave's LDS instructions in order; this only stops
 // the compiler from moving accesses across the hand-off
@@ -88,15 +91,31 @@ __device__ __forceinline__ void slab_copy_out(const char* img, unsigned short* d
 // acc[t][n] += sum_c tok[t][c] * X[n][c] over one slab: A fragments (latent tokens, hi and optionally lo) from global,
 // B fragments (the wave's token rows) from its private image
 template <bool LO>
-__device__ __forceinline__ void logits_slab(f32x16& acc, const unsigned short* th, const unsigned short* tl, long C, int c0, int kc,
+__device__ __forceinline__ void logits_slab(f32x16& acc, const unsigned short* hiF, const unsigned short* loF, int c0, int kc,
                                             const char* img, int lane) {
-  const unsigned short* ah = th + (long)(lane & 31) * C + c0 + (lane >> 5) * 8;
-  const unsigned short* al = tl + (long)(lane & 31) * C + c0 + (lane >> 5) * 8;
+  const unsigned short* ah = hiF + ((long)(c0 >> 4) * 64 + lane) * 8;      // fragment (kk, lane): 16 B, a wave reads 1 KiB contiguous
+  const unsigned short* al = loF + ((long)(c0 >> 4) * 64 + lane) * 8;
   const char* bp = img + (lane & 31) * PX2 + (lane >> 5) * 16;
-  for (int kk = 0; kk < kc; ++kk) {
-    const bfx8 bf = lds8(bp + kk * 32);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldg8(ah + kk * 16), bf, acc, 0, 0, 0);
-    if (LO) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldg8(al + kk * 16), bf, acc, 0, 0, 0);
+  // k-steps in groups of 4: the 8 operand loads of a group are in flight together (one exposed L2 round trip per group
+  // instead of one per load); slabs are whole multiples of 32 channels, so a group is 2 or 4 steps
+#pragma unroll
+  for (int g = 0; g < CS2 / 64; ++g) {
+    if (g * 4 >= kc) break;
+    bfx8 fh[4], fl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = g * 4 + i < kc ? g * 4 + i : 0;
+      fh[i] = ldg8(ah + kk * 512);
+      if (LO) fl[i] = ldg8(al + kk * 512);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (g * 4 + i < kc) {
+        const bfx8 bf = lds8(bp + (g * 4 + i) * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], bf, acc, 0, 0, 0);
+        if (LO) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[i], bf, acc, 0, 0, 0);
+      }
+    }
   }
 }
 // softmax over the latent tokens of a [t][n] accumulator tile (t along the registers + lane ^ 32); tk valid tokens
@@ -120,27 +139,44 @@ __device__ __forceinline__ void softmax_regs(f32x16& a, int tk, int lane) {
 // src fp32 [nb][tk][C] -> pk [nb][hi 32 x C | lo 32 x C | T C x 32] bf16; optionally D[b][t] = sum_c src * (other - base)
 struct PackArgs { const float* src; unsigned short* pk; int tk, C; const float* other; const float* base; float* D; };
 __global__ __launch_bounds__(256) void tok_pack_k(const PackArgs p) {
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, tid = threadIdx.x;
   const long C = p.C;
-  unsigned short* hi = p.pk + (long)b * 96 * C;
-  unsigned short* lo = hi + 32 * C;
-  unsigned short* T = lo + 32 * C;
+  unsigned short* hiF = p.pk + (long)b * 96 * C;
+  unsigned short* loF = hiF + 32 * C;
+  unsigned short* TF = loF + 32 * C;
   const float* s = p.src + (long)b * p.tk * C;
-  // blockIdx.x: 8 latent-token rows per workgroup, 2 per wave
-  for (int i = 0; i < 2; ++i) {
-    const int t = blockIdx.x * 8 + wave * 2 + i;
-    if (t >= 32) break;
-    float d = 0.f;
-    const int pp = perm_pos(t);
-    for (int c = lane; c < p.C; c += 64) {
-      const float x = t < p.tk ? s[(long)t * C + c] : 0.f;
-      const unsigned short h = f2bf(x);
-      hi[(long)t * C + c] = h;
-      lo[(long)t * C + c] = f2bf(x - bf2f(h));
-      T[(long)c * 32 + pp] = h;
-      if (p.D && t < p.tk) d += x * (p.other[((long)b * p.tk + t) * C + c] - p.base[(long)t * C + c]);
+  // one thread per 8-element fragment piece (16 B out), 4 C of them per image
+  for (long f = (long)blockIdx.x * 256 + tid; f < 4 * C; f += (long)gridDim.x * 256) {
+    {   // hiF / loF piece f = (kk*2 + h)*32 + t
+      const int t = (int)(f & 31), h = (int)((f >> 5) & 1), kk = (int)(f >> 6);
+      unsigned hw[4], lw[4];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float x0 = t < p.tk ? s[(long)t * C + 16 * kk + 8 * h + e] : 0.f, x1 = t < p.tk ? s[(long)t * C + 16 * kk + 8 * h + e + 1] : 0.f;
+        const unsigned short h0 = f2bf(x0), h1 = f2bf(x1);
+        hw[e >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lw[e >> 1] = (unsigned)f2bf(x0 - bf2f(h0)) | ((unsigned)f2bf(x1 - bf2f(h1)) << 16);
+      }
+      *reinterpret_cast<uint4*>(hiF + f * 8) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      *reinterpret_cast<uint4*>(loF + f * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
     }
-    if (p.D && t < p.tk) {
+    {   // TF piece f = ((j*2 + kk)*2 + h)*32 + c
+      const int c = (int)(f & 31), h = (int)((f >> 5) & 1), kk = (int)((f >> 6) & 1), j = (int)(f >> 7);
+      unsigned w[4];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const int t0 = 16 * kk + 4 * h + (e & 3) + 8 * (e >> 2), t1 = t0 + 1;
+        const float x0 = t0 < p.tk ? s[(long)t0 * C + 32 * j + c] : 0.f, x1 = t1 < p.tk ? s[(long)t1 * C + 32 * j + c] : 0.f;
+        w[e >> 1] = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+      }
+      *reinterpret_cast<uint4*>(TF + f * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  if (p.D && blockIdx.x == 0) {          // D[b][t] = sum_c src * (other - base): one wave per 8 latent tokens
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int t = wave; t < p.tk; t += 4) {
+      float d = 0.f;
+      for (int c = lane; c < p.C; c += 64) d += s[(long)t * C + c] * (p.other[((long)b * p.tk + t) * C + c] - p.base[(long)t * C + c]);
       d = group_sum(d, 64);
       if (lane == 0) p.D[(long)b * p.tk + t] = d;
     }
@@ -148,7 +184,8 @@ __global__ __launch_bounds__(256) void tok_pack_k(const PackArgs p) {
 }
 void tok_pack(const Ctx& ctx, const float* src, int nb, int tk, int C, void* pk, const float* other, const float* base, float* D) {
   PackArgs a{src, (unsigned short*)pk, tk, C, other, base, D};
-  hipLaunchKernelGGL(tok_pack_k, dim3(4, nb), dim3(256), 0, (hipStream_t)ctx.stream, a);
+  const int gx = (4 * C + 255) / 256;
+  hipLaunchKernelGGL(tok_pack_k, dim3(gx < 4 ? gx : 4, nb), dim3(256), 0, (hipStream_t)ctx.stream, a);
 }
 long tok_pack_elems(int nb, int C) { return (long)nb * 96 * C; }
 
@@ -182,7 +219,7 @@ __global__ __launch_bounds__(256) void xattn_fwd2_k(const XF2Args p) {
     wave_sync();
     if (si + 1 < nsl) slab_load(s, Xg, C, rows, c0 + CS2, p.C, lane);
     else if (nsl > 1) slab_load(s, Xg, C, rows, 0, p.C, lane);           // first slab of the second pass
-    logits_slab<true>(acc, th, tl, C, c0, kc, img, lane);
+    logits_slab<true>(acc, th, tl, c0, kc, img, lane);
   }
   softmax_regs(acc, p.tk, lane);
   float pr[16];
@@ -199,13 +236,22 @@ __global__ __launch_bounds__(256) void xattn_fwd2_k(const XF2Args p) {
       wave_sync();
       if (si + 1 < nsl) slab_load(s, Xg, C, rows, c0 + CS2, p.C, lane);
     }
-    for (int j = 0; j < nt; ++j) {
-      const unsigned short* ap = tT + ((long)(c0 + 32 * j + (lane & 31))) * 32 + (lane >> 5) * 8;
+    const unsigned short* ap = tT + ((long)(c0 >> 5) * 128 + lane) * 8;      // TF fragment (tile j, kk, lane) at + (j*128 + kk*64)*8
+    bfx8 ta[CS2 / 32][2];
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {
+      const int jj = j < nt ? j : 0;
+      ta[j][0] = ldg8(ap + jj * 1024);
+      ta[j][1] = ldg8(ap + jj * 1024 + 512);
+    }
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {
+      if (j >= nt) break;
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldg8(ap), pb0, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldg8(ap + 16), pb1, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[j][0], pb0, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[j][1], pb1, o, 0, 0, 0);
       char* xr = img + (lane & 31) * PX2 + (32 * j + 4 * (lane >> 5)) * 2;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -224,6 +270,262 @@ void xattn_fwd2(const Ctx& ctx, const void* X, const void* tokpk, const float* g
   const int nrb = (N + 31) / 32;
   XF2Args a{(const unsigned short*)X, (const unsigned short*)tokpk, gate_av, N, C, tk, nrb, B * nrb, (unsigned short*)X1};
   hipLaunchKernelGGL(xattn_fwd2_k, dim3((a.total + 3) / 4), dim3(256), 0, (hipStream_t)ctx.stream, a);
+}
+
+
+// ====================================================================================================================
+// Backward kernels.  A workgroup = 4 wavefronts = 4 consecutive 32-row blocks of ONE frame: the row-local part (logits,
+// softmax backward, the token-major output rows) is wave-private as above; the [32 x C] latent-token gradients, which
+// sum over all rows of the frame, are reduced over the 4 waves in LDS (ds_add_f32) and leave as one fp32 atomic per
+// element per workgroup and slab.
+// ====================================================================================================================
+namespace {
+constexpr int PP2 = 64;                        // pitch of a private [32 rows][32 latent tokens] bf16 image (transpose-read)
+// the lane's 16 values of a [t][n] register tile -> image[n][t] (bf16): 4 x 8-byte stores
+__device__ __forceinline__ void regs_to_img(const float* v, char* img, int lane) {
+  char* row = img + (lane & 31) * PP2 + (lane >> 5) * 8;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<uint2*>(row + q * 16) = make_uint2(pack2(v[4 * q], v[4 * q + 1]), pack2(v[4 * q + 2], v[4 * q + 3]));
+}
+// red[t][c] (fp32, [32][CS2]) += sum_n A[n][t] * S[n][c] for the nt 32-channel tiles of a slab; A: [32 n][32 t] image, S: slab image
+__device__ __forceinline__ void tokgrad_slab(float* red, const char* aimg, const char* simg, int nt, float scale, int lane) {
+  const mt_bf16x8 a0 = mt_frag_mn(aimg, PP2, 0, 0, lane), a1 = mt_frag_mn(aimg, PP2, 0, 1, lane);
+#pragma unroll
+  for (int j = 0; j < CS2 / 32; ++j) {
+    if (j >= nt) break;
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, mt_frag_mn(simg, PX2, 32 * j, 0, lane), o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, mt_frag_mn(simg, PX2, 32 * j, 1, lane), o, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(red + mt_row(r, lane) * CS2 + 32 * j + (lane & 31), scale * o[r]);   // ds_add_f32
+  }
+}
+__device__ __forceinline__ void zero_red(float* red, int tid) {
+#pragma unroll
+  for (int i = tid; i < 32 * CS2 / 4; i += 256) reinterpret_cast<float4*>(red)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void flush_red(const float* red, float* dst, long C, int c0, int tk, int tid) {
+  for (int i = tid; i < 32 * CS2; i += 256) {
+    const int t = i / CS2, c = i % CS2;
+    if (t < tk && c0 + c < C) unsafeAtomicAdd(dst + (long)t * C + c0 + c, red[i]);
+  }
+}
+// o[c][n] tile = sum_t TF[c][t] * frag(t, n): two MFMAs with the packed transposed latent tokens as A (fragment order)
+__device__ __forceinline__ void tokT_tile(f32x16& o, const unsigned short* TFslab, int j, const bfx8& b0, const bfx8& b1, int lane) {
+  const unsigned short* ap = TFslab + ((long)j * 128 + lane) * 8;
+  o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldg8(ap), b0, o, 0, 0, 0);
+  o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldg8(ap + 512), b1, o, 0, 0, 0);
+}
+}  // namespace
+
+// ---- xattn_bwd ------------------------------------------------------------------------------------------------------
+struct XB2Args {
+  const unsigned short* X; const unsigned short* G; const unsigned short* pk; const float* gate_av; int N, C, tk, wpf;
+  unsigned short* dX; const unsigned short* R2; float* dtok; float* dgate;
+};
+__global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * (IMG2 + 2 * 32 * PP2)];
+  __shared__ __attribute__((aligned(16))) float red[32 * CS2];
+  __shared__ float dgs[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / p.wpf, n0 = ((blockIdx.x - b * p.wpf) * 4 + wave) * 32;
+  const bool active = n0 < p.N;
+  const int rows = active ? (p.N - n0 < 32 ? p.N - n0 : 32) : 1;
+  const int nb = active ? n0 : 0;
+  const long C = p.C;
+  char* img = smem + wave * IMG2;
+  char* imgP = smem + 4 * IMG2 + wave * 2 * 32 * PP2;
+  char* imgS = imgP + 32 * PP2;
+  const unsigned short* Xg = p.X + ((long)b * p.N + nb) * C;
+  const unsigned short* Gg = p.G + ((long)b * p.N + nb) * C;
+  const unsigned short* hiF = p.pk + (long)b * 96 * C;
+  const unsigned short* loF = hiF + 32 * C;
+  const unsigned short* TF = loF + 32 * C;
+  const float g = *p.gate_av;
+  const int nsl = (p.C + CS2 - 1) / CS2;
+  f32x16 aS, aU;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aU[r] = 0.f; }
+  Slab s;
+  slab_load(s, Xg, C, rows, 0, p.C, lane);
+  for (int si = 0; si < 2 * nsl; ++si) {                         // X slabs (logits), then dX1 slabs (U = dX1 . tok^T)
+    const bool second = si >= nsl;
+    const int c0 = (second ? si - nsl : si) * CS2, kc = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 16;
+    wave_sync();
+    slab_store_lds(s, img, rows, c0, p.C, lane);
+    wave_sync();
+    if (si + 1 < 2 * nsl) slab_load(s, si + 1 < nsl ? Xg : Gg, C, rows, (si + 1 < nsl ? si + 1 : si + 1 - nsl) * CS2, p.C, lane);
+    else if (nsl > 1) slab_load(s, Gg, C, rows, 0, p.C, lane);
+    if (!second) logits_slab<true>(aS, hiF, loF, c0, kc, img, lane);
+    else logits_slab<true>(aU, hiF, loF, c0, kc, img, lane);
+  }
+  softmax_regs(aS, p.tk, lane);
+  float dot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dot += aS[r] * aU[r];
+  dot += xor32b(dot);
+  const bool nvalid = active && (lane & 31) < rows;
+  float pv[16], dv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { pv[r] = nvalid ? aS[r] : 0.f; dv[r] = nvalid ? g * aS[r] * (aU[r] - dot) : 0.f; }
+  const bfx8 db0 = regs_frag(dv), db1 = regs_frag(dv + 8);
+  regs_to_img(pv, imgP, lane);
+  regs_to_img(dv, imgS, lane);
+  {
+    float part = (nvalid && lane < 32) ? dot : 0.f;
+    part = group_sum(part, 64);
+    if (lane == 0) dgs[wave] = part;
+  }
+  // second pass over the slabs: dX1 (dX rows + P^T dX1), then X (dS^T X)
+  for (int si = 0; si < nsl; ++si) {
+    const int c0 = si * CS2, nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
+    zero_red(red, tid);
+    if (nsl > 1) {
+      wave_sync();
+      slab_store_lds(s, img, rows, c0, p.C, lane);
+    }
+    slab_load(s, Xg, C, rows, c0, p.C, lane);                     // X slab for the second half of this iteration
+    __syncthreads();                                              // red zeroed, images visible
+    tokgrad_slab(red, imgP, img, nt, g, lane);                    // red += g * P^T . dX1
+    wave_sync();
+    const unsigned short* TFs = TF + (long)(c0 >> 5) * 1024;
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {                          // dX rows = dX1 + dS . tok
+      if (j >= nt) break;
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      tokT_tile(o, TFs, j, db0, db1, lane);
+      char* xr = img + (lane & 31) * PX2 + (32 * j + 4 * (lane >> 5)) * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 w = *reinterpret_cast<uint2*>(xr + q * 16);
+        const float x0 = __uint_as_float(w.x << 16) + o[4 * q], x1 = __uint_as_float(w.x & 0xffff0000u) + o[4 * q + 1];
+        const float x2 = __uint_as_float(w.y << 16) + o[4 * q + 2], x3 = __uint_as_float(w.y & 0xffff0000u) + o[4 * q + 3];
+        *reinterpret_cast<uint2*>(xr + q * 16) = make_uint2(pack2(x0, x1), pack2(x2, x3));
+      }
+    }
+    wave_sync();
+    if (active) slab_copy_out(img, p.dX + ((long)b * p.N + n0) * C, p.R2 ? p.R2 + ((long)b * p.N + n0) * C : nullptr, C, rows, c0, p.C, lane);
+    wave_sync();
+    slab_store_lds(s, img, active ? rows : 0, c0, p.C, lane);     // X slab
+    wave_sync();
+    if (si + 1 < nsl) slab_load(s, Gg, C, rows, c0 + CS2, p.C, lane);
+    tokgrad_slab(red, imgS, img, nt, 1.f, lane);                  // red += dS^T . X
+    __syncthreads();
+    flush_red(red, p.dtok + (long)b * p.tk * C, C, c0, p.tk, tid);
+    __syncthreads();
+  }
+  if (p.dgate && tid == 0) unsafeAtomicAdd(p.dgate, dgs[0] + dgs[1] + dgs[2] + dgs[3]);
+}
+void xattn_bwd2(const Ctx& ctx, const void* X, const void* dX1, const void* tokpk, const float* gate_av, int B, int N, int C, int tk,
+                void* dX, const void* R2, float* dtok, float* dgate) {
+  const int wpf = ((N + 31) / 32 + 3) / 4;
+  XB2Args a{(const unsigned short*)X, (const unsigned short*)dX1, (const unsigned short*)tokpk, gate_av, N, C, tk, wpf,
+            (unsigned short*)dX, (const unsigned short*)R2, dtok, dgate};
+  hipLaunchKernelGGL(xattn_bwd2_k, dim3(B * wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
+}
+
+// ---- tokattn_bwd ----------------------------------------------------------------------------------------------------
+// T0pk: packed my_tokens (one image set); dpk: packed dtok (per frame)
+struct TB2Args {
+  const unsigned short* Yp; const unsigned short* T0pk; const unsigned short* dpk; const float* lse; const float* D; const float* da;
+  float invN; int N, C, tk, wpf; unsigned short* dYp; float* dT0b;
+};
+__global__ __launch_bounds__(256) void tokattn_bwd2_k(const TB2Args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * (IMG2 + 32 * PP2)];
+  __shared__ __attribute__((aligned(16))) float red[32 * CS2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / p.wpf, n0 = ((blockIdx.x - b * p.wpf) * 4 + wave) * 32;
+  const bool active = n0 < p.N;
+  const int rows = active ? (p.N - n0 < 32 ? p.N - n0 : 32) : 1;
+  const int nb = active ? n0 : 0;
+  const long C = p.C;
+  char* img = smem + wave * IMG2;
+  char* imgS = smem + 4 * IMG2 + wave * 32 * PP2;
+  const unsigned short* Yg = p.Yp + ((long)b * p.N + nb) * C;
+  const unsigned short* thF = p.T0pk;
+  const unsigned short* tlF = thF + 32 * C;
+  const unsigned short* tTF = tlF + 32 * C;
+  const unsigned short* dhF = p.dpk + (long)b * 96 * C;
+  const unsigned short* dTF = dhF + 64 * C;
+  const int nsl = (p.C + CS2 - 1) / CS2;
+  f32x16 aS, aD;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aD[r] = 0.f; }
+  Slab s;
+  slab_load(s, Yg, C, rows, 0, p.C, lane);
+  for (int si = 0; si < nsl; ++si) {
+    const int c0 = si * CS2, kc = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 16;
+    wave_sync();
+    slab_store_lds(s, img, rows, c0, p.C, lane);
+    wave_sync();
+    if (si + 1 < nsl) slab_load(s, Yg, C, rows, c0 + CS2, p.C, lane);
+    else if (nsl > 1) slab_load(s, Yg, C, rows, 0, p.C, lane);
+    logits_slab<true>(aS, thF, tlF, c0, kc, img, lane);
+    logits_slab<false>(aD, dhF, dhF, c0, kc, img, lane);
+  }
+  const bool nvalid = active && (lane & 31) < rows;
+  float pv[16], dv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = mt_row(r, lane);
+    const bool ok = nvalid && t < p.tk;
+    const int tc = t < p.tk ? t : 0;
+    const float pr = ok ? __expf(aS[r] - p.lse[(long)b * p.tk + tc]) : 0.f;
+    pv[r] = pr;
+    dv[r] = ok ? pr * (aD[r] - p.D[(long)b * p.tk + tc]) : 0.f;
+  }
+  const bfx8 pb0 = regs_frag(pv), pb1 = regs_frag(pv + 8), db0 = regs_frag(dv), db1 = regs_frag(dv + 8);
+  regs_to_img(dv, imgS, lane);
+  for (int si = 0; si < nsl; ++si) {
+    const int c0 = si * CS2, nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
+    zero_red(red, tid);
+    if (nsl > 1) {
+      wave_sync();
+      slab_store_lds(s, img, active ? rows : 0, c0, p.C, lane);
+      if (si + 1 < nsl) slab_load(s, Yg, C, rows, c0 + CS2, p.C, lane);
+    } else if (!active) {
+      slab_store_lds(s, img, 0, c0, p.C, lane);
+    }
+    __syncthreads();
+    tokgrad_slab(red, imgS, img, nt, 1.f, lane);                  // red += dS1^T . Yp
+    wave_sync();
+    const unsigned short* dTs = dTF + (long)(c0 >> 5) * 1024;
+    const unsigned short* tTs = tTF + (long)(c0 >> 5) * 1024;
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {                          // dYp rows = P1 . dtok + dS1 . T0 + da / N  (over the Yp image)
+      if (j >= nt) break;
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      tokT_tile(o, dTs, j, pb0, pb1, lane);
+      tokT_tile(o, tTs, j, db0, db1, lane);
+      char* xr = img + (lane & 31) * PX2 + (32 * j + 4 * (lane >> 5)) * 2;
+      const float* dap = p.da + (long)b * C + c0 + 32 * j + 4 * (lane >> 5);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 dq = *reinterpret_cast<const float4*>(dap + 8 * q);
+        *reinterpret_cast<uint2*>(xr + q * 16) = make_uint2(pack2(o[4 * q] + dq.x * p.invN, o[4 * q + 1] + dq.y * p.invN),
+                                                            pack2(o[4 * q + 2] + dq.z * p.invN, o[4 * q + 3] + dq.w * p.invN));
+      }
+    }
+    wave_sync();
+    if (active) slab_copy_out(img, p.dYp + ((long)b * p.N + n0) * C, nullptr, C, rows, c0, p.C, lane);
+    __syncthreads();
+    flush_red(red, p.dT0b + (long)b * p.tk * C, C, c0, p.tk, tid);
+    __syncthreads();
+  }
+}
+void tokattn_bwd2(const Ctx& ctx, const void* Yp, const void* T0pk, const void* dtokpk, const float* lse, const float* D,
+                  const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b) {
+  const int wpf = ((N + 31) / 32 + 3) / 4;
+  TB2Args a{(const unsigned short*)Yp, (const unsigned short*)T0pk, (const unsigned short*)dtokpk, lse, D, da, invN, N, C, tk, wpf,
+            (unsigned short*)dYp, dT0b};
+  hipLaunchKernelGGL(tokattn_bwd2_k, dim3(B * wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
 }
 
 }  // namespace dgsct

@@ -178,11 +178,14 @@ void xattn_fwd(const Ctx&, const void* X, const float* tok, const float* gate_av
 // backward of xattn_fwd w.r.t. X and tok given dX1 (E): dX (E) = dX1 + dS2 tok (+ R2, optional, E);
 // dtok fp32 [B][tk][C] += gate_av P2^T dX1 + dS2^T X  (pre-zeroed);  *dgate += sum P2 (dX1 tok^T)  (optional)
 void xattn_bwd(const Ctx&, const void* X, const void* dX1, const float* tok, const float* gate_av, int B, int N, int C, int tk,
-               void* dX, const void* R2, float* dtok, float* dgate);
+               void* dX, const void* R2, float* dtok, float* dgate, const void* tokpk = nullptr);
 // backward of tokattn_fwd given dtok: dYp (E) = P1^T dtok + dS1^T T0 + invN * da[b];  dT0b fp32 [B][tk][C] += dS1 Yp
 // (pre-zeroed; the my_tokens gradient is sum_b (dtok + dT0b));  Dscratch: B*tk floats.
+// T0pk: packed my_tokens (tok_pack with nb = 1; from dgsct_prepare), dtokpk: tok_pack_elems(B, C) bf16 of scratch -- both
+// optional (fast path).
 void tokattn_bwd(const Ctx&, const void* Yp, const float* T0, const float* tok, const float* lse, const float* dtok,
-                 const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float* Dscratch);
+                 const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float* Dscratch,
+                 const void* T0pk = nullptr, void* dtokpk = nullptr);
 
 // Small fp32/E elementwise helpers on [n]-sized vectors (n <= a few 100k).
 enum EwOp : int {

@@ -187,7 +187,8 @@ typedef struct dgsct_gemm_args {
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream);
 
 /* One fused latent-token attention kernel (csrc/attn.hip; reference net_trans.py:572-589 and its autograd), for unit
- * tests against torch and for tools/attn_bench.py.  op: 0 tokattn_fwd, 1 xattn_fwd, 2 xattn_bwd, 3 tokattn_bwd.
+ * tests against torch and for tools/attn_bench.py.  op: 0 tokattn_fwd, 1 xattn_fwd, 2 xattn_bwd, 3 tokattn_bwd,
+ * 4 pack T0 into T0pk (what dgsct_prepare does).
  * Activations X / Yp / dX1 / out / R2: [B][N][C] in `mode`'s element type; T0 [tk][C], tok / dtok / dT0b [B][tk][C], lse [B][tk],
  * a / da [B][C]: fp32.  Accumulated outputs (a, dtok, dT0b, dgate) must be zeroed by the caller.  scratch: at least
  * dgsct_test_attn_scratch_floats(B, N, C, tk) floats. */
@@ -196,7 +197,9 @@ typedef struct dgsct_attn_args {
   const void* X; const void* Yp; const void* dX1; const void* R2; void* out;
   const float* T0; float* tok; float* lse; float* a; void* aE; const float* gate_av;
   float* dtok; float* dgate; const float* da; float invN; float* dT0b; float* scratch;
-  void* tokpk;         /* optional: 96 * B * C bf16 (packed latent tokens: written by op 0, read by ops 1-3) */
+  void* tokpk;         /* optional: 96 * B * C bf16 (packed latent tokens: written by op 0, read by ops 1-2) */
+  void* T0pk;          /* optional: 96 * C bf16 (packed my_tokens: written by op 4, read by op 3)                 */
+  void* dtokpk;        /* optional: 96 * B * C bf16 of scratch (op 3)                                             */
 } dgsct_attn_args;
 int64_t dgsct_test_attn_scratch_floats(int B, int N, int C, int tk);
 int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream);

@@ -62,7 +62,9 @@ class AttnCall:
                       aE=torch.empty(B, C, device=dev, dtype=dtype), dtok=torch.zeros(B, tk, C, device=dev),
                       dgate=torch.zeros(1, device=dev), dT0b=torch.zeros(B, tk, C, device=dev),
                       scratch=torch.empty(int(lib.c.dgsct_test_attn_scratch_floats(B, N, C, tk)), device=dev),
-                      tokpk=torch.zeros(96 * B * C, device=dev, dtype=torch.bfloat16))
+                      tokpk=torch.zeros(96 * B * C, device=dev, dtype=torch.bfloat16),
+                      T0pk=torch.zeros(96 * C, device=dev, dtype=torch.bfloat16),
+                      dtokpk=torch.zeros(96 * B * C, device=dev, dtype=torch.bfloat16))
         a = AttnArgs()
         a.mode = 1 if dtype == torch.bfloat16 else 0
         a.B, a.N, a.C, a.tk = B, N, C, tk

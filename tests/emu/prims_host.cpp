@@ -546,7 +546,7 @@ void xattn_fwd(const Ctx& ctx, const void* X, const float* tok, const float* gat
     }
 }
 void xattn_bwd(const Ctx& ctx, const void* X, const void* dX1, const float* tok, const float* gate_av, int B, int N, int C, int tk,
-               void* dX, const void* R2, float* dtok, float* dgate) {
+               void* dX, const void* R2, float* dtok, float* dgate, const void*) {
   const int E = ctx.mode;
   const float g = *gate_av;
   std::vector<double> P(tk), U(tk);
@@ -579,7 +579,7 @@ void xattn_bwd(const Ctx& ctx, const void* X, const void* dX1, const float* tok,
   if (dgate) *dgate += (float)dg;
 }
 void tokattn_bwd(const Ctx& ctx, const void* Yp, const float* T0, const float* tok, const float* lse, const float* dtok,
-                 const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float*) {
+                 const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float*, const void*, void*) {
   const int E = ctx.mode;
   std::vector<float> P1((size_t)tk * N), dS1((size_t)tk * N);
   for (int b = 0; b < B; ++b) {

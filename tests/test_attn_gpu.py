@@ -70,6 +70,7 @@ def test_tokattn_bwd(shape, dtype):
     c.d["tok"].copy_(tok)
     c.d["lse"].copy_(lse)
     c.d["dtok"].copy_(c.dtok_in)
+    c.run(4)                                   # packed my_tokens (dgsct_prepare's job)
     c.run(3)
     torch.cuda.synchronize()
     dYp, dT0b = ref_tokattn_bwd(c.Yp, c.T0, c.dtok_in, c.da, 1.0 / shape[1])

@@ -25,6 +25,7 @@ print(f"{'N':>5} {'C':>5} " + " ".join(f"{n:>22}" for n in names))
 for s in ave_stage_shapes(backbone):
     for (N, C) in ((s["Nv"], s["Cv"]), (s["Na"], s["Ca"])):
         c = AttnCall(lib, dtype, 160, N, C, 32, dev)
+        c.run(4)
         row = []
         for op in range(4):
             for _ in range(3):
