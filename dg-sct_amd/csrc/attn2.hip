@@ -265,7 +265,10 @@ __global__ __launch_bounds__(256) void xattn_fwd2_k(const XF2Args p) {
     slab_copy_out(img, Og, nullptr, C, rows, c0, p.C, lane);
   }
 }
-bool attn2_ok(const Ctx& ctx, int C) { return ctx.mode == DT_BF16 && C % 32 == 0 && !getenv("DGSCT_ATTN_V1"); }
+bool attn2_ok(const Ctx& ctx, int C) {
+  static const bool v1 = getenv("DGSCT_ATTN_V1") != nullptr;
+  return ctx.mode == DT_BF16 && C % 32 == 0 && !v1;
+}
 void xattn_fwd2(const Ctx& ctx, const void* X, const void* tokpk, const float* gate_av, int B, int N, int C, int tk, void* X1) {
   const int nrb = (N + 31) / 32;
   XF2Args a{(const unsigned short*)X, (const unsigned short*)tokpk, gate_av, N, C, tk, nrb, B * nrb, (unsigned short*)X1};
@@ -288,36 +291,35 @@ __device__ __forceinline__ void regs_to_img(const float* v, char* img, int lane)
   for (int q = 0; q < 4; ++q)
     *reinterpret_cast<uint2*>(row + q * 16) = make_uint2(pack2(v[4 * q], v[4 * q + 1]), pack2(v[4 * q + 2], v[4 * q + 3]));
 }
-// red[t][c] (fp32, [32][CS2]) += sum_n A[n][t] * S[n][c] for the nt 32-channel tiles of a slab; A: [32 n][32 t] image, S: slab image
-__device__ __forceinline__ void tokgrad_slab(float* red, const char* aimg, const char* simg, int nt, float scale, int lane) {
-  const mt_bf16x8 a0 = mt_frag_mn(aimg, PP2, 0, 0, lane), a1 = mt_frag_mn(aimg, PP2, 0, 1, lane);
+// o[t][c] += sum over the 128 rows of the workgroup of A[n][t] * S[n][c] for ONE 32-channel tile (column tile `j` of the slab):
+// the wave walks the P / dS images and the slab images of all 4 waves (visible after a __syncthreads), so every wave
+// produces a complete tile of the workgroup's contribution -- no cross-wave reduction
+__device__ __forceinline__ void tokgrad_tile(f32x16& o, const char* aimg0, int astride, const char* simg0, int j, int lane) {
 #pragma unroll
-  for (int j = 0; j < CS2 / 32; ++j) {
-    if (j >= nt) break;
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, mt_frag_mn(simg, PX2, 32 * j, 0, lane), o, 0, 0, 0);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, mt_frag_mn(simg, PX2, 32 * j, 1, lane), o, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(red + mt_row(r, lane) * CS2 + 32 * j + (lane & 31), scale * o[r]);   // ds_add_f32
+  for (int w = 0; w < 4; ++w) {
+    const char* aimg = aimg0 + w * astride;
+    const char* simg = simg0 + w * IMG2;
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mt_frag_mn(aimg, PP2, 0, 0, lane), mt_frag_mn(simg, PX2, 32 * j, 0, lane), o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mt_frag_mn(aimg, PP2, 0, 1, lane), mt_frag_mn(simg, PX2, 32 * j, 1, lane), o, 0, 0, 0);
   }
 }
-__device__ __forceinline__ void zero_red(float* red, int tid) {
+__device__ __forceinline__ void tile_atomic_out(const f32x16& o, float* dst, long C, int c, int tk, int lane) {
 #pragma unroll
-  for (int i = tid; i < 32 * CS2 / 4; i += 256) reinterpret_cast<float4*>(red)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ void flush_red(const float* red, float* dst, long C, int c0, int tk, int tid) {
-  for (int i = tid; i < 32 * CS2; i += 256) {
-    const int t = i / CS2, c = i % CS2;
-    if (t < tk && c0 + c < C) unsafeAtomicAdd(dst + (long)t * C + c0 + c, red[i]);
+  for (int r = 0; r < 16; ++r) {
+    const int t = mt_row(r, lane);
+    if (t < tk) unsafeAtomicAdd(dst + (long)t * C + c, o[r]);
   }
 }
 // o[c][n] tile = sum_t TF[c][t] * frag(t, n): two MFMAs with the packed transposed latent tokens as A (fragment order)
-__device__ __forceinline__ void tokT_tile(f32x16& o, const unsigned short* TFslab, int j, const bfx8& b0, const bfx8& b1, int lane) {
+struct TFrag { bfx8 k0, k1; };
+__device__ __forceinline__ TFrag tokT_load(const unsigned short* TFslab, int j, int lane) {
   const unsigned short* ap = TFslab + ((long)j * 128 + lane) * 8;
-  o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldg8(ap), b0, o, 0, 0, 0);
-  o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldg8(ap + 512), b1, o, 0, 0, 0);
+  TFrag f; f.k0 = ldg8(ap); f.k1 = ldg8(ap + 512);
+  return f;
+}
+__device__ __forceinline__ void tokT_mma(f32x16& o, const TFrag& f, const bfx8& b0, const bfx8& b1) {
+  o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k0, b0, o, 0, 0, 0);
+  o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k1, b1, o, 0, 0, 0);
 }
 }  // namespace
 
@@ -328,7 +330,6 @@ struct XB2Args {
 };
 __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * (IMG2 + 2 * 32 * PP2)];
-  __shared__ __attribute__((aligned(16))) float red[32 * CS2];
   __shared__ float dgs[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / p.wpf, n0 = ((blockIdx.x - b * p.wpf) * 4 + wave) * 32;
@@ -380,25 +381,26 @@ __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
     if (lane == 0) dgs[wave] = part;
   }
   // second pass over the slabs: dX1 (dX rows + P^T dX1), then X (dS^T X)
+  const char* img0 = smem;
+  const char* imgP0 = smem + 4 * IMG2;
   for (int si = 0; si < nsl; ++si) {
     const int c0 = si * CS2, nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
-    zero_red(red, tid);
-    if (nsl > 1) {
-      wave_sync();
-      slab_store_lds(s, img, rows, c0, p.C, lane);
-    }
-    slab_load(s, Xg, C, rows, c0, p.C, lane);                     // X slab for the second half of this iteration
-    __syncthreads();                                              // red zeroed, images visible
-    tokgrad_slab(red, imgP, img, nt, g, lane);                    // red += g * P^T . dX1
-    wave_sync();
+    if (nsl > 1) { wave_sync(); slab_store_lds(s, img, rows, c0, p.C, lane); }
+    slab_load(s, Xg, C, rows, c0, p.C, lane);                     // X slab for the second half of this iteration (L2-hot re-read)
+    __syncthreads();                                              // dX1 slab images + P / dS images of all 4 waves visible
+    f32x16 a1, a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
+    if (wave < nt) tokgrad_tile(a1, imgP0, 2 * 32 * PP2, img0, wave, lane);              // P^T . dX1, column tile `wave`
     const unsigned short* TFs = TF + (long)(c0 >> 5) * 1024;
+    __syncthreads();                                              // operand reads done before the rows are modified
 #pragma unroll
     for (int j = 0; j < CS2 / 32; ++j) {                          // dX rows = dX1 + dS . tok
       if (j >= nt) break;
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
-      tokT_tile(o, TFs, j, db0, db1, lane);
+      tokT_mma(o, tokT_load(TFs, j, lane), db0, db1);
       char* xr = img + (lane & 31) * PX2 + (32 * j + 4 * (lane >> 5)) * 2;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -412,11 +414,14 @@ __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
     if (active) slab_copy_out(img, p.dX + ((long)b * p.N + n0) * C, p.R2 ? p.R2 + ((long)b * p.N + n0) * C : nullptr, C, rows, c0, p.C, lane);
     wave_sync();
     slab_store_lds(s, img, active ? rows : 0, c0, p.C, lane);     // X slab
-    wave_sync();
     if (si + 1 < nsl) slab_load(s, Gg, C, rows, c0 + CS2, p.C, lane);
-    tokgrad_slab(red, imgS, img, nt, 1.f, lane);                  // red += dS^T . X
     __syncthreads();
-    flush_red(red, p.dtok + (long)b * p.tk * C, C, c0, p.tk, tid);
+    if (wave < nt) {
+      tokgrad_tile(a2, imgP0 + 32 * PP2, 2 * 32 * PP2, img0, wave, lane);                 // dS^T . X
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[r] += g * a1[r];
+      tile_atomic_out(a2, p.dtok + (long)b * p.tk * C, C, c0 + 32 * wave + (lane & 31), p.tk, lane);
+    }
     __syncthreads();
   }
   if (p.dgate && tid == 0) unsafeAtomicAdd(p.dgate, dgs[0] + dgs[1] + dgs[2] + dgs[3]);
@@ -437,7 +442,6 @@ struct TB2Args {
 };
 __global__ __launch_bounds__(256) void tokattn_bwd2_k(const TB2Args p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * (IMG2 + 32 * PP2)];
-  __shared__ __attribute__((aligned(16))) float red[32 * CS2];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / p.wpf, n0 = ((blockIdx.x - b * p.wpf) * 4 + wave) * 32;
   const bool active = n0 < p.N;
@@ -481,9 +485,10 @@ __global__ __launch_bounds__(256) void tokattn_bwd2_k(const TB2Args p) {
   }
   const bfx8 pb0 = regs_frag(pv), pb1 = regs_frag(pv + 8), db0 = regs_frag(dv), db1 = regs_frag(dv + 8);
   regs_to_img(dv, imgS, lane);
+  const char* img0 = smem;
+  const char* imgS0 = smem + 4 * IMG2;
   for (int si = 0; si < nsl; ++si) {
     const int c0 = si * CS2, nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
-    zero_red(red, tid);
     if (nsl > 1) {
       wave_sync();
       slab_store_lds(s, img, active ? rows : 0, c0, p.C, lane);
@@ -492,18 +497,25 @@ __global__ __launch_bounds__(256) void tokattn_bwd2_k(const TB2Args p) {
       slab_store_lds(s, img, 0, c0, p.C, lane);
     }
     __syncthreads();
-    tokgrad_slab(red, imgS, img, nt, 1.f, lane);                  // red += dS1^T . Yp
-    wave_sync();
+    if (wave < nt) {                                              // dT0b += dS1^T . Yp, column tile `wave`
+      f32x16 a2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+      tokgrad_tile(a2, imgS0, 32 * PP2, img0, wave, lane);
+      tile_atomic_out(a2, p.dT0b + (long)b * p.tk * C, C, c0 + 32 * wave + (lane & 31), p.tk, lane);
+    }
     const unsigned short* dTs = dTF + (long)(c0 >> 5) * 1024;
     const unsigned short* tTs = tTF + (long)(c0 >> 5) * 1024;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < CS2 / 32; ++j) {                          // dYp rows = P1 . dtok + dS1 . T0 + da / N  (over the Yp image)
       if (j >= nt) break;
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
-      tokT_tile(o, dTs, j, pb0, pb1, lane);
-      tokT_tile(o, tTs, j, db0, db1, lane);
+      const TFrag fd = tokT_load(dTs, j, lane), ft = tokT_load(tTs, j, lane);
+      tokT_mma(o, fd, pb0, pb1);
+      tokT_mma(o, ft, db0, db1);
       char* xr = img + (lane & 31) * PX2 + (32 * j + 4 * (lane >> 5)) * 2;
       const float* dap = p.da + (long)b * C + c0 + 32 * j + 4 * (lane >> 5);
 #pragma unroll
@@ -515,8 +527,6 @@ __global__ __launch_bounds__(256) void tokattn_bwd2_k(const TB2Args p) {
     }
     wave_sync();
     if (active) slab_copy_out(img, p.dYp + ((long)b * p.N + n0) * C, nullptr, C, rows, c0, p.C, lane);
-    __syncthreads();
-    flush_red(red, p.dT0b + (long)b * p.tk * C, C, c0, p.tk, tid);
     __syncthreads();
   }
 }

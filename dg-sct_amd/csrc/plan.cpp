@@ -87,6 +87,7 @@ void Plan::layout() {
     prep_rowb = a.take("rowb", (int64_t)N * 4);
     prep_colb = a.take("colb", (int64_t)C * 4);
     prep_colb2 = a.take("colb2", (int64_t)C * 4);
+    prep_t0pk = E == DT_BF16 ? a.take("t0pk", tok_pack_elems(1, C) * 2) : -1;      // my_tokens packed for attn2.hip
     prep_bytes = a.off;
   }
   // ---- saved
@@ -101,6 +102,7 @@ void Plan::layout() {
     s.Yp = a.take("Yp", R * C * es);
     s.T = a.take("T", orderA ? R * Co * es : (int64_t)B * C * Nop * es);
     s.tok = a.take("tok", (int64_t)B * tk * C * 4);          // fp32: the un-scaled logits X . tok^T amplify its rounding
+    s.tokpk = E == DT_BF16 ? a.take("tokpk", tok_pack_elems(B, C) * 2) : -1;   // bf16 hi / lo / transposed fragment images
     s.lse = a.take("lse", (int64_t)B * tk * 4);
     s.aE = a.take("aE", (int64_t)B * C * es);
     s.X1 = a.take("X1", R * C * es);
@@ -163,6 +165,7 @@ void Plan::layout() {
     wb.da = a.take("da", (int64_t)B * C * 4);
     wb.dpre_t = a.take("dpre_t", (int64_t)B * 4);
     wb.Dtok = a.take("Dtok", (int64_t)B * tk * 4);
+    wb.dtokpk = E == DT_BF16 ? a.take("dtokpk", tok_pack_elems(B, C) * 2) : -1;
     wb.dYp = a.take("dYp", R * C * es);
     wb.dT = a.take("dT", orderA ? R * Co * es : (int64_t)B * No * C * es);
     wb.rowtmp = a.take("rowtmp", R * 4);
@@ -272,6 +275,7 @@ int Plan::prepare(float* const* params, void* prep, void* stream) const {
     rowsum_f32(ctx, params[DGSCT_P_WN], N, No, rowb);
     zero(ctx, colb2, (size_t)C * 4);
   }
+  if (prep_t0pk >= 0) tok_pack(ctx, params[DGSCT_P_TOKENS], 1, tk, C, p + prep_t0pk);
   check_async("dgsct_prepare");
   return has_error() ? 1 : 0;
 }
@@ -317,8 +321,9 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     gemm(ctx, g2);
   }
   // F2 ---- latent tokens attend to the remapped tokens (one pass over Yp)   :572-580, :592
+  void* tokpk = s.tokpk >= 0 ? b.S(s.tokpk) : nullptr;
   tokattn_fwd(ctx, Yp, b.F(DGSCT_P_TOKENS), B, N, C, tk, b.S<float>(s.tok), b.S<float>(s.lse), b.S<float>(s.a), b.S(s.aE),
-              b.Wk<float>(wf.tokscr));
+              b.Wk<float>(wf.tokscr), tokpk);
   {
     stream_fork(ctx);                                            // a = mean_N(Yp) is complete on the main stream
     Gemm g1 = mk(B, C, C);                                       // aq1 = relu(a Wa1^T + b)
@@ -331,7 +336,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     gemm(side, g2);
   }
   // F3 ---- X attends to the latent tokens (one pass over X)             :583-589
-  xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1));
+  xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1), tokpk);
   // F4-F6 ---- channel gate                                              :593-598
   {
     Gemm g3 = mk((int)R, C, C);                                  // vq1 = relu(X1 Wv1^T + b)
@@ -618,7 +623,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B3 ---- X <- tokens attention: dX (output), dtok, d gate_av in one pass over X and dX1 (P2 recomputed)
   {
     xattn_bwd(ctx, X, dX1, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX, skip_into_dx ? dOut : nullptr,
-              b.Wk<float>(wb.dtokF), G(DGSCT_P_GATE_AV));     // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
+              b.Wk<float>(wb.dtokF), G(DGSCT_P_GATE_AV),      // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
+              s.tokpk >= 0 ? b.S(s.tokpk) : nullptr);
     if (d.remap == DGSCT_REMAP_CONV) {
       // d fc.bias = sum_{b,n} dYp[b,n,:].  Softmax rows sum to 1 and dS1 rows sum to 0, so this equals
       // sum_b (sum_t dtok[b,t,:] + da[b,:]) exactly -- computed from these two small fp32 tensors instead of
@@ -631,7 +637,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   void* dYp = b.Wk(wb.dYp);
   {
     tokattn_bwd(ctx, b.S(s.Yp), b.F(DGSCT_P_TOKENS), b.S<float>(s.tok), b.S<float>(s.lse), b.Wk<float>(wb.dtokF),
-                b.Wk<float>(wb.da), invN, B, N, C, tk, dYp, b.Wk<float>(wb.dT0b), b.Wk<float>(wb.Dtok));
+                b.Wk<float>(wb.da), invN, B, N, C, tk, dYp, b.Wk<float>(wb.dT0b), b.Wk<float>(wb.Dtok),
+                prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr, wb.dtokpk >= 0 ? b.Wk(wb.dtokpk) : nullptr);
     defer([=, &side, &b] {                                       // d my_tokens = sum_b (dtok + dS1 . Yp)
       sum_batch(side, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
       sum_batch(side, b.Wk<float>(wb.dT0b), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);

@@ -20,11 +20,11 @@ struct Plan {
   bool orderA;   // remap association: (Wn.Y).Wc^T (A) or Wn.(Y.Wc^T) (B), whichever is cheaper
 
   // prep
-  int64_t prep_w[DGSCT_P_COUNT], wnumel[DGSCT_P_COUNT], prep_rowb, prep_colb, prep_colb2, prep_bytes;
+  int64_t prep_w[DGSCT_P_COUNT], wnumel[DGSCT_P_COUNT], prep_rowb, prep_colb, prep_colb2, prep_t0pk, prep_bytes;
   // saved
   struct {
     int64_t a, mvq1, bnacc1, bnacc2, zero_end;
-    int64_t Yp, T, tok, lse, aE, X1, aq1, aq2, vq1, m1, q, ch, Xc, vq2, sl, sg, map, tg, X3, mu_b, rstd_b, Zp, Z, Op,
+    int64_t Yp, T, tok, tokpk, lse, aE, X1, aq1, aq2, vq1, m1, q, ch, Xc, vq2, sl, sg, map, tg, X3, mu_b, rstd_b, Zp, Z, Op,
         bn1, bn2, mu_p, rstd_p;
   } s;
   std::vector<Region> saved_regions;
@@ -33,7 +33,7 @@ struct Plan {
   struct { int64_t tokscr; } wf;
   struct {
     int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, dtokF, dT0b, zero_end;
-    int64_t dO, dZ, dX3, dX1, dXc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dYp, dT, rowtmp, rowpart;
+    int64_t dO, dZ, dX3, dX1, dXc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart;
   } wb;
   int64_t ws_fwd_bytes, ws_bwd_bytes;
   // gradients
