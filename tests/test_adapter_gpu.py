@@ -1,6 +1,15 @@
 """GPU parity: libdgsct.so (hand-written gfx950 kernels, through the C ABI) against the reference golden
-vectors and against the oracle at real AVE shapes.  Tolerances are BASELINE.json's: 1e-3 (fp32), 1e-2 (bf16),
-measured as max|err| / max(1, max|ref|) (fp32) and max|err| / max|ref| (bf16, tensors can be small)."""
+vectors and against the oracle at real AVE shapes.
+
+fp32: BASELINE.json's 1e-3, measured as max|err| / max(1, max|ref|), every output, every gradient, BN buffers.
+bf16: OUTPUTS (out, map) within BASELINE.json's 1e-2 in relative L2 and 2e-2 in the worst element (max|err| / max|ref|) at
+real shapes; every tensor (outputs AND all gradients) within the emulator-derived per-case bound of
+tests/golden/bf16_bounds.json (oracle/make_bf16_bounds.py: the range an IDEAL bf16-storage evaluation of the same
+schedule covers when its inputs move by one bf16 ulp -- gradients of this model are not 1e-2-stable under ANY bf16
+rounding: ReLU-mask flips and un-scaled softmax logits, DESIGN.md section 7 / tools/bf16_sensitivity.py).  The oracle
+always sees the same bf16-representable inputs as the library."""
+import json
+import os
 import pytest
 import torch
 
@@ -13,6 +22,27 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 TOL_F32 = 1e-3
 TOL_BF16 = 1e-2
+BOUNDS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bounds.json")))
+
+
+def _l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def check_bounds(name, got, ref_out, ref_map, ref_dX, ref_dY, ref_grads):
+    """every tensor of a bf16 run within the emulator-derived relative-L2 bound of its case"""
+    b = BOUNDS[name]
+    bad = []
+    for k, g, r in (("out", got["out"], ref_out), ("map", got["map"], ref_map), ("dX", got["dX"], ref_dX), ("dY", got["dY"], ref_dY)):
+        assert torch.isfinite(g.float()).all(), k
+        if not _l2(g, r) <= b[k]:
+            bad.append((k, round(_l2(g, r), 4), round(b[k], 4)))
+    for k, bound in b["grads"].items():
+        e = _l2(got["grads"][k].reshape(-1), ref_grads[k].reshape(-1))
+        if not e <= bound:
+            bad.append((k, round(e, 4), round(bound, 4)))
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -46,23 +76,20 @@ def test_golden_eval_fp32(name):
 
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_bf16(name):
-    """bf16 storage + bf16 MFMA on tiny un-averaged problems: outputs within 1e-2; gradients of the tiny
-    problems (C=16..64, K as small as 2) are checked at 3e-2 of the tensor's max."""
-    # The golden cases are deliberately tiny (C = 16..64, bottleneck width 4, 1-2 channels per conv group):
-    # LayerNorm/BatchNorm over 4-16 values with rstd up to 1/sqrt(eps) amplify bf16 storage rounding far beyond
-    # what real shapes see (the host emulation of bf16 storage with fp64 accumulation shows the same numbers:
-    # tests/test_schedule_emu.py).  So here: forward within 3e-2, gradients only on the well-conditioned cases;
-    # the 1e-2 bf16 bar of BASELINE.json is enforced at real AVE shapes in test_real_shapes_bf16.
+    """all 12 flavour cases in bf16, outputs AND every gradient, against the oracle on the same bf16-rounded inputs (the
+    fixtures' own inputs are generic fp32, so their stored results are not the reference of a bf16 run), each tensor within
+    its emulator-derived bound.  The cases are deliberately tiny (4-16 bottleneck channels): one flipped ReLU unit moves a
+    gradient by 1-25 %, which is what the bounds of these cases reflect."""
     fx = load_golden(name)
     r = run_library(default_lib(), fx, DEV, torch.bfloat16, training=True)
-    degenerate = name == "avqa_audio_nogate"       # 1 bottleneck channel per group, no BN, no gate
-    assert nrm_err(r["out"], fx["out"]) < (0.2 if degenerate else 3e-2)
-    assert nrm_err(r["map"], fx["map"]) < TOL_BF16
-    # gradient check only where the IDEAL bf16-storage emulation (tests/emu, fp64 accumulation) itself stays below 4 %:
-    # on the other tiny cases a ReLU/BatchNorm over 4-16 values flips with any change of rounding (0.8 % <-> 17 %)
-    if name in ("ave_orderB", "ave_nobn_noln", "pretrain", "avs_ms3"):
-        assert nrm_err(r["dX"], fx["dX"]) < 8e-2       # one realisation of amplified bf16 rounding noise: 0.8-6 %
-        assert nrm_err(r["dY"], fx["dY"]) < 8e-2
+    cfg = oracle_cfg(fx["cfg"])
+    state = {k: v.clone() for k, v in fx["state0"].items()}
+    if cfg.remap == "bicubic":
+        state["_bicubic"] = O.bicubic_matrix(cfg.No, cfg.N)
+    rb = lambda t: t.bfloat16().float()
+    out_o, map_o, _, s = O.forward(state, rb(fx["X"]), rb(fx["Y"]), cfg, training=True)
+    dX_o, dY_o, g_o = O.backward(state, s, cfg, rb(fx["dOut"]), fx["dMap"], fx["dTmap"], training=True)
+    check_bounds(name, r, out_o, map_o, dX_o, dY_o, g_o)
 
 
 def _real_case(N, C, No, Co, BT, dtype, seed=0, flavour="ave"):
@@ -107,34 +134,18 @@ def test_real_shapes_fp32(shape):
         assert rel_err(g, go.reshape(-1)) < TOL_F32, k
 
 
-def _l2(a, b):
-    a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
-
-
 @pytest.mark.parametrize("shape", REAL)
 def test_real_shapes_bf16(shape):
     """bf16 storage + bf16 MFMA at real AVE shapes against the fp32 oracle on the same (bf16-representable) inputs.
-    BASELINE.json's bf16 bar is on OUTPUTS: out and map within 1e-2 (relative L2; worst element within 3e-2 of
-    max|ref|).  Gradients are reported at the accuracy an ideal bf16-storage implementation reaches (host emulation
-    with fp64 accumulation gives the same figures): relative L2 <= 0.1 for dX/dY and the weight
-    gradients; ln_before.bias (analytically zero: BN removes it) and the two scalar gates (ill-conditioned global
-    sums) are checked loosely."""
-    r = _real_case(*shape, BT=10, dtype=torch.bfloat16)
+    Outputs: BASELINE.json's 1e-2 (relative L2) and 2e-2 of max|ref| in the worst element.  Every tensor, gradients
+    included: the emulator-derived bound of the shape (tests/golden/bf16_bounds.json)."""
+    r = _real_case(*shape, BT=10, dtype=torch.bfloat16, seed=0)
     for k in ("out", "map"):
         assert _l2(*r[k]) < TOL_BF16, (k, _l2(*r[k]))
-        assert nrm_err(*r[k]) < 3 * TOL_BF16, (k, nrm_err(*r[k]))
-    for k in ("dX", "dY"):
-        assert _l2(*r[k]) < 0.1, (k, _l2(*r[k]))
-    for k, (g, go) in r["grads"].items():
-        if k == "ln_before.bias":
-            assert g.abs().max().item() < 1e-2 * r["grads"]["ln_before.weight"][1].abs().max().item()
-        elif go.dim() < 2 or go.numel() == go.shape[0]:
-            # biases / scalar gates / 1-D vectors: global sums with heavy cancellation (|grad| << sum of |terms|), so the
-            # ~5 % error the bf16 forward puts on the activations shows up amplified; weight MATRICES stay below 0.15
-            assert _l2(g, go.reshape(-1)) < 0.6, (k, _l2(g, go.reshape(-1)))
-        else:
-            assert _l2(g, go.reshape(-1)) < 0.15, (k, _l2(g, go.reshape(-1)))
+        assert nrm_err(*r[k]) < 2 * TOL_BF16, (k, nrm_err(*r[k]))
+    got = dict(out=r["out"][0], map=r["map"][0], dX=r["dX"][0], dY=r["dY"][0], grads={k: v[0] for k, v in r["grads"].items()})
+    check_bounds(f"real_{shape[0]}x{shape[1]}", got, r["out"][1], r["map"][1], r["dX"][1], r["dY"][1],
+                 {k: v[1] for k, v in r["grads"].items()})
 
 
 @pytest.mark.parametrize("flavour", ["avvp", "avs_s4", "avs_ms3", "avqa", "pretrain"])

@@ -10,6 +10,9 @@
   an unpinned link (fp32@160 frames).
 
 All through the C ABI, against the CPU oracle on identical (bf16-representable for the bf16 runs) inputs."""
+import json
+import os
+
 import pytest
 import torch
 
@@ -69,19 +72,27 @@ def check_fp32(r):
         assert rel_err(g, go.reshape(-1)) < TOL_F32, (k, rel_err(g, go.reshape(-1)))
 
 
-def check_bf16(r, grad_l2=0.1):
-    """outputs: BASELINE's 1e-2 (relative L2; worst element 3e-2 of max|ref|); gradients: see DESIGN.md section 7 (the
-    ReLU-mask / un-scaled-logit sensitivity bounds what ANY bf16-operand evaluation can reach against fp32)."""
+_B = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bounds.json")))
+_REAL = [v for k, v in _B.items() if k.startswith("real_")]
+CAP_DX = max(v["dX"] for v in _REAL)            # largest emulator-derived bound among the four stage-2/3 AVE shapes
+CAP_DY = max(v["dY"] for v in _REAL)
+CAP_W = max(max(v["grads"].values()) for v in _REAL)
+
+
+def check_bf16(r):
+    """outputs: BASELINE's 1e-2 (relative L2) and 2e-2 of max|ref| in the worst element.  Gradients: the largest
+    emulator-derived bound of the real-shape cases of tests/golden/bf16_bounds.json (the shapes here have no bound of
+    their own: the host emulation of a stage-0 shape takes minutes) -- see tests/test_adapter_gpu.py's docstring."""
     for k in ("out", "map"):
         assert torch.isfinite(r[k][0].float()).all(), k
         assert _l2(*r[k]) < 1e-2, (k, _l2(*r[k]))
-        assert nrm_err(*r[k]) < 3e-2, (k, nrm_err(*r[k]))
-    for k in ("dX", "dY"):
-        assert _l2(*r[k]) < grad_l2, (k, _l2(*r[k]))
+        assert nrm_err(*r[k]) < 2e-2, (k, nrm_err(*r[k]))
+    assert _l2(*r["dX"]) < CAP_DX, ("dX", _l2(*r["dX"]))
+    assert _l2(*r["dY"]) < CAP_DY, ("dY", _l2(*r["dY"]))
     for k, (g, go) in r["grads"].items():
         assert torch.isfinite(g).all(), k
         if go.dim() >= 2 and go.numel() > go.shape[0] and k != "ln_before.bias":
-            assert _l2(g, go.reshape(-1)) < 1.5 * grad_l2, (k, _l2(g, go.reshape(-1)))
+            assert _l2(g, go.reshape(-1)) < CAP_W, (k, _l2(g, go.reshape(-1)))
 
 
 # (N, C, No, Co): Swin-V2-L visual widths 192/384/768/1536 against HTS-AT 96/192/384/768, visual and audio direction

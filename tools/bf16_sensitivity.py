@@ -1,0 +1,157 @@
+"""Where does the bf16 gradient error of the adapter come from?  (evidence for DESIGN.md section 7; TEST TOOLING -- imports oracle/)
+
+The oracle's forward/backward with a switchable bf16 rounding at every tensor the bf16 schedule stores or feeds to an MFMA
+(`Q([...names...])`), at one real AVE shape against the un-rounded fp32 evaluation.  Findings it reproduces (rel-L2 of dX / dY):
+
+* rounding ONLY X1 (the adapter's main-path activation) to bf16 costs ~3 % on dX, ONLY X3 ~2.6 %, ONLY the bottleneck weight
+  Wd ~2.7 %, while rounding the bottleneck pre-activation Zp itself costs 0.4 %: the error is not proportional to the
+  perturbation -- the bottleneck ReLU flips the mask of the units whose pre-activation the perturbation carries across zero
+  (a fraction ~eps of them), and each flip changes that unit's gradient by 100 %: error ~ sqrt(eps);
+* rounding ONLY the remap weights Wn / Wc, or ONLY Yp, moves dY by 1.5-3 % at C = 512 and by 7-10 % at C = 1024: the
+  latent-token softmaxes are un-scaled (logits ~ sqrt(C) ~ 18-32), so a 2^-9 perturbation of Yp / tok is amplified ~20x
+  before it reaches X1 and that ReLU;
+* keeping the main path X1 -> X3 -> Zp, the latent tokens and Wd in fp32 ("new scheme") takes dX from ~4.5 % to ~2-3 %;
+  the rest needs Yp / T / Wn / Wc un-rounded, i.e. the remap GEMMs (half of all FLOPs) at 2-3x their bf16 cost.
+
+usage: python tools/bf16_sensitivity.py [N,C,No,Co]        (default 144,512,256,384; CPU, ~1 min)
+"""
+import sys, torch, torch.nn.functional as F
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import dgsct_oracle as O
+torch.set_num_threads(8)
+def mk(N,C,No,Co,BT=10,seed=0):
+    cfg = O.AdapterConfig(N=N,C=C,No=No,Co=Co,tk=32,r=8,g=2)
+    p = O.random_params(cfg,'ave',seed=seed,scale=0.577)
+    gen = torch.Generator().manual_seed(seed+1)
+    X = torch.randn(BT,N,C,generator=gen).bfloat16().float(); Y = torch.randn(BT,No,Co,generator=gen).bfloat16().float()
+    dOut = torch.randn(BT,N,C,generator=gen).bfloat16().float(); dMap = torch.randn(BT,N,generator=gen)
+    return cfg,p,X,Y,dOut,dMap
+class Q:
+    def __init__(self, names): self.names=set(names)
+    def __call__(self, name, x):
+        if name in self.names or '*' in self.names and ('-'+name) not in self.names: return x.bfloat16().float()
+        return x
+def run(cfg,p,X,Y,dOut,dMap,q):
+    B,N,C = X.shape; R=B*N
+    W = lambda n: q('W:'+n.replace('fc_affine_','').replace('.weight',''), p[n])    # bf16 weight copies
+    Wc,bc = p['fc.weight'],p['fc.bias']; Wn = p['conv_adapter.weight'].reshape(N,cfg.No); bn = p['conv_adapter.bias']
+    rowb,colb,colb2 = bn, Wc.sum(1), bc
+    order = cfg.remap_order()
+    if order=='A':
+        T1 = q('T', torch.einsum('mn,bnk->bmk', q('W:Wn',Wn), Y)); Yp = T1 @ q('W:Wc',Wc).t()
+    else:
+        T2t = q('T', torch.einsum('ck,bnk->bcn', q('W:Wc',Wc), Y)); Yp = torch.einsum('mn,bcn->bmc', q('W:Wn',Wn), T2t)
+    Yp = q('Yp', Yp + rowb[None,:,None]*colb[None,None,:] + colb2)
+    T0 = p['my_tokens']
+    S1 = torch.einsum('tc,bnc->btn', q('T0',T0), Yp)
+    P1f = torch.softmax(S1,-1); P1 = q('P1',P1f)
+    tok = q('tok', T0[None] + P1 @ Yp)
+    a = Yp.mean(1)
+    S2 = X @ q('tokS',tok).transpose(1,2)
+    P2 = q('P2', torch.softmax(S2,-1))
+    gav = p['gate_av']
+    X1full = X + gav*(q('P2m',torch.softmax(S2,-1)) @ q('tokV',tok)); X1 = q('X1', X + gav*(P2 @ q('tokV',tok))); X1m = q('X1m', X1full)
+    aE = q('aE',a)
+    aq1 = q('aq', F.relu(F.linear(aE, W('fc_affine_audio_1.weight'), p['fc_affine_audio_1.bias'])))
+    aq2 = q('aq', F.relu(F.linear(aE, W('fc_affine_audio_2.weight'), p['fc_affine_audio_2.bias'])))
+    vq1 = q('vq1', F.relu(F.linear(X1, W('fc_affine_video_1.weight'), p['fc_affine_video_1.bias'])))
+    mvq1 = vq1.mean(1); m1 = q('m1', aq1*mvq1)
+    qq = q('q', F.relu(F.linear(m1, W('fc_affine_bottleneck.weight'), p['fc_affine_bottleneck.bias'])))
+    ch = torch.sigmoid(F.linear(qq, W('fc_affine_v_c_att.weight'), p['fc_affine_v_c_att.bias']))
+    Xc = q('Xc', X1*(1+ch[:,None,:]))
+    vq2 = q('vq2', F.relu(F.linear(Xc, W('fc_affine_video_2.weight'), p['fc_affine_video_2.bias'])))
+    ws,bs = p['fc_affine_v_s_att.weight'].reshape(-1), p['fc_affine_v_s_att.bias']
+    sl = (vq2*(aq2*ws)[:,None,:]).sum(-1)+bs; sg = torch.sigmoid(sl); amap = torch.softmax(torch.tanh(sl),-1)
+    mod = cfg.alpha*ch[:,None,:] + cfg.beta*sg[:,:,None] + (1-cfg.alpha)
+    X2 = X1m*mod
+    X3f, xh_b, rstd_b = O._ln(X2, p['ln_before.weight'], p['ln_before.bias'], cfg.eps); X3 = q('X3',X3f)
+    Wd = p['down_sampler.weight'].reshape(cfg.ds, C//cfg.g); Wu = p['up_sampler.weight'].reshape(C, cfg.ds//cfg.g)
+    Zp = q('Zp', O._groupmm(X3, q('W:Wd',Wd), cfg.g))
+    def bn_(x,name):
+        w,b = p[name+'.weight'],p[name+'.bias']; xf=x.reshape(R,-1); mu=xf.mean(0); var=((xf-mu)**2).mean(0); rstd=torch.rsqrt(var+cfg.eps); xh=(x-mu)*rstd
+        return xh*w+b, xh, rstd
+    Zb,zh,rstd1 = bn_(Zp,'bn1'); Z = q('Z',F.relu(Zb))
+    Op = q('Op', O._groupmm(Z, q('W:Wu',Wu), cfg.g))
+    Oo,oh,rstd2 = bn_(Op,'bn2')
+    L,xh_p,rstd_p = O._ln(Oo, p['ln_post.weight'], p['ln_post.bias'], cfg.eps)
+    gate = p['gate']; out = q('out', L*gate)
+    # ---- backward
+    g={}
+    g['gate']=(dOut*L).sum().reshape(1); dL = dOut*gate
+    dO,g['ln_post.weight'],g['ln_post.bias'] = O._ln_bwd(dL,xh_p,rstd_p,p['ln_post.weight']); dO = q('dO',dO)
+    def bn_bwd(dy,xh,rstd,name):
+        w=p[name+'.weight']; dyf,xhf=dy.reshape(R,-1),xh.reshape(R,-1); dw=(dyf*xhf).sum(0); db=dyf.sum(0)
+        g[name+'.weight'],g[name+'.bias']=dw,db
+        return w*rstd*(dy-db/R-xh*(dw/R))
+    dOp = q('dO', bn_bwd(dO,oh,rstd2,'bn2'))
+    dZ,dWu = O._groupmm_bwd(dOp,Z,q('W:Wu',Wu),cfg.g); g['up_sampler.weight']=dWu.reshape(p['up_sampler.weight'].shape); dZ=q('dZ',dZ)
+    dZb = dZ*(Z>0); dZp = q('dZ', bn_bwd(dZb,zh,rstd1,'bn1'))
+    dX3,dWd = O._groupmm_bwd(dZp,X3,q('W:Wd',Wd),cfg.g); g['down_sampler.weight']=dWd.reshape(p['down_sampler.weight'].shape); dX3=q('dX3',dX3)
+    dX2,g['ln_before.weight'],g['ln_before.bias'] = O._ln_bwd(dX3,xh_b,rstd_b,p['ln_before.weight'])
+    dX1 = q('dX1', dX2*mod); dmod = dX2*X1m
+    dch = cfg.alpha*dmod.sum(1); dsg = cfg.beta*dmod.sum(2)
+    dsl = dsg*sg*(1-sg); dt = amap*(dMap-(amap*dMap).sum(-1,keepdim=True)); dsl = dsl + dt*(1-torch.tanh(sl)**2)
+    u = (dsl[:,:,None]*vq2).sum(1); g['fc_affine_v_s_att.bias']=dsl.sum().reshape(1); g['fc_affine_v_s_att.weight']=(u*aq2).sum(0)
+    daq2 = u*ws
+    dvq2 = q('dvq2', dsl[:,:,None]*(aq2*ws)[:,None,:]*(vq2>0))
+    dXc = q('dXc', dvq2 @ W('fc_affine_video_2.weight'))
+    g['fc_affine_video_2.weight'] = dvq2.reshape(R,-1).t() @ Xc.reshape(R,C); g['fc_affine_video_2.bias']=dvq2.reshape(R,-1).sum(0)
+    dX1 = q('dX1', dX1 + dXc*(1+ch[:,None,:])); dch = dch + (dXc*X1).sum(1)
+    dpre_c = q('dpre', dch*ch*(1-ch))
+    g['fc_affine_v_c_att.weight']=dpre_c.t()@qq; g['fc_affine_v_c_att.bias']=dpre_c.sum(0)
+    dq = q('dpre', (dpre_c @ W('fc_affine_v_c_att.weight'))*(qq>0))
+    g['fc_affine_bottleneck.weight']=dq.t()@m1; g['fc_affine_bottleneck.bias']=dq.sum(0)
+    dm1 = dq @ W('fc_affine_bottleneck.weight'); daq1 = dm1*mvq1; dmvq1 = dm1*aq1
+    dvq1 = q('dvq1', (dmvq1/N)[:,None,:]*(vq1>0))
+    dX1 = q('dX1', dX1 + dvq1 @ W('fc_affine_video_1.weight'))
+    g['fc_affine_video_1.weight']=dvq1.reshape(R,C).t()@X1.reshape(R,C); g['fc_affine_video_1.bias']=dvq1.reshape(R,C).sum(0)
+    dpa1 = q('dpre', daq1*(aq1>0)); dpa2 = q('dpre', daq2*(aq2>0))
+    g['fc_affine_audio_1.weight']=dpa1.t()@aE; g['fc_affine_audio_1.bias']=dpa1.sum(0); g['fc_affine_audio_2.weight']=dpa2.t()@aE; g['fc_affine_audio_2.bias']=dpa2.sum(0)
+    da = dpa1 @ W('fc_affine_audio_1.weight') + dpa2 @ W('fc_affine_audio_2.weight')
+    U = dX1 @ q('tokS',tok).transpose(1,2)
+    g['gate_av']=(P2*U).sum().reshape(1); dP2 = gav*U
+    dS2 = q('dS2', P2*(dP2-(P2*dP2).sum(-1,keepdim=True)))
+    dX = q('dX', dX1 + dS2 @ q('tokV',tok))
+    dtok = gav*(P2.transpose(1,2)@dX1) + dS2.transpose(1,2)@X
+    dtokE = q('dtok',dtok)
+    dP1 = dtokE @ Yp.transpose(1,2)
+    dS1 = q('dS1', P1*(dP1-(P1*dP1).sum(-1,keepdim=True)))
+    g['my_tokens'] = dtok.sum(0) + torch.einsum('btn,bnc->tc',dS1,Yp)
+    dYp = q('dYp', P1.transpose(1,2)@dtokE + torch.einsum('btn,tc->bnc',dS1,q('T0',T0)) + (da/N)[:,None,:])
+    wcsum = Wc.sum(1)
+    g['fc.bias']=dYp.sum((0,1)); g['conv_adapter.bias']=torch.einsum('bmc,c->m',dYp,wcsum); dwcsum=torch.einsum('bmc,m->c',dYp,bn)
+    if order=='A':
+        dT1 = q('dT', dYp @ q('W:Wc',Wc)); dWc = torch.einsum('bmc,bmk->ck',dYp,T1); dY = torch.einsum('mn,bmk->bnk',q('W:Wn',Wn),dT1); dWn = torch.einsum('bmk,bnk->mn',dT1,Y)
+    else:
+        dT2t = q('dT', torch.einsum('bmc,mn->bcn',dYp,q('W:Wn',Wn))); dWn = torch.einsum('bmc,bcn->mn',dYp,T2t); dY = torch.einsum('bcn,ck->bnk',dT2t,q('W:Wc',Wc)); dWc = torch.einsum('bcn,bnk->ck',dT2t,Y)
+    g['fc.weight']=dWc+dwcsum[:,None]; g['conv_adapter.weight']=dWn
+    return dict(out=out,map=amap,dX=dX,dY=q('dY',dY),g=g)
+def l2(a,b): return ((a-b).norm()/b.norm().clamp_min(1e-30)).item()
+def report(tag, r, ref):
+    gs = sorted(((l2(r['g'][k].reshape(-1), ref['g'][k].reshape(-1)),k) for k in ref['g'] if k not in('ln_before.bias',)), reverse=True)
+    print(f"{tag:34s} out {l2(r['out'],ref['out']):.4f} dX {l2(r['dX'],ref['dX']):.4f} dY {l2(r['dY'],ref['dY']):.4f} | "+' '.join(f"{k.replace('fc_affine_','').replace('.weight','.w').replace('.bias','.b')}:{e:.3f}" for e,k in gs[:6]))
+
+
+
+if __name__=='__main__':
+    shape = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv)>1 else (144,512,256,384)
+    args = mk(*shape)
+    WS = ['W:Wn','W:Wc','W:Wd','W:Wu','W:audio_1','W:audio_2','W:video_1','W:video_2','W:bottleneck','W:v_c_att']
+    ALL = WS+['T','Yp','T0','P1','tok','tokS','tokV','P2','P2m','X1','X1m','aE','aq','vq1','m1','q','Xc','vq2','X3','Zp','Z','Op','out','dO','dZ','dX3','dX1','dvq2','dXc','dpre','dvq1','dS2','dX','dtok','dS1','dYp','dT','dY']
+    def without(*xs): return [a for a in ALL if a not in xs]
+    ref = run(*args, Q([]))
+    print('== one tensor rounded at a time (generic fp32 weights)')
+    for n in ['X1m','X3','W:Wd','Zp','W:Wn','W:Wc','Yp','T','tok','P1','P2']:
+        report('only '+n, run(*args,Q([n] + (['X1'] if n=='X1m' else []))), ref)
+    NEW = without('X1m','P2m','X3','W:Wd','tok','tokS','tokV','T0')
+    for wexact in (False, True):
+        cfg,p,X,Y,dOut,dMap = args
+        if wexact:
+            p = {k:(v.bfloat16().float() if v.is_floating_point() and v.dim()>=2 else v) for k,v in p.items()}
+        a2 = (cfg,p,X,Y,dOut,dMap)
+        ref = run(*a2, Q([]))
+        print('== weights bf16-representable' if wexact else '== generic fp32 weights')
+        report('  every stored tensor bf16', run(*a2,Q(ALL)), ref)
+        report('  fp32 main path + latent tokens + Wd', run(*a2,Q(NEW)), ref)
+        report('  ... + Yp, T un-rounded', run(*a2,Q([n for n in NEW if n not in('P1','Yp','T')])), ref)
