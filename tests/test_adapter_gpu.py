@@ -13,7 +13,7 @@ import os
 import pytest
 import torch
 
-from helpers import golden_names, load_golden, nrm_err, oracle_cfg, param_table, rel_err, run_library, spec_of
+from helpers import golden_names, grad_close_fp32, load_golden, nrm_err, oracle_cfg, param_table, rel_err, run_library, spec_of
 from dgsct_amd import ops
 from dgsct_amd._lib import P_INDEX, PARAM_NAMES, default_lib
 from oracle import dgsct_oracle as O
@@ -131,7 +131,7 @@ def test_real_shapes_fp32(shape):
     for k in ("out", "map", "dX", "dY"):
         assert rel_err(*r[k]) < TOL_F32, k
     for k, (g, go) in r["grads"].items():
-        assert rel_err(g, go.reshape(-1)) < TOL_F32, k
+        assert grad_close_fp32(g, go, TOL_F32), (k, rel_err(g, go.reshape(-1)))
 
 
 @pytest.mark.parametrize("shape", REAL)
@@ -158,7 +158,7 @@ def test_real_shapes_flavours_fp32(flavour):
     assert not r["extra"], r["extra"]
     assert r["grads"]
     for k, (g, go) in r["grads"].items():
-        assert rel_err(g, go.reshape(-1)) < TOL_F32, k
+        assert grad_close_fp32(g, go, TOL_F32), (k, rel_err(g, go.reshape(-1)))
 
 
 def _full_size_setup(shape, seed, gate=None):
@@ -282,7 +282,7 @@ def test_real_shapes_stage01_fp32(shape):
     for k in ("out", "map", "dX", "dY"):
         assert rel_err(*r[k]) < TOL_F32, k
     for k, (g, go) in r["grads"].items():
-        assert rel_err(g, go.reshape(-1)) < TOL_F32, k
+        assert grad_close_fp32(g, go, TOL_F32), (k, rel_err(g, go.reshape(-1)))
 
 
 @pytest.mark.parametrize("shape", [STAGE01[0], STAGE01[1]])
