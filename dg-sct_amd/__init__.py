@@ -7,4 +7,5 @@ from ._lib import Lib, default_lib, LIB_PATH, PARAM_NAMES          # noqa: F401
 from .ops import AdapterSpec, map_pool                             # noqa: F401
 from .adapter import VisualAdapter, bicubic_matrix                 # noqa: F401
 from .stack import AdapterStack, ave_stage_shapes                  # noqa: F401
-from .dp import GradAllReducer, init_process_group                                     # noqa: F401
+from .dp import GradAllReducer, init_process_group                 # noqa: F401
+from .temporal import TemporalAttention                            # noqa: F401

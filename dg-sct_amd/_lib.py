@@ -63,7 +63,7 @@ class AttnArgs(C.Structure):
                                                                ("dtokpk", C.c_void_p)]
 
 
-EXPORTS = ["dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
+EXPORTS = ["dgsct_temporal_gate_forward", "dgsct_temporal_gate_backward", "dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
            "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect",
            "dgsct_stream_create", "dgsct_stream_destroy", "dgsct_map_pool_forward", "dgsct_map_pool_backward"]
 
@@ -100,6 +100,8 @@ class Lib:
                                          C.POINTER(C.c_int64)]
         c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
         c.dgsct_test_attn.argtypes = [C.c_int, C.POINTER(AttnArgs), C.c_void_p]
+        c.dgsct_temporal_gate_forward.argtypes = [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 14
+        c.dgsct_temporal_gate_backward.argtypes = [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 20
         c.dgsct_test_attn_scratch_floats.argtypes = [C.c_int] * 4
         c.dgsct_test_attn_scratch_floats.restype = C.c_int64
         c.dgsct_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -168,6 +170,12 @@ class Lib:
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         self.c.dgsct_prof_collect(C.byref(n), C.byref(ms), C.byref(fl))
         return n.value, ms.value, fl.value
+
+    def temporal_gate_forward(self, R, D, gamma, *ptrs):
+        self._check(self.c.dgsct_temporal_gate_forward(R, D, gamma, *ptrs), "dgsct_temporal_gate_forward")
+
+    def temporal_gate_backward(self, R, D, gamma, *ptrs):
+        self._check(self.c.dgsct_temporal_gate_backward(R, D, gamma, *ptrs), "dgsct_temporal_gate_backward")
 
     def test_attn(self, op: int, args: "AttnArgs", stream: int):
         self._check(self.c.dgsct_test_attn(int(op), C.byref(args), stream), "dgsct_test_attn")

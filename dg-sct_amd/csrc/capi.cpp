@@ -141,6 +141,35 @@ int dgsct_map_pool_backward(int dtype, int BT, int N, int C, const void* F, cons
   return has_error() ? 1 : 0;
 }
 
+int dgsct_temporal_gate_forward(int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
+                                const float* wa, const float* ba, const float* wv, const float* bv, float* out_v, float* out_a,
+                                float* gate, float* ga, float* gv, void* stream) {
+  clear_error();
+  if (!akv || !vkv || !vq || !aq || !wa || !ba || !wv || !bv || !out_v || !out_a || !gate || !ga || !gv) {
+    set_error("dgsct_temporal_gate_forward: NULL argument");
+    return 2;
+  }
+  Ctx ctx{stream, DT_F32};
+  temporal_gate_fwd(ctx, R, D, gamma, akv, vkv, vq, aq, wa, ba, wv, bv, out_v, out_a, gate, ga, gv);
+  check_async("dgsct_temporal_gate_forward");
+  return has_error() ? 1 : 0;
+}
+int dgsct_temporal_gate_backward(int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
+                                 const float* wa, const float* wv, const float* ga, const float* gv, const float* dOv,
+                                 const float* dOa, const float* dg, float* dakv, float* dvkv, float* dvq, float* daq, float* dwa,
+                                 float* dba, float* dwv, float* dbv, void* stream) {
+  clear_error();
+  if (!akv || !vkv || !vq || !aq || !wa || !wv || !ga || !gv || !dOv || !dOa || !dakv || !dvkv || !dvq || !daq || !dwa || !dba ||
+      !dwv || !dbv) {
+    set_error("dgsct_temporal_gate_backward: NULL argument");
+    return 2;
+  }
+  Ctx ctx{stream, DT_F32};
+  temporal_gate_bwd(ctx, R, D, gamma, akv, vkv, vq, aq, wa, wv, ga, gv, dOv, dOa, dg, dakv, dvkv, dvq, daq, dwa, dba, dwv, dbv);
+  check_async("dgsct_temporal_gate_backward");
+  return has_error() ? 1 : 0;
+}
+
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
   clear_error();
   if (!a) return 2;

@@ -187,6 +187,14 @@ void tokattn_bwd(const Ctx&, const void* Yp, const float* T0, const float* tok, 
                  const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float* Dscratch,
                  const void* T0pk = nullptr, void* dtokpk = nullptr);
 
+// ---- TemporalAttention gate application (temporal.hip; reference net_trans.py:240-251), fp32 rows [R][D] ----------------
+void temporal_gate_fwd(const Ctx&, int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
+                       const float* wa, const float* ba, const float* wv, const float* bv, float* out_v, float* out_a, float* gate,
+                       float* ga, float* gv);
+void temporal_gate_bwd(const Ctx&, int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
+                       const float* wa, const float* wv, const float* ga, const float* gv, const float* dOv, const float* dOa,
+                       const float* dg, float* dakv, float* dvkv, float* dvq, float* daq, float* dwa, float* dba, float* dwv, float* dbv);
+
 // Small fp32/E elementwise helpers on [n]-sized vectors (n <= a few 100k).
 enum EwOp : int {
   EW_MUL = 0,          // o = a*b

@@ -164,6 +164,22 @@ int dgsct_map_pool_forward(int dtype, int BT, int N, int C, const void* F, const
 int dgsct_map_pool_backward(int dtype, int BT, int N, int C, const void* F, const float* map, const float* dPooled,
                             void* dF, float* dMap, void* stream);
 
+/* ---- gate application of the post-backbone TemporalAttention ---------------------------
+ * Replaces the tail of `TemporalAttention.forward` (DG-SCT/AVE/nets/net_trans.py:240-251; AVVP nets/mgn.py:148-159):
+ *   audio_gate = audio_gated(audio_key_value_feature); video_gate = video_gated(video_key_value_feature)     [T,B,1]
+ *   video_query_output += audio_gate * video_query_output * gamma;  audio_query_output += video_gate * audio_query_output * gamma
+ *   audio_visual_gate = audio_gate * video_gate
+ * with `*_gated` = nn.Sequential(nn.Linear(d_model, 1), nn.Sigmoid()).  All tensors fp32, rows R = T * B, D = d_model
+ * (a multiple of 4, <= 1024).  forward writes out_v, out_a [R][D], gate [R] and the two gates ga, gv [R] (kept for backward);
+ * backward writes the input gradients and OVERWRITES dwa, dwv [D], dba, dbv [1].  dg may be NULL. */
+int dgsct_temporal_gate_forward(int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
+                                const float* wa, const float* ba, const float* wv, const float* bv, float* out_v, float* out_a,
+                                float* gate, float* ga, float* gv, void* stream);
+int dgsct_temporal_gate_backward(int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
+                                 const float* wa, const float* wv, const float* ga, const float* gv, const float* dOv,
+                                 const float* dOa, const float* dg, float* dakv, float* dvkv, float* dvq, float* daq, float* dwa,
+                                 float* dba, float* dwv, float* dbv, void* stream);
+
 /* ---- introspection / test hooks (used by tests/ only) ------------------------------------------ */
 /* i-th named region of the `saved` buffer; returns 0 and fills name/offset/bytes, or 1 past the end. */
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes);

@@ -613,4 +613,39 @@ void tokattn_bwd(const Ctx& ctx, const void* Yp, const float* T0, const float* t
       }
   }
 }
+void temporal_gate_fwd(const Ctx&, int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
+                       const float* wa, const float* ba, const float* wv, const float* bv, float* out_v, float* out_a, float* gate,
+                       float* ga, float* gv) {
+  for (int r = 0; r < R; ++r) {
+    double sa = *ba, sv = *bv;
+    for (int c = 0; c < D; ++c) { sa += (double)akv[(long)r * D + c] * wa[c]; sv += (double)vkv[(long)r * D + c] * wv[c]; }
+    const float a = sigm((float)sa), v = sigm((float)sv);
+    ga[r] = a; gv[r] = v; gate[r] = a * v;
+    for (int c = 0; c < D; ++c) { out_v[(long)r * D + c] = vq[(long)r * D + c] * (1.f + gamma * a); out_a[(long)r * D + c] = aq[(long)r * D + c] * (1.f + gamma * v); }
+  }
+}
+void temporal_gate_bwd(const Ctx&, int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
+                       const float* wa, const float* wv, const float* ga, const float* gv, const float* dOv, const float* dOa,
+                       const float* dg, float* dakv, float* dvkv, float* dvq, float* daq, float* dwa, float* dba, float* dwv, float* dbv) {
+  std::vector<double> A(D, 0.0), V(D, 0.0);
+  double sa = 0, sv = 0;
+  for (int r = 0; r < R; ++r) {
+    double da = 0, dv = 0;
+    for (int c = 0; c < D; ++c) {
+      const long o = (long)r * D + c;
+      da += (double)dOv[o] * vq[o]; dv += (double)dOa[o] * aq[o];
+      dvq[o] = dOv[o] * (1.f + gamma * ga[r]); daq[o] = dOa[o] * (1.f + gamma * gv[r]);
+    }
+    const double dgr = dg ? dg[r] : 0.0;
+    const double dpa = (gamma * da + dgr * gv[r]) * ga[r] * (1.0 - ga[r]), dpv = (gamma * dv + dgr * ga[r]) * gv[r] * (1.0 - gv[r]);
+    sa += dpa; sv += dpv;
+    for (int c = 0; c < D; ++c) {
+      const long o = (long)r * D + c;
+      dakv[o] = (float)(dpa * wa[c]); dvkv[o] = (float)(dpv * wv[c]);
+      A[c] += dpa * akv[o]; V[c] += dpv * vkv[o];
+    }
+  }
+  for (int c = 0; c < D; ++c) { dwa[c] = (float)A[c]; dwv[c] = (float)V[c]; }
+  *dba = (float)sa; *dbv = (float)sv;
+}
 }  // namespace dgsct
