@@ -155,8 +155,8 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no audio/visual adapter overlap)")
     ap.add_argument("--no-aux", action="store_true", help="no aux stream for weight gradients")
     ap.add_argument("--force-dp", action="store_true", help="run the RCCL gradient all-reduce path even with one rank (self-test)")
-    ap.add_argument("--overlap", action="store_true", help="DP: launch each stage's all-reduce from autograd hooks while the "
-                    "earlier stages' backward still runs (default: one grouped all-reduce after backward; see DESIGN.md section 5)")
+    ap.add_argument("--no-overlap", action="store_true", help="DP: one grouped all-reduce after backward instead of per-stage "
+                    "buckets launched from autograd hooks while the earlier stages' backward still runs (DESIGN.md section 5)")
     ap.add_argument("--phases", action="store_true", help="also report GPU ms of forward / backward (events on the main stream)")
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of eager launches "
                     "(ROCm 7.2: replaying ~6000 nodes costs as much host time as launching them, so this is off by default)")
@@ -190,7 +190,7 @@ def main():
     # N > 1: the 48 flat gradient buffers are all-reduced in place (RCCL, ncclAvg) as ONE grouped call after backward.
     # --overlap launches per-stage groups from autograd hooks instead; on ROCm 7.2 its extra cross-stream events can
     # stall the HIP launch path depending on stream->hardware-queue placement, so it is opt-in.
-    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack), overlap=args.overlap and not args.graph, force=args.force_dp) if dp else None
+    reducer = GradAllReducer(GradAllReducer.stage_buckets(stack), overlap=(not args.no_overlap) and not args.graph, force=args.force_dp) if dp else None
     use_graph = args.graph
     if use_graph or args.no_aux:
         from dgsct_amd import ops as _ops
@@ -204,34 +204,28 @@ def main():
     feats, cots, mcots = make_inputs(stages, BT, dtype, device, seed=1 + rank)
 
     phase_ev = []                          # (start, end-of-forward, end-of-backward) events of the timed steps (--phases)
+    from dgsct_amd.train import StackTrainer
+    trainer = StackTrainer(stack, opt, reducer)      # the step logic the gloo world-2 test drives (tests/test_host_cpu.py)
 
     def fwd_bwd():
         if args.phases:
             e0 = torch.cuda.Event(enable_timing=True); e0.record()
-        outs, maps = stack(feats)
-        if args.phases:
+            outs, maps = stack(feats)
             e1 = torch.cuda.Event(enable_timing=True); e1.record()
-        tensors = [t for pair in outs for t in pair] + [maps[0], maps[1]]
-        grads = [g for pair in cots for g in pair] + [mcots[0], mcots[1]]
-        torch.autograd.backward(tensors, grads)
-        if args.phases:
+            torch.autograd.backward([t for pair in outs for t in pair] + [maps[0], maps[1]],
+                                    [g for pair in cots for g in pair] + [mcots[0], mcots[1]])
             e2 = torch.cuda.Event(enable_timing=True); e2.record()
             phase_ev.append((e0, e1, e2))
-        for fv, fa in feats:
-            fv.grad = None
-            fa.grad = None
+            for fv, fa in feats:
+                fv.grad = None
+                fa.grad = None
+        else:
+            trainer.fwd_bwd(feats, cots, mcots)
 
     def update():
         if opt is not None:
             opt.step()
-            opt.zero_grad(set_to_none=not (use_graph and dp))
-        elif not (use_graph and dp):
-            for p in params:
-                p.grad = None
-        else:
-            for p in params:
-                if p.grad is not None:
-                    p.grad.zero_()
+        trainer.zero_grad(set_to_none=not (use_graph and dp))
 
     graphs = []
 
@@ -311,7 +305,7 @@ def main():
     clips_per_s = args.batch * world / (elapsed / args.steps)
 
     roofline = None
-    if rank == 0 and not args.no_roofline and not (dp and args.overlap):     # (overlap: autograd hooks would issue collectives)
+    if rank == 0 and not args.no_roofline:
         # dominant kernel family = the MFMA GEMM engine (gemm_kernel<...>): time every launch of two extra steps
         # with HIP events on the launch stream (the library records them itself: dgsct_prof_enable).
         lib = default_lib()
@@ -322,6 +316,9 @@ def main():
         def local_step():                # rank-local (no collective: the other ranks are not in this pass)
             fwd_bwd()
             update()
+
+        if reducer is not None:
+            reducer.paused = True        # the autograd hooks must not launch collectives here
 
         local_step()
         torch.cuda.synchronize()
@@ -357,6 +354,8 @@ def main():
         except Exception:
             pass
         stack.concurrent, _ops.USE_AUX_STREAM = conc, aux
+        if reducer is not None:
+            reducer.paused = False
         alg = 3.0 * alg_flops_per_frame(stages) * BT                 # fwd + bwd, per step
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = alg * nprof / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0

@@ -64,7 +64,9 @@ class GradAllReducer:
         # same graph, so every rank learns the same numbers); from the second step on the hooks launch each bucket as
         # soon as its last gradient exists.
         self._expected: List[Optional[int]] = [None] * len(self.buckets)
+        self._producers: List[set] = [set() for _ in self.buckets]
         self.hook_launches = 0                          # buckets launched from hooks (before finish()) in the last step
+        self.paused = False                             # True: hooks do nothing (rank-local passes, e.g. bench.py's profiling leg)
         self._work: List[object] = []
         self._reduced: List[torch.Tensor] = []          # tensors to scale by 1/world after the wait
         self._copy_back: List[tuple] = []               # (flat, params) of the fallback path
@@ -79,10 +81,14 @@ class GradAllReducer:
     # ------------------------------------------------------------------
     def _make_hook(self, bi: int):
         def hook(param):
+            if self.paused:
+                return
             if param.grad is not None and param.grad.is_cuda:
                 # the gradient was produced on whatever stream this adapter's backward ran on (main or the audio-side
-                # stream of AdapterStack): the communication stream must order after every producer of the bucket
-                self._comm_stream(param.grad.device).wait_stream(torch.cuda.current_stream(param.grad.device))
+                # stream of AdapterStack).  Only REMEMBER the stream here: the communication stream waits for the
+                # producer streams once per BUCKET, at launch (one event pair per stream and bucket -- 8 per step -- instead
+                # of one per gradient: every cross-stream event costs the recording stream a barrier packet)
+                self._producers[bi].add(torch.cuda.current_stream(param.grad.device))
             self._pending[bi] += 1
             if self._expected[bi] is not None and self._pending[bi] == self._expected[bi]:
                 self.hook_launches += 1
@@ -98,7 +104,7 @@ class GradAllReducer:
             self._stream = ops.priority_stream(_lib.default_lib(), device, +1)
         return self._stream
 
-    def _all_reduce(self, tensors: List[torch.Tensor]):
+    def _all_reduce(self, tensors: List[torch.Tensor], producers=()):
         """one grouped, in-place all-reduce of `tensors` (ncclGroupStart/End: ONE work object and ONE pair of stream
         events for the whole group -- per-tensor calls cost 48 event pairs per step, which stalls the HIP launch path)"""
         # RCCL averages in the collective itself (ncclAvg); gloo (CPU tests) sums and finish() scales
@@ -116,7 +122,11 @@ class GradAllReducer:
 
         if tensors[0].is_cuda and self.overlap:
             st = self._comm_stream(tensors[0].device)
-            st.wait_stream(torch.cuda.current_stream(tensors[0].device))
+            cur = torch.cuda.current_stream(tensors[0].device)
+            st.wait_stream(cur)
+            for ps in producers:
+                if ps != cur:
+                    st.wait_stream(ps)
             with torch.cuda.stream(st):
                 issue()
         else:
@@ -135,13 +145,13 @@ class GradAllReducer:
             # flattened adapters (VisualAdapter.flatten_parameters): the gradient of an adapter IS the library's flat
             # buffer -> reduce it in place, no staging copies
             if big:
-                self._all_reduce([p.grad for p in big])
+                self._all_reduce([p.grad for p in big], self._producers[bi])
             loose = [p for p in grads if all(p is not q for q in big)]
         else:
             loose = grads
         if loose:                                       # everything else: one flattened message per bucket
             flat = torch.cat([p.grad.reshape(-1).to(self.comm_dtype or torch.float32) for p in loose])
-            self._all_reduce([flat])
+            self._all_reduce([flat], self._producers[bi])
             self._copy_back.append((flat, loose))
 
     def finish(self):
@@ -165,10 +175,25 @@ class GradAllReducer:
                 n = p.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
+        self._reset()
+
+    def _reset(self):
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._producers = [set() for _ in self.buckets]
         self._work, self._reduced, self._copy_back = [], [], []
         self.last_hook_launches, self.hook_launches = self.hook_launches, 0
+
+    def discard(self):
+        """An iteration whose gradients are thrown away (the reference's `accum_itr` control flow, train.py): complete
+        whatever the hooks launched -- every rank launched the same collectives -- and forget it."""
+        if not self.active:
+            return
+        for w in self._work:
+            w.wait()
+        if self._stream is not None:
+            torch.cuda.current_stream(self._stream.device).wait_stream(self._stream)
+        self._reset()
 
     @staticmethod
     def stage_buckets(stack) -> List[List[torch.nn.Parameter]]:

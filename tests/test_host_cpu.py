@@ -276,3 +276,79 @@ def test_flat_parameters_refresh_prepared_weights_after_optimizer_step(dtype):
     out_ref = ref(X, Y)[0].detach()
     assert rel_err(out1, out_ref) < (1e-5 if dtype == torch.float32 else 2e-2)
     assert rel_err(out1, out0.detach()) > 1e-2, "the step did not change the output: stale prepared weights?"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _train_setup(emu, fx, lo, hi, flat):
+    from dgsct_amd.train import StackTrainer, make_optimizer, seed_everything
+    seed_everything(43, 0)
+    st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4, is_bn=0), lib=emu, concurrent=False)
+    st.load_state_dict(fx["state0"], strict=False)
+    if flat:
+        st.flatten_parameters()
+    opt, sched = make_optimizer(st, lr=1e-2, lr_mlp=1e-3, fused=False)
+    feats = [(a[lo:hi].clone(), b[lo:hi].clone()) for a, b in fx["feats"]]
+    cots = [(a[lo:hi].clone() / (hi - lo), b[lo:hi].clone() / (hi - lo)) for a, b in fx["cots"]]     # mean over the local clips
+    return st, opt, sched, feats, cots
+
+
+def _train_worker(rank, world, port, emu_path, q, accum_itr):
+    from dgsct_amd.train import StackTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    fx = load_golden("stack_2stage")
+    BT = fx["feats"][0][0].shape[0]
+    st, opt, sched, feats, cots = _train_setup(Lib(emu_path), fx, rank * BT // world, (rank + 1) * BT // world, True)
+    red = GradAllReducer(GradAllReducer.stage_buckets(st))
+    tr = StackTrainer(st, opt, red, accum_itr=accum_itr, accum_mode="reference")
+    stepped = [tr.step(feats, cots) for _ in range(4)]
+    if rank == 0:
+        q.put((stepped, {k: v.numpy().copy() for k, v in st.state_dict().items() if v.is_floating_point()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("accum_itr", [1, 2])
+def test_training_steps_under_dp_match_single_process(accum_itr):
+    """N optimizer steps (Adam + the reference's freeze rule and `accum_itr` control flow,
+    main_trans.py:110,135-136,211-278) of the identity-backbone stack, clips sharded over 2 gloo ranks with overlapped
+    bucketed gradient all-reduce, reproduce the single-process parameters.  accum_itr = 2 reproduces the reference's quirk:
+    zero_grad every iteration, step every 2nd -- only the 2nd, 4th, ... batch ever reaches the weights."""
+    from dgsct_amd.train import StackTrainer, shard_clips, trainable_by_name
+    emu_path = build_emu()
+    fx = load_golden("stack_2stage")
+    BT = fx["feats"][0][0].shape[0]
+    st, opt, sched, feats, cots = _train_setup(Lib(emu_path), fx, 0, BT, False)
+    assert all(p.requires_grad for n, p in st.named_parameters())          # every name contains 'adapter_blocks'
+    tr = StackTrainer(st, opt, None, accum_itr=accum_itr, accum_mode="reference")
+    stepped = [tr.step(feats, cots) for _ in range(4)]
+    assert stepped == ([True] * 4 if accum_itr == 1 else [False, True, False, True])
+    ref = {k: v.clone() for k, v in st.state_dict().items() if v.is_floating_point()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + 11 * accum_itr
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, emu_path, q, accum_itr)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got_stepped, got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert got_stepped == stepped
+    moved = 0
+    for k, v in ref.items():
+        assert rel_err(torch.from_numpy(got[k]), v) < 2e-4, k
+        moved += int((v - fx["state0"][k]).abs().max() > 1e-4) if k in fx["state0"] else 0
+    assert moved > 20                                                       # the steps really changed the parameters
+    # the name rule and the sampler
+    class P:                                                                # noqa: E306
+        requires_grad = True
+    named = [(n, P()) for n in ("swin.layers.0.blocks.0.norm1.weight", "htsat.patch_embed.proj.weight", "vis_adapter_blocks_p1.0.gate",
+                                "CMBS.video_input_proj.weight", "mlp_class.weight", "temporal_attn.v_fc.weight", "other.weight")]
+    groups = trainable_by_name(named, lr=5e-4, lr_mlp=5e-6)
+    assert [p.requires_grad for _, p in named] == [False, False, True, True, True, True, False]
+    assert [g["lr"] for g in groups] == [5e-4, 5e-4, 5e-4, 5e-4, 5e-6, 5e-4, 5e-4]
+    a, b = shard_clips(11, 0, 2, seed=43, epoch=3), shard_clips(11, 1, 2, seed=43, epoch=3)
+    assert len(a) == len(b) == 6 and set(a) | set(b) == set(range(11))
