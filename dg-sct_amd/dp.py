@@ -120,7 +120,18 @@ class GradAllReducer:
                         dist.all_reduce(t, op=op, group=self.group)
                 self._work.append(cm)
 
-        if tensors[0].is_cuda and self.overlap:
+        if tensors[0].is_cuda and self.overlap and os.environ.get("DGSCT_DP_COMM_STREAM", "0") != "1":
+            # Launch from the stream that produced the bucket's last gradient: ProcessGroupNCCL orders its own collective
+            # stream behind an event on the CURRENT stream, so no extra stream is needed -- the current stream only has to
+            # be behind the bucket's other producer (the second adapter stream of AdapterStack).  A dedicated communication
+            # stream costs one more hardware queue: its pending event waits sat in the low-priority queue pool next to the
+            # weight-gradient (aux) streams and stalled them (1 GPU, --force-dp: 100 vs 67 ms per step).
+            cur = torch.cuda.current_stream(tensors[0].device)
+            for ps in producers:
+                if ps != cur:
+                    cur.wait_stream(ps)
+            issue()
+        elif tensors[0].is_cuda and self.overlap:
             st = self._comm_stream(tensors[0].device)
             cur = torch.cuda.current_stream(tensors[0].device)
             st.wait_stream(cur)
