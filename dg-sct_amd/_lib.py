@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdgsct.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16_FP8 = 0, 1, 2
 REMAP_CONV, REMAP_FIXED = 0, 1
 
 # parameter table order == enum in include/dgsct.h; values are the reference state_dict names
@@ -63,7 +63,7 @@ class AttnArgs(C.Structure):
                                                                ("dtokpk", C.c_void_p)]
 
 
-EXPORTS = ["dgsct_temporal_gate_forward", "dgsct_temporal_gate_backward", "dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
+EXPORTS = ["dgsct_test_gemm_fp8", "dgsct_temporal_gate_forward", "dgsct_temporal_gate_backward", "dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
            "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect",
            "dgsct_stream_create", "dgsct_stream_destroy", "dgsct_map_pool_forward", "dgsct_map_pool_backward"]
 
@@ -100,6 +100,7 @@ class Lib:
                                          C.POINTER(C.c_int64)]
         c.dgsct_test_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
         c.dgsct_test_attn.argtypes = [C.c_int, C.POINTER(AttnArgs), C.c_void_p]
+        c.dgsct_test_gemm_fp8.argtypes = [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4
         c.dgsct_temporal_gate_forward.argtypes = [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 14
         c.dgsct_temporal_gate_backward.argtypes = [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 20
         c.dgsct_test_attn_scratch_floats.argtypes = [C.c_int] * 4
@@ -176,6 +177,9 @@ class Lib:
 
     def temporal_gate_backward(self, R, D, gamma, *ptrs):
         self._check(self.c.dgsct_temporal_gate_backward(R, D, gamma, *ptrs), "dgsct_temporal_gate_backward")
+
+    def test_gemm_fp8(self, M, N, K, A, W, bias, relu, D, w8, scale, stream):
+        self._check(self.c.dgsct_test_gemm_fp8(M, N, K, A, W, bias, int(relu), D, w8, scale, stream), "dgsct_test_gemm_fp8")
 
     def test_attn(self, op: int, args: "AttnArgs", stream: int):
         self._check(self.c.dgsct_test_attn(int(op), C.byref(args), stream), "dgsct_test_attn")

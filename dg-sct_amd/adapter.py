@@ -54,7 +54,8 @@ class VisualAdapter(nn.Module):
 
     def __init__(self, input_dim, output_dim, adapter_kind, dim_list=None, layer_idx=0, reduction_factor=16, opt=None,
                  use_bn=True, use_gate=True, num_tk=None, conv_dim_in=0, conv_dim_out=0, linear_in=0, linear_out=0,
-                 flavour: str = "ave", compute_dtype: Optional[torch.dtype] = None, lib: Optional[_lib.Lib] = None):
+                 flavour: str = "ave", compute_dtype: Optional[torch.dtype] = None, lib: Optional[_lib.Lib] = None,
+                 fp8_projections: bool = False):
         super().__init__()
         if flavour not in FLAVOUR_DEFAULTS:
             raise ValueError(f"unknown flavour {flavour!r}")
@@ -118,7 +119,7 @@ class VisualAdapter(nn.Module):
             N=int(conv_dim_out), C=int(C), No=int(conv_dim_in), Co=int(linear_in), tk=self.num_tk, r=int(reduction_factor), g=g,
             use_bn=bool(use_bn), use_gate=bool(use_gate), ln_before=bool(opt.is_before_layernorm) and fl["ln_before_ok"],
             ln_post=bool(opt.is_post_layernorm), gate_before_ln_post=fl["gate_first"], remap=fl["remap"],
-            alpha=alpha, beta=beta, gamma=gamma, temporal=fl["temporal"], T=fl["T"])
+            alpha=alpha, beta=beta, gamma=gamma, temporal=fl["temporal"], T=fl["T"], fp8=bool(fp8_projections))
         if fl["remap"] == "bicubic":
             self.register_buffer("_remap_op", bicubic_matrix(int(conv_dim_in), int(conv_dim_out)), persistent=False)
         self._prep_cache = None

@@ -209,6 +209,17 @@ int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream) {
   return has_error() ? 1 : 0;
 }
 
+int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, const float* bias, int relu, void* D, void* w8,
+                        float* scale, void* stream) {
+  clear_error();
+  if (!A || !W || !D || !w8 || !scale) { set_error("dgsct_test_gemm_fp8: NULL argument"); return 2; }
+  Ctx ctx{stream, DT_BF16};
+  fp8_quantize(ctx, W, (long)N * K, w8, scale, scale + 1);
+  gemm_fp8(ctx, M, N, K, A, K, w8, scale, bias, relu, D, N);
+  check_async("dgsct_test_gemm_fp8");
+  return has_error() ? 1 : 0;
+}
+
 int dgsct_prof_enable(int on) { gemm_prof_enable(on); return 0; }
 int dgsct_prof_collect(int64_t* launches, double* total_ms, double* total_flops) {
   long n = 0;

@@ -38,7 +38,8 @@ struct Arena {
 Plan::Plan(const dgsct_adapter_desc& d_, bool record_regions) : record_regions_(record_regions), d(d_) {
   B = d.BT; N = d.N; C = d.C; No = d.No; Co = d.Co; tk = d.tk; g = d.g;
   dd = C / 2; ds = d.r > 0 ? C / d.r : 0;
-  E = d.dtype; es = (int64_t)dt_size(E);
+  fp8 = d.dtype == DGSCT_BF16_FP8;
+  E = fp8 ? (int)DT_BF16 : d.dtype; es = (int64_t)dt_size(E);
   Np = (int)rup(N, 8); Nop = (int)rup(No, 8); tkp = (int)rup(tk, 8);
   R = (int64_t)B * N;
   {
@@ -57,7 +58,9 @@ bool Plan::validate() {
   if (C % 4 || C > 1536) return bad("C must be a multiple of 4 and <= 1536");
   if (dd % 4) return bad("C/2 must be a multiple of 4");
   if (tk > 32) return bad("tk must be <= 32 (the latent tokens of one frame are one 32-row MFMA tile)");
-  if (d.dtype == DT_BF16 && C % 8) return bad("C must be a multiple of 8 in bf16 mode (16-byte rows)");
+  if (d.dtype != DGSCT_F32 && d.dtype != DGSCT_BF16 && d.dtype != DGSCT_BF16_FP8) return bad("dtype");
+  if (fp8 && (C % 16 || Co % 16)) return bad("fp8 projections need C and Co to be multiples of 16");
+  if (E == DT_BF16 && C % 8) return bad("C must be a multiple of 8 in bf16 mode (16-byte rows)");
   if (N > 8192) return bad("N must be <= 8192");
   if (d.temporal && d.T > 0 && B % d.T) return bad("BT must be a multiple of T (temporal gate)");
   if (E != DT_F32 && E != DT_BF16) return bad("dtype");
@@ -87,6 +90,12 @@ void Plan::layout() {
     prep_rowb = a.take("rowb", (int64_t)N * 4);
     prep_colb = a.take("colb", (int64_t)C * 4);
     prep_colb2 = a.take("colb2", (int64_t)C * 4);
+    if (fp8) {
+      prep_w8[0] = a.take("wc8", (int64_t)C * Co);
+      prep_w8[1] = a.take("wv18", (int64_t)C * C);
+      prep_w8[2] = a.take("wv28", (int64_t)dd * C);
+      prep_w8scale = a.take("w8scale", 4 * 4);
+    }
     prep_t0pk = E == DT_BF16 ? a.take("t0pk", tok_pack_elems(1, C) * 2) : -1;      // my_tokens packed for attn2.hip
     prep_bytes = a.off;
   }
@@ -276,6 +285,12 @@ int Plan::prepare(float* const* params, void* prep, void* stream) const {
     zero(ctx, colb2, (size_t)C * 4);
   }
   if (prep_t0pk >= 0) tok_pack(ctx, params[DGSCT_P_TOKENS], 1, tk, C, p + prep_t0pk);
+  if (fp8) {
+    float* sc = (float*)(p + prep_w8scale);
+    fp8_quantize(ctx, params[DGSCT_P_WC], (long)C * Co, p + prep_w8[0], sc + 0, sc + 3);
+    fp8_quantize(ctx, params[DGSCT_P_WV1], (long)C * C, p + prep_w8[1], sc + 1, sc + 3);
+    fp8_quantize(ctx, params[DGSCT_P_WV2], (long)dd * C, p + prep_w8[2], sc + 2, sc + 3);
+  }
   check_async("dgsct_prepare");
   return has_error() ? 1 : 0;
 }
@@ -306,7 +321,12 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     g2.B = km(b.W(DGSCT_P_WC), Co);
     g2.r1_m = b.rowb(); g2.r1_n = b.colb(); g2.m_mod = N; g2.bias_n = b.colb2();
     outE(g2, Yp, E, C);
-    gemm(ctx, g2);
+    if (fp8) {
+      gemm_fp8(ctx, (int)R, C, Co, b.S(s.T), Co, b.prep + prep_w8[0], (const float*)(b.prep + prep_w8scale) + 0, b.colb2(), 0, Yp, C,
+               b.rowb(), b.colb(), N);
+    } else {
+      gemm(ctx, g2);
+    }
   } else {
     Gemm g1 = mk(C, No, Co, B);                                  // T2t[b] = Wc . Y[b]^T   [C][No]
     g1.A = km(b.W(DGSCT_P_WC), Co);
@@ -342,7 +362,8 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     Gemm g3 = mk((int)R, C, C);                                  // vq1 = relu(X1 Wv1^T + b)
     g3.A = km(b.S(s.X1), C); g3.B = km(b.W(DGSCT_P_WV1), C); g3.bias_n = b.F(DGSCT_P_BV1); g3.act = ACT_RELU;
     outE(g3, b.S(s.vq1), E, C);
-    gemm(ctx, g3);
+    if (fp8) gemm_fp8(ctx, (int)R, C, C, b.S(s.X1), C, b.prep + prep_w8[1], (const float*)(b.prep + prep_w8scale) + 1, b.F(DGSCT_P_BV1), 1, b.S(s.vq1), C);
+    else gemm(ctx, g3);
     colsum_batched(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C);
     stream_join(ctx);                                            // aq1 / aq2 / a from the aux stream
     ew(ctx, EW_MUL, b.S(s.m1), E, Earg(b.S(s.aq1), E), F32(b.S(s.mvq1)), NOARG, (long)B * C, 0.f, 1);
@@ -361,7 +382,8 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     Gemm g1 = mk((int)R, dd, C);                                 // vq2 = relu(Xc Wv2^T + b)
     g1.A = km(b.S(s.Xc), C); g1.B = km(b.W(DGSCT_P_WV2), C); g1.bias_n = b.F(DGSCT_P_BV2); g1.act = ACT_RELU;
     outE(g1, b.S(s.vq2), E, dd);
-    gemm(ctx, g1);
+    if (fp8) gemm_fp8(ctx, (int)R, dd, C, b.S(s.Xc), C, b.prep + prep_w8[2], (const float*)(b.prep + prep_w8scale) + 2, b.F(DGSCT_P_BV2), 1, b.S(s.vq2), dd);
+    else gemm(ctx, g1);
     rowdot_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.S(s.aq2), E, dd, b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
                    b.S<float>(s.sl));
     spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map), map);   // saved copy + the returned map

@@ -17,6 +17,8 @@ struct Plan {
   dgsct_adapter_desc d;
   int B, N, C, No, Co, tk, g, dd, ds, E, Np, Nop, tkp;
   int64_t es, R;
+  bool fp8 = false;   // DGSCT_BF16_FP8: fp8 operands for fc / fc_affine_video_1 / fc_affine_video_2 (forward)
+  int64_t prep_w8[3] = {-1, -1, -1}, prep_w8scale = -1;   // fp8 copies of Wc, Wv1, Wv2 + their 3 inverse scales (+ 1 scratch word)
   bool orderA;   // remap association: (Wn.Y).Wc^T (A) or Wn.(Y.Wc^T) (B), whichever is cheaper
 
   // prep

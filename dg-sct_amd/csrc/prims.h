@@ -160,6 +160,13 @@ void tail_bwd(const Ctx&, const void* dOut, const void* Op, const float* sc2, co
               const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums,
               float* part = nullptr, long part_floats = 0);
 
+// ---- fp8 (e4m3) MFMA projections (gemm_fp8.hip; dtype DGSCT_BF16_FP8) ------------------------------------------------------
+// out8[i] = fp8(w[i] * 448 / max|w|), *inv_scale = max|w| / 448;  amax_scratch: 4 bytes of device scratch
+void fp8_quantize(const Ctx&, const float* w, long n, void* out8, float* inv_scale, void* amax_scratch);
+// D (bf16 [M][ldd]) = act(*inv_scale * sum_k fp8(A[m][k]) W8[n][k] + bias[n] + r1_m[m % m_mod] * r1_n[n]);  A bf16 [M][lda], W8 fp8 [N][K]
+void gemm_fp8(const Ctx&, int M, int N, int K, const void* A, long lda, const void* W8, const float* inv_scale, const float* bias,
+              int relu, void* D, long ldd, const float* r1_m = nullptr, const float* r1_n = nullptr, int m_mod = 0);
+
 // ---- fused latent-token attention (attn.hip; reference net_trans.py:572-589 and its autograd) ------------------------
 // tok fp32 [B][tk][C] = T0 + softmax_N(T0 Yp^T) Yp;  lse fp32 [B][tk] = log sum_n exp(logit);  a fp32 [B][C] = mean_N Yp
 // (a must be pre-zeroed; aE: optional copy of a in E);  scratch: tokattn_scratch_floats(B, N, C) floats.  tk <= 32.

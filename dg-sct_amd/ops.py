@@ -38,6 +38,7 @@ class AdapterSpec:
     T: int = 10
     eps: float = 1e-5
     bn_momentum: float = 0.1
+    fp8: bool = False            # bf16 + fp8 (e4m3) MFMA operands for fc / fc_affine_video_1 / fc_affine_video_2 (BASELINE configs[4])
 
     def desc(self, BT: int, dtype: torch.dtype, training: bool) -> AdapterDesc:
         key = (self, BT, dtype, bool(training))
@@ -50,7 +51,7 @@ class AdapterSpec:
     def _make_desc(self, BT: int, dtype: torch.dtype, training: bool) -> AdapterDesc:
         d = AdapterDesc()
         d.BT, d.T, d.N, d.C, d.No, d.Co, d.tk, d.r, d.g = BT, self.T, self.N, self.C, self.No, self.Co, self.tk, self.r, self.g
-        d.dtype = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+        d.dtype = (_lib.BF16_FP8 if self.fp8 else _lib.BF16) if dtype == torch.bfloat16 else _lib.F32
         d.remap = _lib.REMAP_CONV if self.remap == "conv" else _lib.REMAP_FIXED
         d.use_bn, d.use_gate, d.ln_before, d.ln_post = int(self.use_bn), int(self.use_gate), int(self.ln_before), int(self.ln_post)
         d.gate_before_ln_post, d.temporal, d.training = int(self.gate_before_ln_post), int(self.temporal), int(training)

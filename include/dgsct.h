@@ -31,7 +31,10 @@ extern "C" {
 #endif
 
 #define DGSCT_VERSION 100
-enum { DGSCT_F32 = 0, DGSCT_BF16 = 1 };
+enum { DGSCT_F32 = 0, DGSCT_BF16 = 1,
+       DGSCT_BF16_FP8 = 2 };  /* bf16 storage / MFMA everywhere, plus fp8 (OCP e4m3) MFMA operands for the three big weight-stationary
+                                 forward projections fc, fc_affine_video_1, fc_affine_video_2 (BASELINE.json configs[4]); buffers are
+                                 laid out exactly as for DGSCT_BF16, tensors handed in and out are bf16 */
 enum { DGSCT_REMAP_CONV = 0,    /* conv_adapter (token axis) + fc           net_trans.py:553-554        */
        DGSCT_REMAP_FIXED = 1 }; /* fc + fixed token operator (AVS-S4 bicubic resize, PVT_AVSModel.py:190-197);
                                    params[DGSCT_P_WN] is then the dense [N][No] operator, it gets no gradient */
@@ -77,7 +80,7 @@ typedef struct dgsct_adapter_desc {
   int32_t No, Co;    /* other modality: tokens, width (conv_dim_in, linear_in)                    */
   int32_t tk;        /* latent tokens (num_tk / opt.num_tokens)                                   */
   int32_t r, g;      /* reduction_factor (opt.Adapter_downsample), opt.num_conv_group             */
-  int32_t dtype;     /* DGSCT_F32 | DGSCT_BF16: activation storage + MFMA operand type            */
+  int32_t dtype;     /* DGSCT_F32 | DGSCT_BF16 | DGSCT_BF16_FP8: activation storage + MFMA operand type */
   int32_t remap;     /* DGSCT_REMAP_*                                                             */
   int32_t use_bn, use_gate, ln_before, ln_post;
   int32_t gate_before_ln_post;   /* AVS-S4/MS3 order (PVT_AVSModel.py:308-313)                    */
@@ -219,6 +222,12 @@ typedef struct dgsct_attn_args {
 } dgsct_attn_args;
 int64_t dgsct_test_attn_scratch_floats(int B, int N, int C, int tk);
 int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream);
+
+/* The fp8 projection kernel on its own (csrc/gemm_fp8.hip), for unit tests: quantises W (fp32 [N][K]) per tensor into
+ * `w8` (N*K bytes) / `scale` (>= 2 floats of scratch) exactly like dgsct_prepare does, then
+ * D (bf16 [M][N]) = act(A (bf16 [M][K]) . W^T + bias).  K a multiple of 16, N a multiple of 8. */
+int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, const float* bias, int relu, void* D, void* w8,
+                        float* scale, void* stream);
 
 /* ---- measurement hook (bench.py roofline leg) ---------------------------------------------------
  * While enabled, every launch of the MFMA GEMM family issued from the calling thread is bracketed by

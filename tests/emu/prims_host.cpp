@@ -648,4 +648,50 @@ void temporal_gate_bwd(const Ctx&, int R, int D, float gamma, const float* akv, 
   for (int c = 0; c < D; ++c) { dwa[c] = (float)A[c]; dwv[c] = (float)V[c]; }
   *dba = (float)sa; *dbv = (float)sv;
 }
+// ---- fp8 e4m3 (OCP "fn": bias 7, max 448, no infinities) host model of v_cvt_pk_fp8_f32 + the fp8 projections -------------
+static inline float e4m3_round(float x) {
+  if (!(x == x)) return x;
+  float a = std::fabs(x);
+  if (a > 448.f) a = 448.f;
+  if (a == 0.f) return x;
+  int e; std::frexp(a, &e); e -= 1;                 // a = m * 2^e, m in [1, 2)
+  if (e < -6) e = -6;                                // subnormal range shares the exponent of the smallest normal
+  const float step = std::ldexp(1.f, e - 3);
+  float q = std::nearbyint(a / step) * step;         // round-to-nearest-even (default rounding mode)
+  if (q > 448.f) q = 448.f;
+  return x < 0 ? -q : q;
+}
+static inline unsigned char e4m3_encode(float q) {   // q already representable
+  unsigned char s = q < 0 ? 0x80 : 0;
+  float a = std::fabs(q);
+  if (a == 0.f) return s;
+  int e; float m = std::frexp(a, &e); e -= 1; m *= 2.f;        // m in [1,2)
+  if (e < -6) { return s | (unsigned char)std::nearbyint(a / std::ldexp(1.f, -9)); }
+  return s | (unsigned char)(((e + 7) << 3) | (int)std::nearbyint((m - 1.f) * 8.f));
+}
+static inline float e4m3_decode(unsigned char b) {
+  const int e = (b >> 3) & 15, m = b & 7;
+  const float v = e == 0 ? std::ldexp((float)m, -9) : std::ldexp(1.f + m / 8.f, e - 7);
+  return (b & 0x80) ? -v : v;
+}
+void fp8_quantize(const Ctx&, const float* w, long n, void* out8, float* inv_scale, void*) {
+  float amax = 0.f;
+  for (long i = 0; i < n; ++i) amax = std::max(amax, std::fabs(w[i]));
+  const float scale = amax > 0.f ? 448.f / amax : 1.f;
+  *inv_scale = 1.f / scale;
+  for (long i = 0; i < n; ++i) ((unsigned char*)out8)[i] = e4m3_encode(e4m3_round(w[i] * scale));
+}
+void gemm_fp8(const Ctx&, int M, int N, int K, const void* A, long lda, const void* W8, const float* inv_scale, const float* bias,
+              int relu, void* D, long ldd, const float* r1_m, const float* r1_n, int m_mod) {
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      double acc = 0;
+      for (int k = 0; k < K; ++k)
+        acc += (double)e4m3_round(ld(A, DT_BF16, (long)m * lda + k)) * e4m3_decode(((const unsigned char*)W8)[(long)n * K + k]);
+      float v = *inv_scale * (float)acc + (bias ? bias[n] : 0.f);
+      if (r1_m) v += r1_m[m % (m_mod > 0 ? m_mod : 1)] * r1_n[n];
+      if (relu) v = std::max(v, 0.f);
+      st(D, DT_BF16, (long)m * ldd + n, v);
+    }
+}
 }  // namespace dgsct
