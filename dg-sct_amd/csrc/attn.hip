@@ -531,9 +531,17 @@ void xattn_bwd2(const Ctx& ctx, const void* X, const void* dX1, const void* tokp
 void tokattn_bwd2(const Ctx& ctx, const void* Yp, const void* T0pk, const void* dtokpk, const float* lse, const float* D,
                   const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b);
 
+bool tokattn_fwd_small_ok(const Ctx& ctx, int N, int C);
+void tokattn_fwd_small(const Ctx& ctx, const void* Yp, const float* T0, const void* T0pk, int B, int N, int C, int tk, float* tok,
+                       void* tokpk, float* lse, float* a, void* aE);
+
 void tokattn_fwd(const Ctx& ctx, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
-                 void* aE, float* scratch, void* tokpk) {
+                 void* aE, float* scratch, void* tokpk, const void* T0pk) {
   if (!attn_shape_ok(ctx, N, C, tk)) return;
+  if (tokpk && T0pk && aE && tokattn_fwd_small_ok(ctx, N, C)) {       // short frames: one workgroup per frame, final results
+    tokattn_fwd_small(ctx, Yp, T0, T0pk, B, N, C, tk, tok, tokpk, lse, a, aE);
+    return;
+  }
   const int nch = (N + NCH_ROWS - 1) / NCH_ROWS;
   TokFwdArgs p{Yp, T0, N, C, tk, nch, scratch, scratch + (long)B * nch * 32 * C, a};
   hipStream_t s = (hipStream_t)ctx.stream;

@@ -538,4 +538,171 @@ void tokattn_bwd2(const Ctx& ctx, const void* Yp, const void* T0pk, const void* 
   hipLaunchKernelGGL(tokattn_bwd2_k, dim3(B * wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
 }
 
+
+// ====================================================================================================================
+// tokattn_fwd for short frames (N <= 256: the stage-2/3 shapes, 32 of the 48 adapter calls of the AVE stack): ONE workgroup
+// per frame produces the final tok (fp32 + packed bf16 images), lse, a and aE -- no partial results, no combine launch, no
+// pack launch.  Phase A: the 4 waves split the frame's 32-row tiles and compute logits^T[n][t] = Yp[n] . T0[t] (Yp rows
+// from the private image as the A operand, packed my_tokens from global as B), so the softmax axis n runs along the
+// accumulator registers; the probabilities go to ONE shared LDS image [n][t].  Phase B: the waves split the 128-channel
+// slabs instead and walk ALL row tiles: O[t][c] = sum_n P[n][t] Yp[n][c] with both operands transpose-read.
+// ====================================================================================================================
+struct TFS2Args {
+  const unsigned short* Yp; const float* T0; const unsigned short* T0pk; int N, C, tk; float invN;
+  float* tok; unsigned short* tokpk; float* lse; float* a; unsigned short* aE;
+};
+__global__ __launch_bounds__(256) void tokattn_fwd_small_k(const TFS2Args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * IMG2 + 256 * PP2];
+  __shared__ float red[2][4][32];
+  __shared__ float sl[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const long C = p.C;
+  char* img = smem + wave * IMG2;
+  char* sP = smem + 4 * IMG2;
+  const unsigned short* Yb = p.Yp + (long)b * p.N * C;
+  const unsigned short* thF = p.T0pk;
+  const unsigned short* tlF = thF + 32 * C;
+  const int nrt = (p.N + 31) / 32, nsl = (p.C + CS2 - 1) / CS2;
+  const int t = lane & 31;
+  // ---- phase A
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rt = wave + 4 * i;
+    if (rt >= nrt) break;
+    const int rows = p.N - rt * 32 < 32 ? p.N - rt * 32 : 32;
+    const unsigned short* Yg = Yb + (long)rt * 32 * C;
+    Slab s;
+    slab_load(s, Yg, C, rows, 0, p.C, lane);
+    for (int si = 0; si < nsl; ++si) {
+      const int c0 = si * CS2, kc = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 16;
+      wave_sync();
+      slab_store_lds(s, img, rows, c0, p.C, lane);
+      wave_sync();
+      if (si + 1 < nsl) slab_load(s, Yg, C, rows, c0 + CS2, p.C, lane);
+      const unsigned short* bh = thF + ((long)(c0 >> 4) * 64 + lane) * 8;
+      const unsigned short* bl = tlF + ((long)(c0 >> 4) * 64 + lane) * 8;
+      const char* ap = img + (lane & 31) * PX2 + (lane >> 5) * 16;
+#pragma unroll
+      for (int g = 0; g < CS2 / 64; ++g) {
+        if (g * 4 >= kc) break;
+        bfx8 fh[4], fl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int kk = g * 4 + q < kc ? g * 4 + q : 0; fh[q] = ldg8(bh + kk * 512); fl[q] = ldg8(bl + kk * 512); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (g * 4 + q < kc) {
+            const bfx8 af = lds8(ap + (g * 4 + q) * 32);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, fh[q], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, fl[q], acc[i], 0, 0, 0);
+          }
+      }
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((wave + 4 * i) * 32 + mt_row(r, lane) < p.N) mx = fmaxf(mx, acc[i][r]);
+  mx = fmaxf(mx, xor32b(mx));
+  if (lane < 32) red[0][wave][t] = mx;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(red[0][0][t], red[0][1][t]), fmaxf(red[0][2][t], red[0][3][t]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rt = wave + 4 * i;
+    if (rt >= nrt) break;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = rt * 32 + mt_row(r, lane);
+      const float pv = n < p.N ? __expf(acc[i][r] - m) : 0.f;
+      sum += pv;
+      *reinterpret_cast<unsigned short*>(sP + n * PP2 + t * 2) = f2bf(pv);
+    }
+  }
+  sum += xor32b(sum);
+  if (lane < 32) red[1][wave][t] = sum;
+  __syncthreads();
+  if (wave == 0 && lane < 32) {
+    const float l = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
+    sl[t] = 1.f / l;
+    if (t < p.tk) p.lse[(long)b * p.tk + t] = m + __logf(l);
+  }
+  __syncthreads();
+  // ---- phase B: wave -> slabs wave, wave + 4, ...
+  unsigned short* hiF = p.tokpk + (long)b * 96 * C;
+  unsigned short* loF = hiF + 32 * C;
+  unsigned short* TFo = loF + 32 * C;
+  for (int si = wave; si < nsl; si += 4) {
+    const int c0 = si * CS2, nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
+    f32x16 o[CS2 / 32];
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+    float cs0 = 0.f, cs1 = 0.f;                                   // column sums of channels c0 + 2 lane, + 1
+    Slab s;
+    slab_load(s, Yb, C, p.N < 32 ? p.N : 32, c0, p.C, lane);
+    for (int rt = 0; rt < nrt; ++rt) {
+      const int rows = p.N - rt * 32 < 32 ? p.N - rt * 32 : 32;
+      wave_sync();
+      slab_store_lds(s, img, rows, c0, p.C, lane);
+      wave_sync();
+      if (rt + 1 < nrt) slab_load(s, Yb + (long)(rt + 1) * 32 * C, C, p.N - (rt + 1) * 32 < 32 ? p.N - (rt + 1) * 32 : 32, c0, p.C, lane);
+      const mt_bf16x8 a0 = mt_frag_mn(sP + rt * 32 * PP2, PP2, 0, 0, lane), a1 = mt_frag_mn(sP + rt * 32 * PP2, PP2, 0, 1, lane);
+#pragma unroll
+      for (int j = 0; j < CS2 / 32; ++j) {
+        if (j >= nt) break;
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, mt_frag_mn(img, PX2, 32 * j, 0, lane), o[j], 0, 0, 0);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, mt_frag_mn(img, PX2, 32 * j, 1, lane), o[j], 0, 0, 0);
+      }
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(img + r * PX2 + lane * 4);
+        cs0 += __uint_as_float(w << 16); cs1 += __uint_as_float(w & 0xffff0000u);
+      }
+    }
+    if (c0 + 2 * lane < p.C) {
+      const float a0v = cs0 * p.invN, a1v = cs1 * p.invN;
+      *reinterpret_cast<float2*>(p.a + (long)b * C + c0 + 2 * lane) = make_float2(a0v, a1v);
+      *reinterpret_cast<unsigned*>(p.aE + (long)b * C + c0 + 2 * lane) = pack2(a0v, a1v);
+    }
+    // epilogue: tok = T0 + O / l; fp32 rows + the three packed bf16 images
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {
+      if (j >= nt) break;
+      const int c = c0 + 32 * j + (lane & 31);
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tt = mt_row(r, lane);
+        v[r] = tt < p.tk ? p.T0[(long)tt * C + c] + o[j][r] * sl[tt] : 0.f;
+        if (tt < p.tk) p.tok[((long)b * p.tk + tt) * C + c] = v[r];
+        const unsigned short h = f2bf(v[r]);
+        const long fo = (((long)(c >> 4) * 2 + ((c >> 3) & 1)) * 32 + tt) * 8 + (c & 7);     // hiF / loF element of tok[tt][c]
+        hiF[fo] = h;
+        loF[fo] = f2bf(v[r] - bf2f(h));
+      }
+      // TF pieces (tile j of this slab, kk = 0 / 1, lane): the lane's registers [8 kk, 8 kk + 8) ARE the piece
+      unsigned short* tf = TFo + (((long)((c0 >> 5) + j) * 2) * 64 + lane) * 8;
+      *reinterpret_cast<uint4*>(tf) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+      *reinterpret_cast<uint4*>(tf + 512) = make_uint4(pack2(v[8], v[9]), pack2(v[10], v[11]), pack2(v[12], v[13]), pack2(v[14], v[15]));
+    }
+  }
+}
+bool tokattn_fwd_small_ok(const Ctx& ctx, int N, int C) { return attn2_ok(ctx, C) && N <= 256; }
+void tokattn_fwd_small(const Ctx& ctx, const void* Yp, const float* T0, const void* T0pk, int B, int N, int C, int tk, float* tok,
+                       void* tokpk, float* lse, float* a, void* aE) {
+  TFS2Args q{(const unsigned short*)Yp, T0, (const unsigned short*)T0pk, N, C, tk, 1.f / (float)N, tok, (unsigned short*)tokpk, lse, a,
+             (unsigned short*)aE};
+  hipLaunchKernelGGL(tokattn_fwd_small_k, dim3(B), dim3(256), 0, (hipStream_t)ctx.stream, q);
+}
+
 }  // namespace dgsct

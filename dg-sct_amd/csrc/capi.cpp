@@ -197,7 +197,7 @@ int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream) {
   if (!a) return 2;
   Ctx ctx{stream, a->mode};
   switch (op) {
-    case 0: tokattn_fwd(ctx, a->Yp, a->T0, a->B, a->N, a->C, a->tk, a->tok, a->lse, a->a, a->aE, a->scratch, a->tokpk); break;
+    case 0: tokattn_fwd(ctx, a->Yp, a->T0, a->B, a->N, a->C, a->tk, a->tok, a->lse, a->a, a->aE, a->scratch, a->tokpk, a->T0pk); break;
     case 1: xattn_fwd(ctx, a->X, a->tok, a->gate_av, a->B, a->N, a->C, a->tk, a->out, a->tokpk); break;
     case 2: xattn_bwd(ctx, a->X, a->dX1, a->tok, a->gate_av, a->B, a->N, a->C, a->tk, a->out, a->R2, a->dtok, a->dgate, a->tokpk); break;
     case 3: tokattn_bwd(ctx, a->Yp, a->T0, a->tok, a->lse, a->dtok, a->da, a->invN, a->B, a->N, a->C, a->tk, a->out, a->dT0b,

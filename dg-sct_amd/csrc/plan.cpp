@@ -343,7 +343,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   // F2 ---- latent tokens attend to the remapped tokens (one pass over Yp)   :572-580, :592
   void* tokpk = s.tokpk >= 0 ? b.S(s.tokpk) : nullptr;
   tokattn_fwd(ctx, Yp, b.F(DGSCT_P_TOKENS), B, N, C, tk, b.S<float>(s.tok), b.S<float>(s.lse), b.S<float>(s.a), b.S(s.aE),
-              b.Wk<float>(wf.tokscr), tokpk);
+              b.Wk<float>(wf.tokscr), tokpk, prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr);
   {
     stream_fork(ctx);                                            // a = mean_N(Yp) is complete on the main stream
     Gemm g1 = mk(B, C, C);                                       // aq1 = relu(a Wa1^T + b)

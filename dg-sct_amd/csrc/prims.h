@@ -178,7 +178,7 @@ long tok_pack_elems(int nb, int C);
 void tok_pack(const Ctx&, const float* src, int nb, int tk, int C, void* pk, const float* other = nullptr, const float* base = nullptr,
               float* D = nullptr);       // D[b][t] = sum_c src * (other - base)   (optional)
 void tokattn_fwd(const Ctx&, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
-                 void* aE, float* scratch, void* tokpk = nullptr);
+                 void* aE, float* scratch, void* tokpk = nullptr, const void* T0pk = nullptr);
 // X1 (E) = X + gate_av * softmax_tk(X tok^T) tok
 void xattn_fwd(const Ctx&, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1,
                const void* tokpk = nullptr);

@@ -489,7 +489,7 @@ long tokattn_scratch_floats(int, int, int) { return 64; }
 long tok_pack_elems(int nb, int C) { return (long)nb * 96 * C; }
 void tok_pack(const Ctx&, const float*, int, int, int, void*, const float*, const float*, float*) {}
 void tokattn_fwd(const Ctx& ctx, const void* Yp, const float* T0, int B, int N, int C, int tk, float* tok, float* lse, float* a,
-                 void* aE, float*, void*) {
+                 void* aE, float*, void*, const void*) {
   const int E = ctx.mode;
   std::vector<double> S(N);
   for (int b = 0; b < B; ++b) {

@@ -18,7 +18,7 @@ dtype = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torc
 es = 2 if dtype == torch.bfloat16 else 4
 dev = torch.device("cuda:0")
 lib = default_lib()
-names = ["tokattn_fwd", "xattn_fwd", "xattn_bwd", "tokattn_bwd"]
+names = ["tokattn_fwd(+combine,pack)", "xattn_fwd", "xattn_bwd", "tokattn_bwd(+pack)"]
 units = [1, 2, 3, 2]            # algorithmic passes over a [B][N][C] activation: read Yp | X->X1 | X,dX1->dX | Yp->dYp
 tot = [0.0] * 4
 print(f"{'N':>5} {'C':>5} " + " ".join(f"{n:>22}" for n in names))
