@@ -136,9 +136,19 @@ def cpu_baseline(backbone, max_seconds=30.0):
     if not times:
         times = [t_warm]
     t = sorted(times)[len(times) // 2]
-    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port", cpu_model=model,
+                logical_cpus=ncpu,
                 sample=f"1 clip (BT=10) x 48 adapters fwd+bwd, fp32, oracle.forward_autograd (ATen op-for-op port of the "
-                       f"reference adapter), median of {len(times)} passes after 1 warm-up; {t:.2f} s/pass")
+                       f"reference adapter on token-major maps: at least as fast as the reference's permuted-view path), "
+                       f"thread count picked by a sweep, median of {len(times)} passes after 1 warm-up; {t:.2f} s/pass")
 
 
 def main():
@@ -358,20 +368,33 @@ def main():
             reducer.paused = False
         alg = 3.0 * alg_flops_per_frame(stages) * BT                 # fwd + bwd, per step
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        achieved = alg * nprof / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # the GEMM family's own useful FLOPs (2 M N K per launch, summed by the library) over its own time: the latent-token
+        # attention products (8 tk C N per frame of the algorithmic count) now run in the fused attention kernels, not here
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.backbone == "swinv2_base" and args.batch == 16 and args.dtype == "bf16":
-            # bytes per GEMM launch through the L2's memory-side port (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc passes of
-            # tools/pmc_stack.sh over the 8 adapter shapes of this exact workload, scaled by the schedule)
-            traffic = round(json.load(open(tpath))["gemm_kernel<*>"]["bytes_per_launch"])
+        step_block = dict(frac_of_mfma_peak=round(alg / (ms_per_step * 1e-3) / 1e12 / peak, 4), alg_gb_per_step=round(alg_bytes_per_step(stages, BT) / 1e9, 2))
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        tsrc = None
+        if tfiles and args.backbone == "swinv2_base" and args.batch == 16 and args.dtype == "bf16":
+            # bytes through the L2's memory-side port (FETCH_SIZE x2 + WRITE_SIZE; separate rocprofv3 --pmc passes over the 8
+            # adapter shapes of this exact workload, scaled by the schedule: tools/pmc_stack.sh + pmc_stack_summary.py)
+            tj = json.load(open(tfiles[-1]))
+            tsrc = os.path.relpath(tfiles[-1], ROOT)
+            traffic = round(tj["gemm_kernel<*>"]["bytes_per_launch"])
+            if "_total" in tj:
+                tb = tj["_total"]["bytes"]
+                step_block.update(pmc_gb_per_step=round(tb / 1e9, 1), pmc_over_alg=round(tb / alg_bytes_per_step(stages, BT), 2),
+                                  hbm_side_gbps=round(tb / 1e9 / (ms_per_step * 1e-3)), frac_of_hbm_peak=round(tb / (ms_per_step * 1e-3) / 8e12, 3))
+                # which roof is closer: the step as a whole is limited by memory-side traffic of its multi-pass schedule
+                step_block["bound_by_data"] = "hbm" if step_block["frac_of_hbm_peak"] > step_block["frac_of_mfma_peak"] else "mfma"
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                        traffic=traffic, traffic_unit="bytes/launch (PMC, profiles/r01_pmc_traffic.json)",
+                        traffic=traffic, traffic_unit=f"bytes/launch (PMC, {tsrc})" if tsrc else None,
                         alg_bytes_per_launch=round(alg_bytes_per_step(stages, BT) / max(launches // nprof, 1)), kernel="dgsct::gemm_kernel<*> (all MFMA GEMM launches of a step)",
                         launches_per_step=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
                         gemm_ms_per_step=round(gemm_ms / nprof, 3), heaviest_launch=heaviest,
-                        step_frac_of_mfma_peak=round(alg / (ms_per_step * 1e-3) / 1e12 / peak, 4))
+                        step_frac_of_mfma_peak=step_block["frac_of_mfma_peak"], step=step_block)
     if dp:
         barrier()
 
