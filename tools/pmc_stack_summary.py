@@ -39,6 +39,8 @@ for shp, cnt in COUNT.items():
     try:
         for name, cn, val, dur in rows_of(shp, "SQ"):
             sq[fam(name)][cn] += val * cnt / 2
+            if cn == "SQ_WAVE_CYCLES":
+                sq[fam(name)]["_ns"] += dur * cnt / 2
     except Exception as e:
         print("no SQ pass for", shp, e)
 lines = [f"{'launches/step':>13} {'fetch_GB(x2)':>13} {'write_GB':>9} {'MB/launch':>10} {'ms(serial)':>11}  family   (one bench step, B=16, Swin-V2-B shapes, 48 adapter calls)"]
@@ -61,13 +63,14 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
 if sq:
-    l2 = [f"{'family':28s} {'MFMA busy %':>12} {'LDS conflict %':>15} {'issue stall %':>14}   (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / 4 SIMDs; "
-          "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES) -- per-shape passes scaled to one step"]
-    for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[:14]:
-        busy = v.get("SQ_BUSY_CYCLES", 0) or 1
-        mf = 100 * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / busy / 4
+    l2 = [f"{'family':28s} {'ms/step':>8} {'MFMA busy %':>12} {'LDS conflict %':>15} {'issue stall %':>14}   MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+          "(kernel time x 2.4 GHz x 1024 SIMDs) (a lower bound: the chip clocks below 2.4 GHz under load); LDS conflict = SQ_LDS_BANK_CONFLICT / "
+          "SQ_LDS_IDX_ACTIVE; issue stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.  Per-shape passes scaled to one step."]
+    for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("_ns", 0))[:16]:
+        ns = v.get("_ns", 0) or 1
+        mf = 100 * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (ns * 2.4 * 1024)
         lc = 100 * v.get("SQ_LDS_BANK_CONFLICT", 0) / (v.get("SQ_LDS_IDX_ACTIVE", 0) or 1)
         st = 100 * v.get("SQ_WAIT_INST_ANY", 0) / (v.get("SQ_WAVE_CYCLES", 0) or 1)
-        l2.append(f"{k:28s} {mf:12.1f} {lc:15.1f} {st:14.1f}")
+        l2.append(f"{k:28s} {ns/1e6:8.2f} {mf:12.1f} {lc:15.1f} {st:14.1f}")
     print("\n".join(l2))
     open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.txt"), "w").write("\n".join(l2) + "\n")
