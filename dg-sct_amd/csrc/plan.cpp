@@ -483,7 +483,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
            d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
            d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, b.S<float>(s.mu_p), b.S<float>(s.rstd_p), R, C,
            dO, G(DGSCT_P_LNP_W), G(DGSCT_P_LNP_B), G(DGSCT_P_GATE), d.use_bn ? G(DGSCT_P_BN2_B) : nullptr,
-           b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+           d.eps, b.Wk<float>(wb.rowpart), row_part_floats(B, C));
   // B10 ---- BN2 backward, up projection
   if (d.use_bn) {
     bn_bwd_apply(ctx, dO, b.S(s.Op), dO, R, C, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C, G(DGSCT_P_BN2_B), 0, 1, d.training);
@@ -544,7 +544,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                 b.Wk<float>(wb.dsl), G(DGSCT_P_BS));
     colsum_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd);  // u
     ew(ctx, EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1);
-    defer([=, &side, &b] { sum_batch(side, b.Wk<float>(wb.tmpBd), dd, B, dd, G(DGSCT_P_WS), 1.f, 1); });   // dws
+    // (d ws = sum_b tmpBd: with the bias gradients below, colsum_multi)
     ew(ctx, EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd);
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
     relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
@@ -569,10 +569,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g1 = mk(C, dd, B);                                      // dWcatt = dpre^T . q
     g1.A = mn(b.Wk(wb.dpre_c), C); g1.B = mn(b.S(s.q), dd);
     outF(g1, G(DGSCT_P_WCATT), dd);
-    defer([=, &side, &b] {
-      gemm(side, g1);
-      colsum_batched(side, b.Wk(wb.dpre_c), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BCATT), 0);
-    });
+    defer([=, &side] { gemm(side, g1); });
     Gemm g2 = mk(B, dd, C);                                      // dq = (dpre . Wcatt) * (q > 0)
     g2.A = km(b.Wk(wb.dpre_c), C); g2.B = mn(b.W(DGSCT_P_WCATT), dd);
     g2.mask = b.S(s.q); g2.ldmask = dd;
@@ -581,10 +578,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g3 = mk(dd, C, B);                                      // dWb = dq^T . m1
     g3.A = mn(b.Wk(wb.dq), dd); g3.B = mn(b.S(s.m1), C);
     outF(g3, G(DGSCT_P_WB), C);
-    defer([=, &side, &b] {
-      gemm(side, g3);
-      colsum_batched(side, b.Wk(wb.dq), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BB), 0);
-    });
+    defer([=, &side] { gemm(side, g3); });
     Gemm g4 = mk(B, C, dd);                                      // dm1 = dq . Wb
     g4.A = km(b.Wk(wb.dq), dd); g4.B = mn(b.W(DGSCT_P_WB), C);
     outF(g4, b.Wk<float>(wb.dm1), C);
@@ -612,16 +606,17 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g1 = mk(C, C, B);                                       // dWa1 = dpa1^T . a
     g1.A = mn(b.Wk(wb.dpa1), C); g1.B = mn(b.S(s.aE), C);
     outF(g1, G(DGSCT_P_WA1), C);
-    defer([=, &side, &b] {
-      gemm(side, g1);
-      colsum_batched(side, b.Wk(wb.dpa1), C, 0, 1, B, C, nullptr, 0, 1.f, G(DGSCT_P_BA1), 0);
-    });
+    defer([=, &side] { gemm(side, g1); });
     Gemm g2 = mk(dd, C, B);                                      // dWa2 = dpa2^T . a
     g2.A = mn(b.Wk(wb.dpa2), dd); g2.B = mn(b.S(s.aE), C);
     outF(g2, G(DGSCT_P_WA2), C);
     defer([=, &side, &b] {
       gemm(side, g2);
-      colsum_batched(side, b.Wk(wb.dpa2), dd, 0, 1, B, dd, nullptr, 0, 1.f, G(DGSCT_P_BA2), 0);
+      // the four bias gradients of the gate MLPs + d fc_affine_v_s_att.weight: column sums of [BT][C] matrices, one launch
+      const ColsumSeg segs[5] = {{b.Wk(wb.dpre_c), E, B, C, G(DGSCT_P_BCATT)}, {b.Wk(wb.dq), E, B, dd, G(DGSCT_P_BB)},
+                                 {b.Wk(wb.dpa1), E, B, C, G(DGSCT_P_BA1)}, {b.Wk(wb.dpa2), E, B, dd, G(DGSCT_P_BA2)},
+                                 {b.Wk(wb.tmpBd), DT_F32, B, dd, G(DGSCT_P_WS)}};
+      colsum_multi(side, segs, 5);
     });
     side_flush();                                                // dWcatt, dWb, dWv1, dWa1, dWa2 and their biases
     Gemm g3 = mk(B, C, C);                                       // da = dpa1 . Wa1 + dpa2 . Wa2
@@ -651,8 +646,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       // d fc.bias = sum_{b,n} dYp[b,n,:].  Softmax rows sum to 1 and dS1 rows sum to 0, so this equals
       // sum_b (sum_t dtok[b,t,:] + da[b,:]) exactly -- computed from these two small fp32 tensors instead of
       // re-reducing the big bf16-rounded dYp (a cancellation-heavy sum: 30 % relative error in bf16 otherwise).
-      sum_batch(ctx, b.Wk<float>(wb.dtokF), C, B * tk, C, G(DGSCT_P_BC), 1.f, 1);
-      sum_batch(ctx, b.Wk<float>(wb.da), C, B, C, G(DGSCT_P_BC), 1.f, 1);
+      const ColsumSeg segs[2] = {{b.Wk(wb.dtokF), DT_F32, B * tk, C, G(DGSCT_P_BC)}, {b.Wk(wb.da), DT_F32, B, C, G(DGSCT_P_BC)}};
+      colsum_multi(ctx, segs, 2);
     }
   }
   // B2 ---- tokens <- remapped tokens attention: dYp and d my_tokens in one pass over Yp (P1 recomputed from lse)
@@ -662,8 +657,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                 b.Wk<float>(wb.da), invN, B, N, C, tk, dYp, b.Wk<float>(wb.dT0b), b.Wk<float>(wb.Dtok),
                 prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr, wb.dtokpk >= 0 ? b.Wk(wb.dtokpk) : nullptr);
     defer([=, &side, &b] {                                       // d my_tokens = sum_b (dtok + dS1 . Yp)
-      sum_batch(side, b.Wk<float>(wb.dtokF), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
-      sum_batch(side, b.Wk<float>(wb.dT0b), (long)tk * C, B, (long)tk * C, G(DGSCT_P_TOKENS), 1.f, 1);
+      const ColsumSeg segs[2] = {{b.Wk(wb.dtokF), DT_F32, B, tk * C, G(DGSCT_P_TOKENS)}, {b.Wk(wb.dT0b), DT_F32, B, tk * C, G(DGSCT_P_TOKENS)}};
+      colsum_multi(side, segs, 2);
     });
   }
   // B1 ---- remap

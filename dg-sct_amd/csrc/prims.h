@@ -158,7 +158,7 @@ void tail_fwd(const Ctx&, const void* Op, const float* sc2, const float* sh2, co
 void tail_bwd(const Ctx&, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
               const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums,
-              float* part = nullptr, long part_floats = 0);
+              float eps, float* part = nullptr, long part_floats = 0);
 
 // ---- fp8 (e4m3) MFMA projections (gemm_fp8.hip; dtype DGSCT_BF16_FP8) ------------------------------------------------------
 // out8[i] = fp8(w[i] * 448 / max|w|), *inv_scale = max|w| / 448;  amax_scratch: 4 bytes of device scratch
@@ -223,6 +223,12 @@ void cvt(const Ctx&, const float* in, void* out, int odt, long n);
 constexpr int CVT_MAX_SEG = 16;
 struct CvtSeg { const float* src; void* dst; long n; int odt; };
 void cvt_multi(const Ctx&, const CvtSeg* segs, int nseg);
+// Up to COLSUM_MAX_SEG independent small column sums in ONE launch: out[c] += sum_{r < rows} x[r][c] (x: rows x C, dtype dt, leading
+// dimension C).  For the per-frame-vector gradients ([BT][C] matrices: bias gradients of the gate MLPs): five single-workgroup
+// launches of 10-30 us each per adapter call otherwise.
+constexpr int COLSUM_MAX_SEG = 8;
+struct ColsumSeg { const void* x; int dt; int rows; int C; float* out; };
+void colsum_multi(const Ctx&, const ColsumSeg* segs, int nseg);
 // out[r] = sum_c W[r][c]  (fp32 [R][C] -> fp32 [R])
 void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out);
 

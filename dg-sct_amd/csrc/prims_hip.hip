@@ -507,13 +507,18 @@ __device__ __forceinline__ void tail_bwd_body(const void* dOut, const void* Op, 
                                               const float* mean2, const float* rstd2, const float* lnw_,
                                               const float* lnb, const float* gate_, int gate_first_, const float* mu,
                                               const float* rstd, long rows, int C, int gs, int nv, int rpc, void* dO,
-                                              float* dlnw, float* dlnb, float* dgate, float* bnsums, float* part) {
+                                              float* dlnw, float* dlnb, float* dgate, float* bnsums, float* part, float eps) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bool sc2 = AVE || sc2_ != nullptr, lnw = AVE || lnw_ != nullptr, gate = AVE || gate_ != nullptr;
   const bool gate_first = AVE ? false : gate_first_ != 0;
   const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
   const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
   const float gv = gate ? *gate_ : 1.f;
+  // d gate of out = LN(gate * O): LayerNorm is scale invariant, so sum_c dG_c O_c cancels down to its eps term; summed
+  // element by element in fp32 the result is rounding noise (+-3e-4 at 2 M elements, run to run).  For gate != 0 the row
+  // sum has the closed form  C eps rstd^2 mean_c(dy w xhat) / gate  (from sum_c dG = 0 and mean(xhat^2) = 1 - eps rstd^2).
+  const bool gate_closed = gate_first && gate && lnw && gv != 0.f;
+  const float gate_k = gate_closed ? (float)C * eps / gv : 0.f;
   float sc[MAXNV][VE], sh[MAXNV][VE], w[MAXNV][VE], bb[MAXNV][VE];
   float acc[4][MAXNV][VE];   // 0: dlnw 1: dlnb 2: sum dO 3: sum dO*Op (turned into sum dO*xh2 at the end)
 #pragma unroll
@@ -584,6 +589,7 @@ __device__ __forceinline__ void tail_bwd_body(const void* dOut, const void* Op, 
       }
     }
     if (lnw) { group_sum2(s1, s2, gs); s1 /= C; s2 /= C; }
+    if (gate_closed && gl == 0) gsum += gate_k * rs * rs * s2;
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
@@ -593,7 +599,7 @@ __device__ __forceinline__ void tail_bwd_body(const void* dOut, const void* Op, 
         for (int e = 0; e < VE; ++e) {
           float t = lnw ? rs * (g[v][e] - s1 - xh[v][e] * s2) : g[v][e];   // dG (gate_first) or dO
           if (gate_first) {
-            if (gate) gsum += t * o[v][e];
+            if (gate && !gate_closed) gsum += t * o[v][e];
             t *= gv;
           }
           d[e] = t;
@@ -649,9 +655,9 @@ __device__ __forceinline__ void tail_bwd_body(const void* dOut, const void* Op, 
 #define TAIL_BWD_ARGS_                                                                                                  \
   const void *dOut, const void *Op, const float *sc2, const float *sh2, const float *mean2, const float *rstd2,         \
       const float *lnw, const float *lnb, const float *gate, int gate_first, const float *mu, const float *rstd,       \
-      long rows, int C, int gs, int nv, int rpc, void *dO, float *dlnw, float *dlnb, float *dgate, float *bnsums, float *part
+      long rows, int C, int gs, int nv, int rpc, void *dO, float *dlnw, float *dlnb, float *dgate, float *bnsums, float *part, float eps
 #define TAIL_BWD_PASS_                                                                                                  \
-  dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu, rstd, rows, C, gs, nv, rpc, dO, dlnw, dlnb, dgate, bnsums, part
+  dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu, rstd, rows, C, gs, nv, rpc, dO, dlnw, dlnb, dgate, bnsums, part, eps
 template <int DT, int VE, int MAXNV>
 __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_k(TAIL_BWD_ARGS_) {
   tail_bwd_body<DT, VE, MAXNV, false>(TAIL_BWD_PASS_);
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(256, MAXNV == 1 ? 3 : 1) void tail_bwd_ave_k(TAIL_B
 void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
               const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums,
-              float* part, long part_floats) {
+              float eps, float* part, long part_floats) {
   static const int mi = env_int("DGSCT_ROW_MIN_ITERS", 8);
   static const int use_cap = env_int("DGSCT_ROW_CAP", 1);
   RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1, 1024, mi);
@@ -679,10 +685,10 @@ void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2
   if (!use_part || (long)g.chunks * 4 * C > part_floats) part = nullptr;
   if (sc2 && lnw && gate && !gate_first)
     ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_ave_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first,
-                    mu, rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums, part);
+                    mu, rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums, part, eps);
   else
     ROW_DISPATCH_SH(ctx, C, g.nv, tail_bwd_k, dim3(g.chunks), sh, dOut, Op, sc2, sh2, mean2, rstd2, lnw, lnb, gate, gate_first, mu,
-                    rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums, part);
+                    rstd, rows, C, g.gs, g.nv, g.rpc, dO, dlnw, dlnb, dgate, bnsums, part, eps);
   if (part) {
     PartTable t; t.NQ = 4; t.C = C;
     int n = 0;
@@ -1059,6 +1065,42 @@ void cvt_multi(const Ctx& ctx, const CvtSeg* segs, int nseg) {
   t.first_block[nseg] = blocks;
   if (blocks == 0) return;
   hipLaunchKernelGGL(cvt_multi_k, dim3((int)blocks), dim3(256), 0, STREAM(ctx), t);
+}
+
+struct ColsumTable { ColsumSeg seg[COLSUM_MAX_SEG]; int first_block[COLSUM_MAX_SEG + 1]; int nseg; };
+// thread -> one column (coalesced row reads), 4 row slices per workgroup combined in LDS
+__global__ __launch_bounds__(256) void colsum_multi_k(const ColsumTable t) {
+  __shared__ float red[4][64];
+  int s = 0;
+  while (s + 1 < t.nseg && (int)blockIdx.x >= t.first_block[s + 1]) ++s;
+  const ColsumSeg sg = t.seg[s];
+  const int c = ((int)blockIdx.x - t.first_block[s]) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  // rows in slabs of 256 per blockIdx.y (long segments: the [BT * tk] rows of dtok)
+  const int r_lo = (int)blockIdx.y * 256, r_hi = r_lo + 256 < sg.rows ? r_lo + 256 : sg.rows;
+  if (r_lo >= sg.rows) return;                       // (uniform per workgroup)
+  float a0 = 0.f, a1 = 0.f;
+  if (c < sg.C) {
+    int r = r_lo + q;
+    for (; r + 4 < r_hi; r += 8) { a0 += lde_rt(sg.x, sg.dt, (long)r * sg.C + c); a1 += lde_rt(sg.x, sg.dt, (long)(r + 4) * sg.C + c); }
+    if (r < r_hi) a0 += lde_rt(sg.x, sg.dt, (long)r * sg.C + c);
+  }
+  red[q][threadIdx.x & 63] = a0 + a1;
+  __syncthreads();
+  if (q == 0 && c < sg.C)     // atomic: several segments (and the row slabs of one) may accumulate into the same output
+    unsafeAtomicAdd(sg.out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+void colsum_multi(const Ctx& ctx, const ColsumSeg* segs, int nseg) {
+  if (nseg <= 0) return;
+  if (nseg > COLSUM_MAX_SEG) { set_error("colsum_multi: too many segments"); return; }
+  ColsumTable t;
+  int blocks = 0;
+  t.nseg = nseg;
+  for (int s = 0; s < nseg; ++s) { t.seg[s] = segs[s]; t.first_block[s] = blocks; blocks += (segs[s].C + 63) / 64; }
+  t.first_block[nseg] = blocks;
+  if (blocks == 0) return;
+  int maxrows = 1;
+  for (int s = 0; s < nseg; ++s) maxrows = segs[s].rows > maxrows ? segs[s].rows : maxrows;
+  hipLaunchKernelGGL(colsum_multi_k, dim3(blocks, (maxrows + 255) / 256), dim3(256), 0, STREAM(ctx), t);
 }
 
 __global__ __launch_bounds__(64) void rowsum_f32_k(const float* W, int C, float* out) {

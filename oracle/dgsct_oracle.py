@@ -293,7 +293,20 @@ def backward(p: Dict[str, Tensor], s: Dict[str, Tensor], cfg: AdapterConfig, dOu
         else:
             dG = dOut
         if gate is not None:
-            g["gate"] = (dG * s["O"]).sum().reshape(1)
+            if cfg.ln_post:
+                # LayerNorm is scale invariant: d/dgate of LN(gate * O) cancels down to its eps term, and summed from
+                # the fp32 dG this scalar is rounding noise (+-3e-4 at 2 M elements).  As the yardstick of the fp32
+                # tests this ONE reduction is therefore evaluated in float64 from the fp32 forward values (same formula).
+                O64, w64 = s["O"].double(), p["ln_post.weight"].double()
+                G64 = O64 * gate.double()
+                mu64 = G64.mean(-1, keepdim=True)
+                rs64 = (G64.var(-1, unbiased=False, keepdim=True) + cfg.eps).rsqrt()
+                xh64 = (G64 - mu64) * rs64
+                dyw = dOut.double() * w64
+                dG64 = rs64 * (dyw - dyw.mean(-1, keepdim=True) - xh64 * (dyw * xh64).mean(-1, keepdim=True))
+                g["gate"] = (dG64 * O64).sum().reshape(1).to(dOut.dtype)
+            else:
+                g["gate"] = (dG * s["O"]).sum().reshape(1)
             dO = dG * gate
         else:
             dO = dG

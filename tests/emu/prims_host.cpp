@@ -413,9 +413,10 @@ void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2
 
 void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,
               const float* rstd2, const float* lnw, const float* lnb, const float* gate, int gate_first, const float* mu,
-              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums, float*, long) {
+              const float* rstd, long rows, int C, void* dO, float* dlnw, float* dlnb, float* dgate, float* bnsums, float eps, float*, long) {
   std::vector<float> g(C), o(C), xh(C), op(C);
   const float gv = gate ? *gate : 1.f;
+  const bool closed = gate_first && gate && lnw && gv != 0.f;      // see tail_bwd_body (prims_hip.hip)
   double gsum = 0;
   for (long r = 0; r < rows; ++r) {
     double s1 = 0, s2 = 0;
@@ -435,10 +436,11 @@ void tail_bwd(const Ctx& ctx, const void* dOut, const void* Op, const float* sc2
     }
     for (int c = 0; c < C; ++c) {
       float t = lnw ? rstd[r] * (g[c] - (float)(s1 / C) - xh[c] * (float)(s2 / C)) : g[c];
-      if (gate_first) { if (gate) gsum += (double)t * o[c]; t *= gv; }
+      if (gate_first) { if (gate && !closed) gsum += (double)t * o[c]; t *= gv; }
       st(dO, ctx.mode, r * C + c, t);
       if (sc2 && bnsums) { bnsums[c] += t; bnsums[C + c] += t * (op[c] - mean2[c]) * rstd2[c]; }
     }
+    if (closed) gsum += (double)C * eps / gv * rstd[r] * rstd[r] * (s2 / C);
   }
   if (gate) *dgate += (float)gsum;
 }
@@ -612,6 +614,14 @@ void tokattn_bwd(const Ctx& ctx, const void* Yp, const float* T0, const float* t
         dT0b[((long)b * tk + t) * C + c] += (float)o;
       }
   }
+}
+void colsum_multi(const Ctx&, const ColsumSeg* segs, int nseg) {
+  for (int s = 0; s < nseg; ++s)
+    for (int c = 0; c < segs[s].C; ++c) {
+      double a = 0;
+      for (int r = 0; r < segs[s].rows; ++r) a += ld(segs[s].x, segs[s].dt, (long)r * segs[s].C + c);
+      segs[s].out[c] += (float)a;
+    }
 }
 void temporal_gate_fwd(const Ctx&, int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
                        const float* wa, const float* ba, const float* wv, const float* bv, float* out_v, float* out_a, float* gate,

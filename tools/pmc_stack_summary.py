@@ -21,9 +21,10 @@ def fam(name):
 
 
 def rows_of(shp, grp):
+    """one row per (dispatch, counter): hardware counters come as one record per XCD / shader engine instance"""
     db = os.path.join(PMC, "%d_%d_%d_%d_%s" % (*shp, grp), "p_results.db")
     c = sqlite3.connect(db)
-    rows = c.execute("select name, counter_name, counter_value, duration from pmc_events").fetchall()
+    rows = c.execute("select name, counter_name, sum(counter_value), max(duration) from pmc_events group by dispatch_id, counter_name").fetchall()
     return [r for r in rows if "dgsct" in r[0] or "rocclr" in r[0]]
 
 
