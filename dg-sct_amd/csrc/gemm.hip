@@ -38,6 +38,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 struct GemmK {
   int M, N, K, KB;
   int tiles_m, tiles_n, kflat, kt_total, kt_per_split; unsigned kinv;
+  int nfast;                       // tile order of the work list: n-tiles fastest (else m-tiles)
   int xgm, xnb;                    // batched GEMM with a SHARED A: m-tiles per group / batches per XCD (0: plain order)
   const char* A; long lda, a_bs, a_kbs; int a_vec;
   const char* B; long ldb, b_bs, b_kbs; int b_vec;
@@ -332,7 +333,7 @@ void gemm_kernel(const GemmK p) {
 
   // XCD-aware tile order: hardware round-robins consecutive workgroup ids over the 8 XCDs; give each XCD a
   // contiguous run of tiles so operand panels shared by neighbouring tiles stay in ONE private L2 (bijective).
-  int tm, tn, b;
+  int tm, tn, b, zs = blockIdx.z;
   if (p.xgm > 0) {
     // Batched product with ONE A for every batch (the remap: Wn . Y_b): the 8 XCDs split the BATCHES (workgroup id mod
     // 8 is the XCD), and an XCD walks its batches m-group by m-group, so the workgroups resident on it at any time are
@@ -347,17 +348,34 @@ void gemm_kernel(const GemmK p) {
     tm = __builtin_amdgcn_readfirstlane(mg * p.xgm + (rem - bb * gs)); tn = 0;      // (the divisions run on the VALU:
     b = __builtin_amdgcn_readfirstlane(c * p.xnb + bb);                              //  back to scalar registers)
   } else {
+    // ONE work list over (split, batch, tile), cut into 8 contiguous runs: hardware dispatches workgroups in linear
+    // (x, y, z) order round-robin over the XCDs, so workgroup L lands on XCD L & 7 and is the (L >> 3)-th to start there.
+    // What an XCD has resident at any time is then a window of ~64-96 neighbouring list entries:
+    //  * all tiles of ONE split (or one batch) -- its operand slices cross the fabric once, not once per XCD (per-(y, z)
+    //    remapping left 6 of a 48-tile split on every XCD: 178 MB fetched for 41 MB of operands at 512 x 384 x 23040);
+    //  * with `nfast`, all n-tiles of an m-panel next to each other: a [23040 x 512] activation against a 512 x 512
+    //    weight fetched its activation once per n-tile (96 MB for 24) when m ran fastest.
     const int ntile = p.tiles_m * p.tiles_n;
-    int t = blockIdx.x;
-    {
+    if (p.nfast < 0) {               // DGSCT_GEMM_NFAST=-2: the round-1 order (per (y, z) plane, m fastest), kept for A/B runs
+      int t = blockIdx.x;
       const int q = ntile >> 3, r = ntile & 7, x = t & 7, y = t >> 3;
       t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+      tm = t % p.tiles_m; tn = t / p.tiles_m; b = blockIdx.y;
+    } else {
+    const unsigned total = (unsigned)ntile * gridDim.y * gridDim.z;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned q = total >> 3, r = total & 7, x = L & 7, y = L >> 3;
+    const unsigned pp = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    const unsigned rest = pp / (unsigned)ntile;
+    const int t = (int)(pp - rest * (unsigned)ntile);
+    zs = __builtin_amdgcn_readfirstlane((int)(rest / gridDim.y));
+    b = __builtin_amdgcn_readfirstlane((int)(rest - (unsigned)zs * gridDim.y));
+    if (p.nfast) { tm = __builtin_amdgcn_readfirstlane(t / p.tiles_n); tn = __builtin_amdgcn_readfirstlane(t - tm * p.tiles_n); }
+    else { tn = __builtin_amdgcn_readfirstlane(t / p.tiles_m); tm = __builtin_amdgcn_readfirstlane(t - tn * p.tiles_m); }
     }
-    tm = t % p.tiles_m; tn = t / p.tiles_m;
-    b = blockIdx.y;
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt_begin = blockIdx.z * p.kt_per_split;
+  const int kt_begin = zs * p.kt_per_split;
   int kt_end = kt_begin + p.kt_per_split;
   if (kt_end > p.kt_total) kt_end = p.kt_total;
 
@@ -885,6 +903,10 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   splitk = (k.kt_total + k.kt_per_split - 1) / k.kt_per_split;
   dim3 grid(k.tiles_m * k.tiles_n, g.batch, splitk);
   k.xgm = k.xnb = 0;
+  // n fastest when there are fewer n- than m-tiles: the window of tiles resident on an XCD then spans whole rows of tiles
+  // (each big-operand panel is fetched once; the small operand once per XCD).  DGSCT_GEMM_NFAST=0|1 forces it.
+  static const int nfast_env = getenv("DGSCT_GEMM_NFAST") ? atoi(getenv("DGSCT_GEMM_NFAST")) : -1;
+  k.nfast = nfast_env >= 0 ? nfast_env : nfast_env == -2 ? -1 : (k.tiles_n < k.tiles_m);
   static const bool no_xgroup = getenv("DGSCT_GEMM_NOXGROUP") != nullptr;
   if (!no_xgroup && g.A.bs == 0 && g.B.bs != 0 && g.batch >= 16 && g.batch % 8 == 0 && k.tiles_n == 1 && k.tiles_m >= 2 && splitk == 1 &&
       kflat >= 512) {
