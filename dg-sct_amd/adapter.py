@@ -23,8 +23,18 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import warnings
+
 from . import _lib, ops
 from ._lib import PARAM_NAMES
+
+_WARNED = set()
+
+
+def _warn_once(msg: str):
+    if msg not in _WARNED:
+        _WARNED.add(msg)
+        warnings.warn(msg, stacklevel=3)
 
 FLAVOUR_DEFAULTS = {
     #            remap      alpha beta  gamma temporal ln_before_ok gate_first T   tokens_init has(num_tk arg)
@@ -109,6 +119,10 @@ class VisualAdapter(nn.Module):
             self.bn2 = nn.BatchNorm2d(output_dim)
         if opt.is_before_layernorm:
             self.ln_before = nn.LayerNorm(output_dim)
+            if not fl["ln_before_ok"]:
+                # the AVS copies of the class build ln_before and never call it (PVT_AVSModel.py:239): mirrored, but say so
+                _warn_once("VisualAdapter(flavour=%r): is_before_layernorm is set but this flavour's forward never applies "
+                           "ln_before (as in the reference); the parameters exist for state_dict compatibility only" % flavour)
         if opt.is_post_layernorm:
             self.ln_post = nn.LayerNorm(output_dim)
 

@@ -75,6 +75,21 @@ def test_unknown_adapter_kind_raises_like_the_reference():
         VisualAdapter(32, 32, "lora", opt=opt, reduction_factor=8, conv_dim_in=36, conv_dim_out=16, linear_in=16, linear_out=32)
 
 
+def test_ignored_ln_before_warns_once():
+    """AVS flavours build ln_before and never apply it (PVT_AVSModel.py:239): mirrored, with a warning."""
+    import warnings
+    from dgsct_amd import adapter as A
+    A._WARNED.clear()
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=4)
+    kw = dict(reduction_factor=8, opt=opt, conv_dim_in=36, conv_dim_out=16, linear_in=16, linear_out=32, flavour="avs_ms3")
+    with pytest.warns(UserWarning, match="never applies"):
+        m = VisualAdapter(32, 32, "bottleneck", **kw)
+    assert hasattr(m, "ln_before") and not m.spec.ln_before
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        VisualAdapter(32, 32, "bottleneck", **kw)                # second construction: silent
+
+
 def test_no_cpu_fallback():
     opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=4)
     m = VisualAdapter(32, 32, "bottleneck", reduction_factor=8, opt=opt, num_tk=4, conv_dim_in=36, conv_dim_out=16,
