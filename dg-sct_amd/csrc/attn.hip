@@ -546,6 +546,7 @@ void tokattn_bwd2(const Ctx& ctx, const void* Yp, const void* T0pk, const void* 
                   const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b);
 
 bool tokattn_fwd_small_ok(const Ctx& ctx, int N, int C);
+bool tokattn_bwd_csplit(int B, int N, int C);      // short frames, wide channels: the C-split kernel (attn2.hip)
 void tokattn_fwd_small(const Ctx& ctx, const void* Yp, const float* T0, const void* T0pk, int B, int N, int C, int tk, float* tok,
                        void* tokpk, float* lse, float* a, void* aE);
 
@@ -587,7 +588,7 @@ void tokattn_bwd(const Ctx& ctx, const void* Yp, const float* T0, const float* t
                  const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float* Dscratch,
                  const void* T0pk, void* dtokpk) {
   if (!attn_shape_ok(ctx, N, C, tk)) return;
-  if (T0pk && dtokpk && attn2_ok(ctx, C) && N >= 512) {    // (tools/attn_bench.py: the generic kernel wins on short frames)
+  if (T0pk && dtokpk && attn2_ok(ctx, C) && (N >= 512 || tokattn_bwd_csplit(B, N, C))) {    // (tools/attn_bench.py: the generic kernel wins on short frames)
     tok_pack(ctx, dtok, B, tk, C, dtokpk, tok, T0, Dscratch);       // packed dtok + D[b][t] = dtok . (tok - T0)
     tokattn_bwd2(ctx, Yp, T0pk, dtokpk, lse, Dscratch, da, invN, B, N, C, tk, dYp, dT0b);
     return;

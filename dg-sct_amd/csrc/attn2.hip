@@ -172,12 +172,16 @@ __global__ __launch_bounds__(256) void tok_pack_k(const PackArgs p) {
       *reinterpret_cast<uint4*>(TF + f * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
   }
-  if (p.D && blockIdx.x == 0) {          // D[b][t] = sum_c src * (other - base): one wave per 8 latent tokens
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int t = wave; t < p.tk; t += 4) {
-      float d = 0.f;
-      for (int c = lane; c < p.C; c += 64) d += s[(long)t * C + c] * (p.other[((long)b * p.tk + t) * C + c] - p.base[(long)t * C + c]);
-      d = group_sum(d, 64);
+  if (p.D) {          // D[b][t] = sum_c src * (other - base): the waves of all the frame's workgroups share the latent tokens
+    const int lane = tid & 63, gw = blockIdx.x * 4 + (tid >> 6), nw = gridDim.x * 4;
+    for (int t = gw; t < p.tk; t += nw) {
+      const float* o = p.other + ((long)b * p.tk + t) * C;
+      const float* bs = p.base + (long)t * C;
+      float d0 = 0.f, d1 = 0.f;
+      int c = lane;
+      for (; c + 64 < p.C; c += 128) { d0 += s[(long)t * C + c] * (o[c] - bs[c]); d1 += s[(long)t * C + c + 64] * (o[c + 64] - bs[c + 64]); }
+      if (c < p.C) d0 += s[(long)t * C + c] * (o[c] - bs[c]);
+      const float d = group_sum(d0 + d1, 64);
       if (lane == 0) p.D[(long)b * p.tk + t] = d;
     }
   }
@@ -191,6 +195,7 @@ long tok_pack_elems(int nb, int C) { return (long)nb * 96 * C; }
 
 // ---- xattn_fwd ------------------------------------------------------------------------------------------------------
 struct XF2Args { const unsigned short* X; const unsigned short* pk; const float* gate_av; int N, C, tk, nrb, total; unsigned short* X1; };
+static bool xattn_fwd3_launch(const Ctx& ctx, const XF2Args& a, int B);      // C-split variant for short frames (below)
 __global__ __launch_bounds__(256) void xattn_fwd2_k(const XF2Args p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * IMG2];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -272,6 +277,7 @@ bool attn2_ok(const Ctx& ctx, int C) {
 void xattn_fwd2(const Ctx& ctx, const void* X, const void* tokpk, const float* gate_av, int B, int N, int C, int tk, void* X1) {
   const int nrb = (N + 31) / 32;
   XF2Args a{(const unsigned short*)X, (const unsigned short*)tokpk, gate_av, N, C, tk, nrb, B * nrb, (unsigned short*)X1};
+  if (xattn_fwd3_launch(ctx, a, B)) return;
   hipLaunchKernelGGL(xattn_fwd2_k, dim3((a.total + 3) / 4), dim3(256), 0, (hipStream_t)ctx.stream, a);
 }
 
@@ -328,6 +334,7 @@ struct XB2Args {
   const unsigned short* X; const unsigned short* G; const unsigned short* pk; const float* gate_av; int N, C, tk, wpf;
   unsigned short* dX; const unsigned short* R2; float* dtok; float* dgate;
 };
+static bool xattn_bwd3_launch(const Ctx& ctx, XB2Args a, int B);
 __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * (IMG2 + 2 * 32 * PP2)];
   __shared__ float dgs[4];
@@ -431,6 +438,7 @@ void xattn_bwd2(const Ctx& ctx, const void* X, const void* dX1, const void* tokp
   const int wpf = ((N + 31) / 32 + 3) / 4;
   XB2Args a{(const unsigned short*)X, (const unsigned short*)dX1, (const unsigned short*)tokpk, gate_av, N, C, tk, wpf,
             (unsigned short*)dX, (const unsigned short*)R2, dtok, dgate};
+  if (xattn_bwd3_launch(ctx, a, B)) return;
   hipLaunchKernelGGL(xattn_bwd2_k, dim3(B * wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
 }
 
@@ -440,6 +448,7 @@ struct TB2Args {
   const unsigned short* Yp; const unsigned short* T0pk; const unsigned short* dpk; const float* lse; const float* D; const float* da;
   float invN; int N, C, tk, wpf; unsigned short* dYp; float* dT0b;
 };
+static bool tokattn_bwd3_launch(const Ctx& ctx, TB2Args a, int B);
 __global__ __launch_bounds__(256) void tokattn_bwd2_k(const TB2Args p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * (IMG2 + 32 * PP2)];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -535,9 +544,346 @@ void tokattn_bwd2(const Ctx& ctx, const void* Yp, const void* T0pk, const void* 
   const int wpf = ((N + 31) / 32 + 3) / 4;
   TB2Args a{(const unsigned short*)Yp, (const unsigned short*)T0pk, (const unsigned short*)dtokpk, lse, D, da, invN, N, C, tk, wpf,
             (unsigned short*)dYp, dT0b};
+  if (tokattn_bwd3_launch(ctx, a, B)) return;
   hipLaunchKernelGGL(tokattn_bwd2_k, dim3(B * wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
 }
 
+
+// ====================================================================================================================
+// C-split kernels for SHORT frames (B * ceil(N / 32) <= 2048 row blocks: the stage-2/3 shapes of the AVE stack, 32 of its
+// 48 adapter calls).  With one wavefront per 32-row block those launches put < 2 waves on a SIMD, and each wave walks
+// C / 128 slabs twice as one dependent chain (29.9 us for 47 MB at N = 144, C = 512; 47.9 us for 12 MB at N = 36,
+// C = 1024).  Here a WORKGROUP owns the row block and its 4 waves split the CHANNELS: wave w takes slabs w, w + 4, ...
+// (SPW <= 3 of them, all loaded up front), the partial logit tiles are summed through LDS (two barriers), and from then
+// on everything is wave-private again -- every wave holds the full probabilities and finishes its own channels, whose rows
+// are still in its LDS images: one pass over the inputs, no second read.
+// ====================================================================================================================
+namespace {
+constexpr int RED_BYTES = 4 * 16 * 64 * 4;     // [wave][register][lane] fp32 exchange buffer (16 KB)
+__device__ __forceinline__ void wg_reduce_acc(f32x16& a, float* red, int wave, int lane) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = a[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    a[r] = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
+  __syncthreads();                                    // the buffer may be reused
+}
+// rows of a private image += (or =) the [c][n] tiles  sum_t TFa[c][t] fa(t, n) (+ sum_t TFb[c][t] fb(t, n))
+template <bool TWO, bool RMW>
+__device__ __forceinline__ void rows_update(char* img, const unsigned short* TFa, const unsigned short* TFb, int nt, const bfx8& a0,
+                                            const bfx8& a1, const bfx8& b0, const bfx8& b1, float scale, const float* addv, float addscale,
+                                            int lane) {
+  TFrag fa[CS2 / 32], fb[CS2 / 32];
+#pragma unroll
+  for (int j = 0; j < CS2 / 32; ++j) {
+    const int jj = j < nt ? j : 0;
+    fa[j] = tokT_load(TFa, jj, lane);
+    if (TWO) fb[j] = tokT_load(TFb, jj, lane);
+  }
+#pragma unroll
+  for (int j = 0; j < CS2 / 32; ++j) {
+    if (j >= nt) break;
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    tokT_mma(o, fa[j], a0, a1);
+    if (TWO) tokT_mma(o, fb[j], b0, b1);
+    char* xr = img + (lane & 31) * PX2 + (32 * j + 4 * (lane >> 5)) * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x0 = scale * o[4 * q], x1 = scale * o[4 * q + 1], x2 = scale * o[4 * q + 2], x3 = scale * o[4 * q + 3];
+      if (RMW) {
+        const uint2 w = *reinterpret_cast<uint2*>(xr + q * 16);
+        x0 += __uint_as_float(w.x << 16); x1 += __uint_as_float(w.x & 0xffff0000u);
+        x2 += __uint_as_float(w.y << 16); x3 += __uint_as_float(w.y & 0xffff0000u);
+      }
+      if (addv) {
+        const float4 dq = *reinterpret_cast<const float4*>(addv + 32 * j + 4 * (lane >> 5) + 8 * q);
+        x0 += dq.x * addscale; x1 += dq.y * addscale; x2 += dq.z * addscale; x3 += dq.w * addscale;
+      }
+      *reinterpret_cast<uint2*>(xr + q * 16) = make_uint2(pack2(x0, x1), pack2(x2, x3));
+    }
+  }
+}
+// o[t][c] tile j = sum over the 32 rows of A[n][t] * S[n][c]  (A: [n][t] image, S: the slab image)
+__device__ __forceinline__ void tokgrad_tile1(f32x16& o, const char* aimg, const char* simg, int j, int lane) {
+  o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mt_frag_mn(aimg, PP2, 0, 0, lane), mt_frag_mn(simg, PX2, 32 * j, 0, lane), o, 0, 0, 0);
+  o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mt_frag_mn(aimg, PP2, 0, 1, lane), mt_frag_mn(simg, PX2, 32 * j, 1, lane), o, 0, 0, 0);
+}
+}  // namespace
+
+template <int SPW>
+__global__ __launch_bounds__(256) void xattn_fwd3_k(const XF2Args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * SPW * IMG2 + RED_BYTES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / p.nrb, rb = blockIdx.x - b * p.nrb, n0 = rb * 32;
+  const int rows = p.N - n0 < 32 ? p.N - n0 : 32;
+  const long C = p.C;
+  char* img = smem + wave * SPW * IMG2;
+  float* red = reinterpret_cast<float*>(smem + 4 * SPW * IMG2);
+  const unsigned short* Xg = p.X + ((long)b * p.N + n0) * C;
+  unsigned short* Og = p.X1 + ((long)b * p.N + n0) * C;
+  const unsigned short* th = p.pk + (long)b * 96 * C;
+  const unsigned short* tl = th + 32 * C;
+  const unsigned short* tT = tl + 32 * C;
+  const float g = *p.gate_av;
+  const int nsl = (p.C + CS2 - 1) / CS2;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  Slab s[SPW];
+#pragma unroll
+  for (int i = 0; i < SPW; ++i)
+    if (wave + 4 * i < nsl) slab_load(s[i], Xg, C, rows, (wave + 4 * i) * CS2, p.C, lane);
+#pragma unroll
+  for (int i = 0; i < SPW; ++i)
+    if (wave + 4 * i < nsl) slab_store_lds(s[i], img + i * IMG2, rows, (wave + 4 * i) * CS2, p.C, lane);
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int c0 = (wave + 4 * i) * CS2;
+    if (wave + 4 * i < nsl) logits_slab<true>(acc, th, tl, c0, (p.C - c0 < CS2 ? p.C - c0 : CS2) / 16, img + i * IMG2, lane);
+  }
+  wg_reduce_acc(acc, red, wave, lane);
+  softmax_regs(acc, p.tk, lane);
+  float pr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pr[r] = acc[r];
+  const bfx8 pb0 = regs_frag(pr), pb1 = regs_frag(pr + 8);
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int c0 = (wave + 4 * i) * CS2;
+    if (wave + 4 * i >= nsl) break;
+    const int nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
+    rows_update<false, true>(img + i * IMG2, tT + (long)(c0 >> 5) * 1024, nullptr, nt, pb0, pb1, pb0, pb1, g, nullptr, 0.f, lane);
+    wave_sync();
+    slab_copy_out(img + i * IMG2, Og, nullptr, C, rows, c0, p.C, lane);
+  }
+}
+
+template <int SPW>
+__global__ __launch_bounds__(256) void xattn_bwd3_k(const XB2Args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * SPW * IMG2 + RED_BYTES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / p.wpf, rb = blockIdx.x - b * p.wpf, n0 = rb * 32;          // wpf = row blocks per frame here
+  const int rows = p.N - n0 < 32 ? p.N - n0 : 32;
+  const long C = p.C;
+  char* img = smem + wave * SPW * IMG2;
+  float* red = reinterpret_cast<float*>(smem + 4 * SPW * IMG2);
+  char* imgP = smem + 4 * SPW * IMG2 + wave * 2 * 32 * PP2;      // aliases `red` (free after the reductions)
+  char* imgS = imgP + 32 * PP2;
+  const unsigned short* Xg = p.X + ((long)b * p.N + n0) * C;
+  const unsigned short* Gg = p.G + ((long)b * p.N + n0) * C;
+  const unsigned short* hiF = p.pk + (long)b * 96 * C;
+  const unsigned short* loF = hiF + 32 * C;
+  const unsigned short* TF = loF + 32 * C;
+  const float g = *p.gate_av;
+  const int nsl = (p.C + CS2 - 1) / CS2;
+  f32x16 aS, aU;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aU[r] = 0.f; }
+  Slab sx[SPW], sg[SPW];
+#pragma unroll
+  for (int i = 0; i < SPW; ++i)
+    if (wave + 4 * i < nsl) {
+      slab_load(sx[i], Xg, C, rows, (wave + 4 * i) * CS2, p.C, lane);
+      slab_load(sg[i], Gg, C, rows, (wave + 4 * i) * CS2, p.C, lane);
+    }
+#pragma unroll
+  for (int i = 0; i < SPW; ++i)
+    if (wave + 4 * i < nsl) slab_store_lds(sx[i], img + i * IMG2, rows, (wave + 4 * i) * CS2, p.C, lane);
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int c0 = (wave + 4 * i) * CS2;
+    if (wave + 4 * i < nsl) logits_slab<true>(aS, hiF, loF, c0, (p.C - c0 < CS2 ? p.C - c0 : CS2) / 16, img + i * IMG2, lane);
+  }
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < SPW; ++i)
+    if (wave + 4 * i < nsl) slab_store_lds(sg[i], img + i * IMG2, rows, (wave + 4 * i) * CS2, p.C, lane);      // dX1 rows stay in the image
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int c0 = (wave + 4 * i) * CS2;
+    if (wave + 4 * i < nsl) logits_slab<true>(aU, hiF, loF, c0, (p.C - c0 < CS2 ? p.C - c0 : CS2) / 16, img + i * IMG2, lane);
+  }
+  wg_reduce_acc(aS, red, wave, lane);
+  wg_reduce_acc(aU, red, wave, lane);
+  softmax_regs(aS, p.tk, lane);
+  float dot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dot += aS[r] * aU[r];
+  dot += xor32b(dot);
+  const bool nvalid = (lane & 31) < rows;
+  float pv[16], dv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { pv[r] = nvalid ? aS[r] : 0.f; dv[r] = nvalid ? g * aS[r] * (aU[r] - dot) : 0.f; }
+  const bfx8 db0 = regs_frag(dv), db1 = regs_frag(dv + 8);
+  regs_to_img(pv, imgP, lane);
+  regs_to_img(dv, imgS, lane);
+  if (p.dgate && wave == 0) {
+    float part = (nvalid && lane < 32) ? dot : 0.f;
+    part = group_sum(part, 64);
+    if (lane == 0) unsafeAtomicAdd(p.dgate, part);
+  }
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int c0 = (wave + 4 * i) * CS2;
+    if (wave + 4 * i >= nsl) break;
+    const int nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
+    char* im = img + i * IMG2;
+    f32x16 a1[CS2 / 32];
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[j][r] = 0.f;
+      if (j < nt) tokgrad_tile1(a1[j], imgP, im, j, lane);                                  // P^T . dX1
+    }
+    wave_sync();                                                                            // operand reads before the rows change
+    rows_update<false, true>(im, TF + (long)(c0 >> 5) * 1024, nullptr, nt, db0, db1, db0, db1, 1.f, nullptr, 0.f, lane);   // dX = dX1 + dS . tok
+    wave_sync();
+    slab_copy_out(im, p.dX + ((long)b * p.N + n0) * C, p.R2 ? p.R2 + ((long)b * p.N + n0) * C : nullptr, C, rows, c0, p.C, lane);
+    wave_sync();
+    slab_store_lds(sx[i], im, rows, c0, p.C, lane);                                         // X rows back (from registers)
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {
+      if (j >= nt) break;
+      f32x16 a2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[r] = g * a1[j][r];
+      tokgrad_tile1(a2, imgS, im, j, lane);                                                 // + dS^T . X
+      tile_atomic_out(a2, p.dtok + (long)b * p.tk * C, C, c0 + 32 * j + (lane & 31), p.tk, lane);
+    }
+  }
+}
+
+template <int SPW>
+__global__ __launch_bounds__(256) void tokattn_bwd3_k(const TB2Args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * SPW * IMG2 + RED_BYTES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / p.wpf, rb = blockIdx.x - b * p.wpf, n0 = rb * 32;          // wpf = row blocks per frame here
+  const int rows = p.N - n0 < 32 ? p.N - n0 : 32;
+  const long C = p.C;
+  char* img = smem + wave * SPW * IMG2;
+  float* red = reinterpret_cast<float*>(smem + 4 * SPW * IMG2);
+  char* imgS = smem + 4 * SPW * IMG2 + wave * 32 * PP2;           // aliases `red`
+  const unsigned short* Yg = p.Yp + ((long)b * p.N + n0) * C;
+  const unsigned short* thF = p.T0pk;
+  const unsigned short* tlF = thF + 32 * C;
+  const unsigned short* tTF = tlF + 32 * C;
+  const unsigned short* dhF = p.dpk + (long)b * 96 * C;
+  const unsigned short* dTF = dhF + 64 * C;
+  const int nsl = (p.C + CS2 - 1) / CS2;
+  f32x16 aS, aD;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aD[r] = 0.f; }
+  {
+    Slab s[SPW];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i)
+      if (wave + 4 * i < nsl) slab_load(s[i], Yg, C, rows, (wave + 4 * i) * CS2, p.C, lane);
+#pragma unroll
+    for (int i = 0; i < SPW; ++i)
+      if (wave + 4 * i < nsl) slab_store_lds(s[i], img + i * IMG2, rows, (wave + 4 * i) * CS2, p.C, lane);
+  }
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int c0 = (wave + 4 * i) * CS2, kc = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 16;
+    if (wave + 4 * i < nsl) {
+      logits_slab<true>(aS, thF, tlF, c0, kc, img + i * IMG2, lane);
+      logits_slab<false>(aD, dhF, dhF, c0, kc, img + i * IMG2, lane);
+    }
+  }
+  wg_reduce_acc(aS, red, wave, lane);
+  wg_reduce_acc(aD, red, wave, lane);
+  const bool nvalid = (lane & 31) < rows;
+  float pv[16], dv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = mt_row(r, lane);
+    const bool ok = nvalid && t < p.tk;
+    const int tc = t < p.tk ? t : 0;
+    const float pr = ok ? __expf(aS[r] - p.lse[(long)b * p.tk + tc]) : 0.f;
+    pv[r] = pr;
+    dv[r] = ok ? pr * (aD[r] - p.D[(long)b * p.tk + tc]) : 0.f;
+  }
+  const bfx8 pb0 = regs_frag(pv), pb1 = regs_frag(pv + 8), db0 = regs_frag(dv), db1 = regs_frag(dv + 8);
+  regs_to_img(dv, imgS, lane);
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int c0 = (wave + 4 * i) * CS2;
+    if (wave + 4 * i >= nsl) break;
+    const int nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
+    char* im = img + i * IMG2;
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {
+      if (j >= nt) break;
+      f32x16 a2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+      tokgrad_tile1(a2, imgS, im, j, lane);                                                 // d my_tokens += dS1^T . Yp
+      tile_atomic_out(a2, p.dT0b + (long)b * p.tk * C, C, c0 + 32 * j + (lane & 31), p.tk, lane);
+    }
+    wave_sync();
+    // dYp rows = P1 . dtok + dS1 . T0 + da / N, written over the Yp image
+    rows_update<true, false>(im, dTF + (long)(c0 >> 5) * 1024, tTF + (long)(c0 >> 5) * 1024, nt, pb0, pb1, db0, db1, 1.f,
+                             p.da + (long)b * C + c0, p.invN, lane);
+    wave_sync();
+    slab_copy_out(im, p.dYp + ((long)b * p.N + n0) * C, nullptr, C, rows, c0, p.C, lane);
+  }
+}
+
+namespace {
+// one wave per row block leaves the SIMDs under-filled below ~2 waves each: let a workgroup split the channels instead
+bool csplit_ok(int B, int N, int C, int max_spw) {
+  static const bool off = getenv("DGSCT_ATTN_NOCSPLIT") != nullptr;
+  static const int min_c = getenv("DGSCT_ATTN_CSPLIT_MINC") ? atoi(getenv("DGSCT_ATTN_CSPLIT_MINC")) : 512;
+  const long blocks = (long)B * ((N + 31) / 32);
+  const int spw = ((C + CS2 - 1) / CS2 + 3) / 4;
+  // measured (tools/attn_bench.py, B = 160): wins where the per-wave slab chain is long (C >= 768: xattn_fwd 47.9 -> 33.0 us,
+  // xattn_bwd 117 -> 79 us at N = 36, C = 1024), even at C = 512, loses at C = 384 (3 slabs: one wave of four idle)
+  return !off && blocks <= 1024 && C >= min_c && spw <= max_spw;
+}
+}  // namespace
+
+#define DGSCT_SPW_LAUNCH(K, SPW, GRID, ARGS)                                                                                  \
+  switch (SPW) {                                                                                                             \
+    case 1: hipLaunchKernelGGL(K<1>, dim3(GRID), dim3(256), 0, (hipStream_t)ctx.stream, ARGS); break;                        \
+    case 2: hipLaunchKernelGGL(K<2>, dim3(GRID), dim3(256), 0, (hipStream_t)ctx.stream, ARGS); break;                        \
+    default: hipLaunchKernelGGL(K<3>, dim3(GRID), dim3(256), 0, (hipStream_t)ctx.stream, ARGS); break;                       \
+  }
+static bool xattn_fwd3_launch(const Ctx& ctx, const XF2Args& a, int B) {
+  if (!csplit_ok(B, a.N, a.C, 3)) return false;
+  const int spw = ((a.C + CS2 - 1) / CS2 + 3) / 4;
+  DGSCT_SPW_LAUNCH(xattn_fwd3_k, spw, a.total, a);
+  return true;
+}
+static bool xattn_bwd3_launch(const Ctx& ctx, XB2Args a, int B) {
+  if (!csplit_ok(B, a.N, a.C, 2)) return false;          // X and dX1 slabs in registers: 64 VGPRs per slab pair
+  const int spw = ((a.C + CS2 - 1) / CS2 + 3) / 4;
+  a.wpf = (a.N + 31) / 32;
+  if (spw == 1) hipLaunchKernelGGL(xattn_bwd3_k<1>, dim3(B * a.wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
+  else hipLaunchKernelGGL(xattn_bwd3_k<2>, dim3(B * a.wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
+  return true;
+}
+static bool tokattn_bwd3_launch(const Ctx& ctx, TB2Args a, int B) {
+  if (!csplit_ok(B, a.N, a.C, 3)) return false;
+  const int spw = ((a.C + CS2 - 1) / CS2 + 3) / 4;
+  a.wpf = (a.N + 31) / 32;
+  DGSCT_SPW_LAUNCH(tokattn_bwd3_k, spw, B * a.wpf, a);
+  return true;
+}
+#undef DGSCT_SPW_LAUNCH
+// tokattn_bwd: against the generic kernel (one workgroup per 128 rows) the C-split one pays 2-5x the fp32 atomics of
+// d my_tokens (one contribution per 32-row block: 25 of its 89 us at N = 144, C = 512, measured by switching them off) -- it
+// wins only where the slab chain is long: 126 -> 105 us at N = 36, C = 1024; 99 -> 94 at N = 64, C = 768
+bool tokattn_bwd_csplit(int B, int N, int C) { return C >= 768 && csplit_ok(B, N, C, 3); }
 
 // ====================================================================================================================
 // tokattn_fwd for short frames (N <= 256: the stage-2/3 shapes, 32 of the 48 adapter calls of the AVE stack): ONE workgroup
