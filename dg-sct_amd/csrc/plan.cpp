@@ -9,6 +9,7 @@
 //   `ws`     : scratch that dies with the call (logits, cotangents), shared by all adapters of a stream.
 //   `prep`   : MFMA-operand (E) copies of the weights + three derived bias vectors.
 #include "plan.h"
+#include <cstdlib>
 
 #include <functional>
 #include <vector>
@@ -68,6 +69,11 @@ bool Plan::validate() {
   return true;
 }
 
+static bool wt_enabled() {
+  static const bool off = getenv("DGSCT_NO_WT") != nullptr;      // A/B switch: no transposed weight copies
+  return !off;
+}
+
 void Plan::layout() {
   // ---- prep: E copies of the GEMM weights (bf16 mode only) + derived fp32 vectors
   {
@@ -76,7 +82,14 @@ void Plan::layout() {
       wnumel[id] = numel;
       prep_w[id] = (E == DT_BF16) ? a.take("w", numel * es) : -1;
     };
-    for (int i = 0; i < DGSCT_P_COUNT; ++i) { prep_w[i] = -1; wnumel[i] = 0; }
+    for (int i = 0; i < DGSCT_P_COUNT; ++i) { prep_w[i] = -1; prep_wt[i] = -1; wcols[i] = 0; wnumel[i] = 0; }
+    // K-major (transposed) bf16 copies for the data-gradient GEMMs dIn = dOut . W: with W [out][in] as stored, the
+    // contraction index `out` is the slow one (an MN-major B operand); at 128 x 128 that kernel variant needs 200 VGPRs
+    // (2 workgroups per CU): 54.6 vs 32.9 us at 23040 x 512 x 512, and 26 vs 10 us for the M = 160 gate-MLP products
+    auto wtcopy = [&](int id, int64_t cols) {
+      wcols[id] = cols;
+      prep_wt[id] = (E == DT_BF16 && wt_enabled()) ? a.take("wt", wnumel[id] * es) : -1;
+    };
     wcopy(DGSCT_P_WN, (int64_t)N * No);
     wcopy(DGSCT_P_WC, (int64_t)C * Co);
     wcopy(DGSCT_P_WA1, (int64_t)C * C);
@@ -87,6 +100,8 @@ void Plan::layout() {
     wcopy(DGSCT_P_WCATT, (int64_t)C * dd);
     wcopy(DGSCT_P_WD, (int64_t)ds * (C / g));
     wcopy(DGSCT_P_WU, (int64_t)C * (ds / g));
+    wtcopy(DGSCT_P_WC, Co); wtcopy(DGSCT_P_WA1, C); wtcopy(DGSCT_P_WV1, C); wtcopy(DGSCT_P_WB, C); wtcopy(DGSCT_P_WV2, C);
+    wtcopy(DGSCT_P_WA2, C); wtcopy(DGSCT_P_WCATT, dd);
     prep_rowb = a.take("rowb", (int64_t)N * 4);
     prep_colb = a.take("colb", (int64_t)C * 4);
     prep_colb2 = a.take("colb2", (int64_t)C * 4);
@@ -249,6 +264,10 @@ struct Bound {
   const float* F(int id) const { return params[id]; }
   float* Fm(int id) const { return params[id]; }
   const void* W(int id) const { return P.E == DT_BF16 ? (const void*)(prep + P.prep_w[id]) : (const void*)params[id]; }
+  // B operand of dIn = dOut . W for W [out][in] (row stride `in`): the K-major transposed copy when prepare made one
+  MatOp WB(int id, long in, long out) const {
+    return P.prep_wt[id] >= 0 ? km(prep + P.prep_wt[id], out) : mn(W(id), in);
+  }
   template <typename T = void> T* S(int64_t off) const { return reinterpret_cast<T*>(saved + off); }
   template <typename T = void> T* Wk(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
   const float* rowb() const { return reinterpret_cast<const float*>(prep + P.prep_rowb); }
@@ -266,20 +285,21 @@ int Plan::prepare(float* const* params, void* prep, void* stream) const {
     for (int i = 0; i < DGSCT_P_COUNT; ++i)
       if (prep_w[i] >= 0) {
         if (!params[i]) { set_error("dgsct_prepare: parameter %d is NULL", i); return 2; }
-        segs[ns++] = CvtSeg{params[i], p + prep_w[i], (long)wnumel[i], E};
+        segs[ns++] = CvtSeg{params[i], p + prep_w[i], (long)wnumel[i], E, 0};
+        if (prep_wt[i] >= 0) segs[ns++] = CvtSeg{params[i], p + prep_wt[i], (long)wnumel[i], E, (long)wcols[i]};
       }
   float* rowb = (float*)(p + prep_rowb);
   float* colb = (float*)(p + prep_colb);
   float* colb2 = (float*)(p + prep_colb2);
   if (d.remap == DGSCT_REMAP_CONV) {
     // Yp = Wn.Y.Wc^T + bn (x) rowsum(Wc) + 1 (x) bc                       (net_trans.py:553-554)
-    segs[ns++] = CvtSeg{params[DGSCT_P_BN], rowb, (long)N, DT_F32};
-    segs[ns++] = CvtSeg{params[DGSCT_P_BC], colb2, (long)C, DT_F32};
+    segs[ns++] = CvtSeg{params[DGSCT_P_BN], rowb, (long)N, DT_F32, 0};
+    segs[ns++] = CvtSeg{params[DGSCT_P_BC], colb2, (long)C, DT_F32, 0};
     cvt_multi(ctx, segs, ns);
     rowsum_f32(ctx, params[DGSCT_P_WC], C, Co, colb);
   } else {
     // Yp = Wfix.(Y.Wc^T + bc) = Wfix.Y.Wc^T + rowsum(Wfix) (x) bc        (PVT_AVSModel.py:190-197)
-    segs[ns++] = CvtSeg{params[DGSCT_P_BC], colb, (long)C, DT_F32};
+    segs[ns++] = CvtSeg{params[DGSCT_P_BC], colb, (long)C, DT_F32, 0};
     cvt_multi(ctx, segs, ns);
     rowsum_f32(ctx, params[DGSCT_P_WN], N, No, rowb);
     zero(ctx, colb2, (size_t)C * 4);
@@ -551,7 +571,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                    G(DGSCT_P_BV2), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
     Gemm g1 = mk((int)R, C, dd);                                 // dXc = dvq2 . Wv2
     g1.A = km(b.S(s.vq2), dd);
-    g1.B = mn(b.W(DGSCT_P_WV2), C);
+    g1.B = b.WB(DGSCT_P_WV2, C, dd);
     outE(g1, b.Wk(wb.dXc), E, C);
     gemm(ctx, g1);
     Gemm g2 = mk(dd, C, (int)R);                                 // dWv2 = dvq2^T . Xc
@@ -571,7 +591,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g1, G(DGSCT_P_WCATT), dd);
     defer([=, &side] { gemm(side, g1); });
     Gemm g2 = mk(B, dd, C);                                      // dq = (dpre . Wcatt) * (q > 0)
-    g2.A = km(b.Wk(wb.dpre_c), C); g2.B = mn(b.W(DGSCT_P_WCATT), dd);
+    g2.A = km(b.Wk(wb.dpre_c), C); g2.B = b.WB(DGSCT_P_WCATT, dd, C);
     g2.mask = b.S(s.q); g2.ldmask = dd;
     outE(g2, b.Wk(wb.dq), E, dd);
     gemm(ctx, g2);
@@ -580,7 +600,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g3, G(DGSCT_P_WB), C);
     defer([=, &side] { gemm(side, g3); });
     Gemm g4 = mk(B, C, dd);                                      // dm1 = dq . Wb
-    g4.A = km(b.Wk(wb.dq), dd); g4.B = mn(b.W(DGSCT_P_WB), C);
+    g4.A = km(b.Wk(wb.dq), dd); g4.B = b.WB(DGSCT_P_WB, C, dd);
     outF(g4, b.Wk<float>(wb.dm1), C);
     gemm(ctx, g4);
     ew(ctx, EW_MUL_MASK, b.Wk(wb.dpa1), E, F32(b.Wk(wb.dm1)), F32(b.S(s.mvq1)), Earg(b.S(s.aq1), E), (long)B * C, 0.f, 1);
@@ -591,7 +611,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     relu_bwd_scale(ctx, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N,
                    G(DGSCT_P_BV1), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
     Gemm g1 = mk((int)R, C, C);                                  // dX1 += dvq1 . Wv1
-    g1.A = km(b.S(s.vq1), C); g1.B = mn(b.W(DGSCT_P_WV1), C);
+    g1.A = km(b.S(s.vq1), C); g1.B = b.WB(DGSCT_P_WV1, C, C);
     resid(g1, dX1, E, C);
     outE(g1, dX1, E, C);
     gemm(ctx, g1);
@@ -620,11 +640,11 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     });
     side_flush();                                                // dWcatt, dWb, dWv1, dWa1, dWa2 and their biases
     Gemm g3 = mk(B, C, C);                                       // da = dpa1 . Wa1 + dpa2 . Wa2
-    g3.A = km(b.Wk(wb.dpa1), C); g3.B = mn(b.W(DGSCT_P_WA1), C);
+    g3.A = km(b.Wk(wb.dpa1), C); g3.B = b.WB(DGSCT_P_WA1, C, C);
     outF(g3, b.Wk<float>(wb.da), C);
     gemm(ctx, g3);
     Gemm g4 = mk(B, C, dd);
-    g4.A = km(b.Wk(wb.dpa2), dd); g4.B = mn(b.W(DGSCT_P_WA2), C);
+    g4.A = km(b.Wk(wb.dpa2), dd); g4.B = b.WB(DGSCT_P_WA2, C, dd);
     resid(g4, b.Wk(wb.da), DT_F32, C);
     outF(g4, b.Wk<float>(wb.da), C);
     gemm(ctx, g4);
@@ -675,7 +695,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       defer([=, &side] { gemm(side, g2); });
       side_flush();
       Gemm g1 = mk((int)R, Co, C);                               // dT1 = dYp . Wc
-      g1.A = km(dYp, C); g1.B = mn(b.W(DGSCT_P_WC), Co);
+      g1.A = km(dYp, C); g1.B = b.WB(DGSCT_P_WC, Co, C);
       outE(g1, b.Wk(wb.dT), E, Co);
       gemm(ctx, g1);
       Gemm g3 = mk(No, Co, N, B);                                // dY[b] = Wn^T . dT1[b]
@@ -719,7 +739,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       side_flush();
       Gemm g3 = mk(No, Co, C, B);                                // dY[b] = dT2[b] . Wc
       g3.A = km(b.Wk(wb.dT), C, (long)No * C);
-      g3.B = mn(b.W(DGSCT_P_WC), Co);
+      g3.B = b.WB(DGSCT_P_WC, Co, C);
       outE(g3, dY, E, Co, (long)No * Co);
       gemm(ctx, g3);
     }

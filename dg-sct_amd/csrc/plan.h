@@ -22,7 +22,7 @@ struct Plan {
   bool orderA;   // remap association: (Wn.Y).Wc^T (A) or Wn.(Y.Wc^T) (B), whichever is cheaper
 
   // prep
-  int64_t prep_w[DGSCT_P_COUNT], wnumel[DGSCT_P_COUNT], prep_rowb, prep_colb, prep_colb2, prep_t0pk, prep_bytes;
+  int64_t prep_w[DGSCT_P_COUNT], prep_wt[DGSCT_P_COUNT], wcols[DGSCT_P_COUNT], wnumel[DGSCT_P_COUNT], prep_rowb, prep_colb, prep_colb2, prep_t0pk, prep_bytes;
   // saved
   struct {
     int64_t a, mvq1, bnacc1, bnacc2, zero_end;

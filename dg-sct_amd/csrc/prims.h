@@ -220,8 +220,8 @@ void temporal_fwd(const Ctx&, const float* a, const float* wt, const float* bt, 
 // out[i] = (E) in[i]   i < n, for weights: fp32 master -> E copy
 void cvt(const Ctx&, const float* in, void* out, int odt, long n);
 // Up to CVT_MAX_SEG independent fp32 -> odt[i] copies in ONE launch (all weight casts of dgsct_prepare).
-constexpr int CVT_MAX_SEG = 16;
-struct CvtSeg { const float* src; void* dst; long n; int odt; };
+constexpr int CVT_MAX_SEG = 24;
+struct CvtSeg { const float* src; void* dst; long n; int odt; long tr_cols; };   // tr_cols > 0: src is [n / tr_cols][tr_cols], dst its transpose
 void cvt_multi(const Ctx&, const CvtSeg* segs, int nseg);
 // Up to COLSUM_MAX_SEG independent small column sums in ONE launch: out[c] += sum_{r < rows} x[r][c] (x: rows x C, dtype dt, leading
 // dimension C).  For the per-frame-vector gradients ([BT][C] matrices: bias gradients of the gate MLPs): five single-workgroup

@@ -1052,7 +1052,11 @@ __global__ __launch_bounds__(256) void cvt_multi_k(const CvtTable t) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const long i = base + k * 256 + threadIdx.x;
-    if (i < sg.n) ste_rt(sg.dst, sg.odt, i, sg.src[i]);
+    if (i < sg.n) {
+      long si = i;
+      if (sg.tr_cols > 0) { const long rows = sg.n / sg.tr_cols, j = i / rows; si = (i - j * rows) * sg.tr_cols + j; }   // dst[j][r] = src[r][j]
+      ste_rt(sg.dst, sg.odt, i, sg.src[si]);
+    }
   }
 }
 void cvt_multi(const Ctx& ctx, const CvtSeg* segs, int nseg) {

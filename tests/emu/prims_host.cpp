@@ -474,7 +474,12 @@ void temporal_fwd(const Ctx&, const float* a, const float* wt, const float* bt, 
 void cvt(const Ctx&, const float* in, void* out, int odt, long n) { for (long i = 0; i < n; ++i) st(out, odt, i, in[i]); }
 
 void cvt_multi(const Ctx&, const CvtSeg* segs, int nseg) {
-  for (int s = 0; s < nseg; ++s) for (long i = 0; i < segs[s].n; ++i) st(segs[s].dst, segs[s].odt, i, segs[s].src[i]);
+  for (int s = 0; s < nseg; ++s)
+    for (long i = 0; i < segs[s].n; ++i) {
+      long si = i;
+      if (segs[s].tr_cols > 0) { const long rows = segs[s].n / segs[s].tr_cols, j = i / rows; si = (i - j * rows) * segs[s].tr_cols + j; }
+      st(segs[s].dst, segs[s].odt, i, segs[s].src[si]);
+    }
 }
 
 void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out) {
