@@ -42,11 +42,12 @@ def run_case(N, C, No, Co, BT, dtype, flavour="ave", seed=0, over=None):
     Y = torch.randn(BT, No, Co, generator=gen)
     dOut = torch.randn(BT, N, C, generator=gen)
     dMap = torch.randn(BT, N, generator=gen)
+    dTmap = torch.randn(BT, generator=gen) if cfg.temporal else None          # cotangent of the per-frame temporal gate
     if dtype == torch.bfloat16:
         X, Y, dOut = X.bfloat16().float(), Y.bfloat16().float(), dOut.bfloat16().float()
     po = {k: v.clone() for k, v in p.items()}
     out_o, map_o, _, s = O.forward(po, X, Y, cfg, training=True)
-    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, None, training=True)
+    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, dTmap, training=True)
     spec = spec_of(cfg)
     params = param_table(p, spec, DEV)
     lib = default_lib()
@@ -54,7 +55,7 @@ def run_case(N, C, No, Co, BT, dtype, flavour="ave", seed=0, over=None):
     prep = ops.prepare(lib, spec, params, dtype, DEV)
     out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
     dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(DEV, dtype).contiguous(),
-                                     dMap.to(DEV), None)
+                                     dMap.to(DEV), dTmap.to(DEV) if dTmap is not None else None)
     torch.cuda.synchronize()
     return dict(out=(out, out_o), map=(amap, map_o), dX=(dX, dX_o), dY=(dY, dY_o),
                 grads={PARAM_NAMES[i]: (g, g_o[PARAM_NAMES[i]]) for i, g in enumerate(grads)
@@ -146,6 +147,21 @@ def test_avqa_swin_large_fp32(shape, use_gate):
                                             ((36, 1536, 64, 768), True)])
 def test_avqa_swin_large_bf16(shape, use_gate):
     check_bf16(run_case(*shape, BT=10, dtype=torch.bfloat16, flavour="avqa", over=dict(use_gate=use_gate)), _key("avqa", shape))
+
+
+# the two flavours no BASELINE config names, at real shapes (the goldens hold them at toy sizes only): AVS-MS3 (conv remap,
+# alpha 0.2 / beta 0.1, gate before ln_post, T = 5) and pretrain / few-shot / zero-shot (temporal gate, gamma, 3-tuple output)
+@pytest.mark.parametrize("shape", [(576, 384, 1024, 192), (36, 1536, 64, 768)])
+def test_avs_ms3_fp32(shape):
+    check_fp32(run_case(*shape, BT=5, dtype=torch.float32, flavour="avs_ms3"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(144, 512, 256, 384), (64, 768, 36, 1024)])
+def test_pretrain_temporal_gate(shape, dtype):
+    r = run_case(*shape, BT=20, dtype=dtype, flavour="pretrain")
+    assert "temporal_gated.0.weight" in r["grads"] and "temporal_gated.0.bias" in r["grads"]
+    (check_fp32 if dtype == torch.float32 else check_bf16)(r)
 
 
 # configs[2] AVVP: B = 32 clips over DP = 4 -> 80 frames per GPU
