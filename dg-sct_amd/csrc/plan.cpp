@@ -488,8 +488,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     pend.clear();
   };
   auto G = [&](int id) -> float* { return grad_off[id] >= 0 ? grads + grad_off[id] : nullptr; };
-  zero(ctx, b.Wk(0), (size_t)wb.zero_end);
-  zero(ctx, grads, (size_t)grad_floats * 4);
+  zero2(ctx, b.Wk(0), (size_t)wb.zero_end, grads, (size_t)grad_floats * 4);
   const float* bn1 = b.S<float>(s.bn1);
   const float* bn2 = b.S<float>(s.bn2);
   const float* tg = d.temporal ? b.S<float>(s.tg) : nullptr;
@@ -563,9 +562,9 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     spatial_bwd(ctx, b.S<float>(s.sl), b.S<float>(s.sg), b.S<float>(s.map), b.Wk<float>(wb.dsg), dMap, B, N,
                 b.Wk<float>(wb.dsl), G(DGSCT_P_BS));
     colsum_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd);  // u
-    ew(ctx, EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1);
-    // (d ws = sum_b tmpBd: with the bias gradients below, colsum_multi)
-    ew(ctx, EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd);
+    // tmpBd = u * aq2 (d ws = sum_b tmpBd: with the bias gradients below, colsum_multi);  dpa2 = u * ws * (aq2 > 0)
+    ew2(ctx, EwCall{EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1},
+        EwCall{EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd});
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
     relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
                    G(DGSCT_P_BV2), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
@@ -603,8 +602,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g4.A = km(b.Wk(wb.dq), dd); g4.B = b.WB(DGSCT_P_WB, C, dd);
     outF(g4, b.Wk<float>(wb.dm1), C);
     gemm(ctx, g4);
-    ew(ctx, EW_MUL_MASK, b.Wk(wb.dpa1), E, F32(b.Wk(wb.dm1)), F32(b.S(s.mvq1)), Earg(b.S(s.aq1), E), (long)B * C, 0.f, 1);
-    ew(ctx, EW_MUL, b.Wk(wb.coef), DT_F32, F32(b.Wk(wb.dm1)), Earg(b.S(s.aq1), E), NOARG, (long)B * C, 0.f, 1);
+    ew2(ctx, EwCall{EW_MUL_MASK, b.Wk(wb.dpa1), E, F32(b.Wk(wb.dm1)), F32(b.S(s.mvq1)), Earg(b.S(s.aq1), E), (long)B * C, 0.f, 1},
+        EwCall{EW_MUL, b.Wk(wb.coef), DT_F32, F32(b.Wk(wb.dm1)), Earg(b.S(s.aq1), E), NOARG, (long)B * C, 0.f, 1});
   }
   // B5 ---- video query 1
   {

@@ -76,6 +76,7 @@ void gemm(const Ctx&, const Gemm&);
 void gemm_prof_enable(int on);
 void gemm_prof_collect(long* launches, double* total_ms, double* total_flops);
 void zero(const Ctx&, void* p, size_t bytes);
+void zero2(const Ctx&, void* a, size_t abytes, void* b, size_t bbytes);      // both in one launch
 
 // out[r][0..L) = softmax(pre_tanh ? tanh(in[r][.]) : in[r][.]); out[r][L..ld_out) = 0.  out dtype odt.
 void softmax_rows(const Ctx&, const float* in, long ld_in, void* out, int odt, long ld_out, long rows, int L, int pre_tanh);
@@ -215,6 +216,8 @@ enum EwOp : int {
 };
 struct EwArg { const void* p = nullptr; int dt = DT_F32; };
 void ew(const Ctx&, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n, float s, long div);
+struct EwCall { int op; void* o; int odt; EwArg a, b, c; long n; float s; long div; };
+void ew2(const Ctx&, EwCall p, EwCall q);      // two independent ops, one launch
 // tg[b] = sigmoid(a[b][:] . wt + bt)
 void temporal_fwd(const Ctx&, const float* a, const float* wt, const float* bt, int B, int C, float* tg);
 // out[i] = (E) in[i]   i < n, for weights: fp32 master -> E copy

@@ -86,6 +86,27 @@ void stream_join(const Ctx& ctx) {
 void zero(const Ctx& ctx, void* p, size_t bytes) {
   if (bytes) (void)hipMemsetAsync(p, 0, bytes, STREAM(ctx));
 }
+// two buffers in one launch (backward: the accumulate-into scratch block and the flat gradient buffer; two hipMemsetAsync
+// are two fill kernels of 5-8 us each on the dependency chain).  Pointers 16-byte aligned, sizes multiples of 4.
+__global__ __launch_bounds__(256) void zero2_k(uint4* a, long na16, unsigned* atail, int nat, uint4* b, long nb16, unsigned* btail, int nbt) {
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x, step = (long)gridDim.x * 256;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (long i = i0; i < na16; i += step) a[i] = z;
+  for (long i = i0; i < nb16; i += step) b[i] = z;
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < nat) atail[threadIdx.x] = 0;
+    if ((int)threadIdx.x < nbt) btail[threadIdx.x] = 0;
+  }
+}
+void zero2(const Ctx& ctx, void* a, size_t abytes, void* b, size_t bbytes) {
+  if (((uintptr_t)a | (uintptr_t)b) & 15 || (abytes | bbytes) & 3) { zero(ctx, a, abytes); zero(ctx, b, bbytes); return; }
+  const long na = (long)(abytes / 16), nb = (long)(bbytes / 16);
+  long blocks = (na + nb + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zero2_k, dim3((int)blocks), dim3(256), 0, STREAM(ctx), (uint4*)a, na, (unsigned*)((char*)a + na * 16),
+                     (int)((abytes - na * 16) / 4), (uint4*)b, nb, (unsigned*)((char*)b + nb * 16), (int)((bbytes - nb * 16) / 4));
+}
 
 // ================================================================================================
 // row-kernel geometry
@@ -1001,27 +1022,45 @@ void spatial_bwd(const Ctx& ctx, const float* sl, const float* sg, const float* 
 // ================================================================================================
 // small helpers
 // ================================================================================================
-__global__ void ew_k(int op, void* o, int odt, const void* a, int adt, const void* b, int bdt, const void* c, int cdt, long n,
-                     float s, long div) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void ew_eval(const EwCall& p, long i) {
   float r;
-  switch (op) {
-    case EW_MUL: r = lde_rt(a, adt, i) * lde_rt(b, bdt, i); break;
-    case EW_MUL_MASK: r = lde_rt(c, cdt, i) > 0.f ? lde_rt(a, adt, i) * lde_rt(b, bdt, i) : 0.f; break;
-    case EW_SIGMOID_BWD: { const float y = lde_rt(b, bdt, i); r = lde_rt(a, adt, i) * y * (1.f - y); break; }
-    case EW_SCALE: r = s * lde_rt(a, adt, i); break;
-    case EW_ADD_BCAST: r = lde_rt(a, adt, i) + s * lde_rt(b, bdt, i / div); break;
-    case EW_MULB_MASK: r = lde_rt(c, cdt, i) > 0.f ? lde_rt(a, adt, i) * lde_rt(b, bdt, i % div) : 0.f; break;
-    case EW_OUTER_ACC: r = lde_rt(o, odt, i) + lde_rt(a, adt, i / div) * lde_rt(b, bdt, i % div); break;
-    default: r = lde_rt(a, adt, i); break;
+  switch (p.op) {
+    case EW_MUL: r = lde_rt(p.a.p, p.a.dt, i) * lde_rt(p.b.p, p.b.dt, i); break;
+    case EW_MUL_MASK: r = lde_rt(p.c.p, p.c.dt, i) > 0.f ? lde_rt(p.a.p, p.a.dt, i) * lde_rt(p.b.p, p.b.dt, i) : 0.f; break;
+    case EW_SIGMOID_BWD: { const float y = lde_rt(p.b.p, p.b.dt, i); r = lde_rt(p.a.p, p.a.dt, i) * y * (1.f - y); break; }
+    case EW_SCALE: r = p.s * lde_rt(p.a.p, p.a.dt, i); break;
+    case EW_ADD_BCAST: r = lde_rt(p.a.p, p.a.dt, i) + p.s * lde_rt(p.b.p, p.b.dt, i / p.div); break;
+    case EW_MULB_MASK: r = lde_rt(p.c.p, p.c.dt, i) > 0.f ? lde_rt(p.a.p, p.a.dt, i) * lde_rt(p.b.p, p.b.dt, i % p.div) : 0.f; break;
+    case EW_OUTER_ACC: r = lde_rt(p.o, p.odt, i) + lde_rt(p.a.p, p.a.dt, i / p.div) * lde_rt(p.b.p, p.b.dt, i % p.div); break;
+    default: r = lde_rt(p.a.p, p.a.dt, i); break;
   }
-  ste_rt(o, odt, i, r);
+  ste_rt(p.o, p.odt, i, r);
+}
+__global__ void ew_k(const EwCall p) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.n) ew_eval(p, i);
+}
+// two independent element-wise ops in one launch (the gate-MLP backward has two pairs with shared inputs)
+__global__ void ew2_k(const EwCall p, const EwCall q, int first_q) {
+  if ((int)blockIdx.x < first_q) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.n) ew_eval(p, i);
+  } else {
+    const long i = (long)((int)blockIdx.x - first_q) * blockDim.x + threadIdx.x;
+    if (i < q.n) ew_eval(q, i);
+  }
 }
 void ew(const Ctx& ctx, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n, float s, long div) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(ew_k, dim3((int)cdiv(n, 256)), dim3(256), 0, STREAM(ctx), op, o, odt, a.p, a.dt, b.p, b.dt, c.p, c.dt, n, s,
-                     div < 1 ? 1 : div);
+  const EwCall p{op, o, odt, a, b, c, n, s, div < 1 ? 1 : div};
+  hipLaunchKernelGGL(ew_k, dim3((int)cdiv(n, 256)), dim3(256), 0, STREAM(ctx), p);
+}
+void ew2(const Ctx& ctx, EwCall p, EwCall q) {
+  if (p.n <= 0 || q.n <= 0) { if (p.n > 0) ew(ctx, p.op, p.o, p.odt, p.a, p.b, p.c, p.n, p.s, p.div); if (q.n > 0) ew(ctx, q.op, q.o, q.odt, q.a, q.b, q.c, q.n, q.s, q.div); return; }
+  if (p.div < 1) p.div = 1;
+  if (q.div < 1) q.div = 1;
+  const int fq = (int)cdiv(p.n, 256);
+  hipLaunchKernelGGL(ew2_k, dim3(fq + (int)cdiv(q.n, 256)), dim3(256), 0, STREAM(ctx), p, q, fq);
 }
 
 __global__ __launch_bounds__(64) void temporal_fwd_k(const float* a, const float* wt, const float* bt, int C, float* tg) {

@@ -72,6 +72,7 @@ static void gemm_softmax(const Ctx& ctx, const Gemm& g) {      // ACT_SOFTMAX / 
     }
   if (g.act == ACT_SOFTMAX_BWD && g.sm_dot) *g.sm_dot += (float)tot;
 }
+void zero2(const Ctx& c, void* a, size_t abytes, void* b, size_t bbytes) { zero(c, a, abytes); zero(c, b, bbytes); }
 
 void gemm(const Ctx& ctx, const Gemm& g) {
   if (g.act == ACT_SOFTMAX || g.act == ACT_SOFTMAX_BWD) { gemm_softmax(ctx, g); return; }
@@ -461,6 +462,11 @@ void ew(const Ctx&, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n,
     }
     st(o, odt, i, r);
   }
+}
+
+void ew2(const Ctx& c, EwCall p, EwCall q) {
+  ew(c, p.op, p.o, p.odt, p.a, p.b, p.c, p.n, p.s, p.div);
+  ew(c, q.op, q.o, q.odt, q.a, q.b, q.c, q.n, q.s, q.div);
 }
 
 void temporal_fwd(const Ctx&, const float* a, const float* wt, const float* bt, int B, int C, float* tg) {
