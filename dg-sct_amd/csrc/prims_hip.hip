@@ -1084,18 +1084,28 @@ void cvt(const Ctx& ctx, const float* in, void* out, int odt, long n) {
 
 struct CvtTable { CvtSeg seg[CVT_MAX_SEG]; long first_block[CVT_MAX_SEG + 1]; int nseg; };
 __global__ __launch_bounds__(256) void cvt_multi_k(const CvtTable t) {
+  __shared__ float tile[64][65];
   int s = 0;
   while (s + 1 < t.nseg && (long)blockIdx.x >= t.first_block[s + 1]) ++s;
   const CvtSeg sg = t.seg[s];
-  const long base = ((long)blockIdx.x - t.first_block[s]) * 2048;
+  const long blk = (long)blockIdx.x - t.first_block[s];
+  if (sg.tr_cols > 0) {
+    // dst[j][r] = src[r][j] in 64 x 64 tiles through LDS: rows of src are read, rows of dst are written (a thread-per-
+    // destination-element version read with a stride of tr_cols floats: 3.8 GB fetched per step for 0.3 GB of weights)
+    const long cols = sg.tr_cols, rows = sg.n / cols, tcols = (cols + 63) / 64;
+    const long r0 = (blk / tcols) * 64, c0 = (blk % tcols) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) tile[k][tx] = (r0 + k < rows && c0 + tx < cols) ? sg.src[(r0 + k) * cols + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4)
+      if (c0 + k < cols && r0 + tx < rows) ste_rt(sg.dst, sg.odt, (c0 + k) * rows + r0 + tx, tile[tx][k]);
+    return;
+  }
+  const long base = blk * 2048;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const long i = base + k * 256 + threadIdx.x;
-    if (i < sg.n) {
-      long si = i;
-      if (sg.tr_cols > 0) { const long rows = sg.n / sg.tr_cols, j = i / rows; si = (i - j * rows) * sg.tr_cols + j; }   // dst[j][r] = src[r][j]
-      ste_rt(sg.dst, sg.odt, i, sg.src[si]);
-    }
+    if (i < sg.n) ste_rt(sg.dst, sg.odt, i, sg.src[i]);
   }
 }
 void cvt_multi(const Ctx& ctx, const CvtSeg* segs, int nseg) {
@@ -1104,7 +1114,11 @@ void cvt_multi(const Ctx& ctx, const CvtSeg* segs, int nseg) {
   CvtTable t;
   long blocks = 0;
   t.nseg = nseg;
-  for (int s = 0; s < nseg; ++s) { t.seg[s] = segs[s]; t.first_block[s] = blocks; blocks += cdiv(segs[s].n, 2048); }
+  for (int s = 0; s < nseg; ++s) {
+    t.seg[s] = segs[s]; t.first_block[s] = blocks;
+    if (segs[s].tr_cols > 0) blocks += cdiv(segs[s].n / segs[s].tr_cols, 64) * cdiv(segs[s].tr_cols, 64);
+    else blocks += cdiv(segs[s].n, 2048);
+  }
   t.first_block[nseg] = blocks;
   if (blocks == 0) return;
   hipLaunchKernelGGL(cvt_multi_k, dim3((int)blocks), dim3(256), 0, STREAM(ctx), t);
