@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void tokattn_combine_k(const TokCombArgs p) {
 // ====================================================================================================================
 // xattn_fwd: X1 = X + gate_av * softmax_t(X . tok^T) . tok
 // ====================================================================================================================
-struct XFwdArgs { const void* X; const float* tok; const float* gate_av; int N, C, tk; void* X1; int dbg; };
+struct XFwdArgs { const void* X; const float* tok; const float* gate_av; int N, C, tk; void* X1; };
 template <int MODE>
 __global__ __launch_bounds__(256) void xattn_fwd_k(const XFwdArgs p) {
   using M = MT<MODE>;
@@ -249,7 +249,6 @@ __global__ __launch_bounds__(256) void xattn_fwd_k(const XFwdArgs p) {
       stv<MODE, 4>(prow, 8 * q + 4 * (lane >> 5), v);
     }
   }
-  if (p.dbg == 1) return;
   {   // ---- phase B: X1[n][c] = X[n][c] + g * sum_t P[n][t] tok[t][c]
     char* sX = smem; char* sTh = smem + NCH_ROWS * PXB; char* sTl = sTh + 32 * PTB;
     for (int cs = 0; cs < p.C; cs += CSB) {
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_k(const XFwdArgs p) {
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < CSB / 32; ++j) {
-        if (cs + 32 * j >= p.C || p.dbg == 2) break;
+        if (cs + 32 * j >= p.C) break;
         mt_f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -272,7 +271,6 @@ __global__ __launch_bounds__(256) void xattn_fwd_k(const XFwdArgs p) {
           ste<MODE>(q, c, lde<MODE>(q, c) + g * o[r]);
         }
       }
-      if (p.dbg != 3)
       copy_out_rows<MODE, CSB>(sX, PXB, 32 * wave, p.X1, nullptr, p.C, (long)b * p.N + n0 + 32 * wave, p.N - n0 - 32 * wave, cs,
                                p.C, lane);
     }
@@ -570,7 +568,7 @@ void xattn_fwd(const Ctx& ctx, const void* X, const float* tok, const float* gat
                const void* tokpk) {
   if (!attn_shape_ok(ctx, N, C, tk)) return;
   if (tokpk && attn2_ok(ctx, C)) { xattn_fwd2(ctx, X, tokpk, gate_av, B, N, C, tk, X1); return; }
-  XFwdArgs p{X, tok, gate_av, N, C, tk, X1, getenv("DGSCT_ATTN_DBG") ? atoi(getenv("DGSCT_ATTN_DBG")) : 0};
+  XFwdArgs p{X, tok, gate_av, N, C, tk, X1};
   const dim3 grid((N + NCH_ROWS - 1) / NCH_ROWS, B);
   if (ctx.mode == DT_BF16) hipLaunchKernelGGL(xattn_fwd_k<DT_BF16>, grid, dim3(256), 0, (hipStream_t)ctx.stream, p);
   else hipLaunchKernelGGL(xattn_fwd_k<DT_F32>, grid, dim3(256), 0, (hipStream_t)ctx.stream, p);
