@@ -147,27 +147,37 @@ __global__ __launch_bounds__(256) void tok_pack_k(const PackArgs p) {
   const float* s = p.src + (long)b * p.tk * C;
   // one thread per 8-element fragment piece (16 B out), 4 C of them per image
   for (long f = (long)blockIdx.x * 256 + tid; f < 4 * C; f += (long)gridDim.x * 256) {
+    // loads are unconditional from clamped rows and masked afterwards (`t < tk ? s[..] : 0` per element compiles to a
+    // branch + load + s_waitcnt vmcnt(0) each: 16 serial round trips per piece)
     {   // hiF / loF piece f = (kk*2 + h)*32 + t
       const int t = (int)(f & 31), h = (int)((f >> 5) & 1), kk = (int)(f >> 6);
+      const float* row = s + (long)(t < p.tk ? t : 0) * C + 16 * kk + 8 * h;
+      const float4 q0 = *reinterpret_cast<const float4*>(row), q1 = *reinterpret_cast<const float4*>(row + 4);
+      const float m = t < p.tk ? 1.f : 0.f;
+      const float x[8] = {q0.x * m, q0.y * m, q0.z * m, q0.w * m, q1.x * m, q1.y * m, q1.z * m, q1.w * m};
       unsigned hw[4], lw[4];
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
-        const float x0 = t < p.tk ? s[(long)t * C + 16 * kk + 8 * h + e] : 0.f, x1 = t < p.tk ? s[(long)t * C + 16 * kk + 8 * h + e + 1] : 0.f;
-        const unsigned short h0 = f2bf(x0), h1 = f2bf(x1);
+        const unsigned short h0 = f2bf(x[e]), h1 = f2bf(x[e + 1]);
         hw[e >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
-        lw[e >> 1] = (unsigned)f2bf(x0 - bf2f(h0)) | ((unsigned)f2bf(x1 - bf2f(h1)) << 16);
+        lw[e >> 1] = (unsigned)f2bf(x[e] - bf2f(h0)) | ((unsigned)f2bf(x[e + 1] - bf2f(h1)) << 16);
       }
       *reinterpret_cast<uint4*>(hiF + f * 8) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
       *reinterpret_cast<uint4*>(loF + f * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
     }
     {   // TF piece f = ((j*2 + kk)*2 + h)*32 + c
       const int c = (int)(f & 31), h = (int)((f >> 5) & 1), kk = (int)((f >> 6) & 1), j = (int)(f >> 7);
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int t = 16 * kk + 4 * h + (e & 3) + 8 * (e >> 2);
+        x[e] = s[(long)(t < p.tk ? t : 0) * C + 32 * j + c];
+      }
       unsigned w[4];
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
-        const int t0 = 16 * kk + 4 * h + (e & 3) + 8 * (e >> 2), t1 = t0 + 1;
-        const float x0 = t0 < p.tk ? s[(long)t0 * C + 32 * j + c] : 0.f, x1 = t1 < p.tk ? s[(long)t1 * C + 32 * j + c] : 0.f;
-        w[e >> 1] = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+        const int t0 = 16 * kk + 4 * h + (e & 3) + 8 * (e >> 2);
+        w[e >> 1] = (unsigned)f2bf(t0 < p.tk ? x[e] : 0.f) | ((unsigned)f2bf(t0 + 1 < p.tk ? x[e + 1] : 0.f) << 16);
       }
       *reinterpret_cast<uint4*>(TF + f * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -1025,17 +1035,33 @@ __global__ __launch_bounds__(256) void tokattn_fwd_small_k(const TFS2Args p) {
     for (int j = 0; j < CS2 / 32; ++j) {
       if (j >= nt) break;
       const int c = c0 + 32 * j + (lane & 31);
-      float v[16];
+      float v[16], t0[16];
+      // unconditional loads from clamped rows, select afterwards: `tt < tk ? T0[..] : 0` compiles to branch + load +
+      // s_waitcnt vmcnt(0) PER ELEMENT (the hipcc pitfall of gemm.hip's guarded staging): 16 serial L2 round trips per
+      // tile were 30 of this kernel's 56 us at N = 144, C = 512 and 57 of 80 us at N = 36, C = 1024
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const int tt = mt_row(r, lane); t0[r] = p.T0[(long)(tt < p.tk ? tt : 0) * C + c]; }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tt = mt_row(r, lane);
-        v[r] = tt < p.tk ? p.T0[(long)tt * C + c] + o[j][r] * sl[tt] : 0.f;
+        v[r] = tt < p.tk ? t0[r] + o[j][r] * sl[tt] : 0.f;
         if (tt < p.tk) p.tok[((long)b * p.tk + tt) * C + c] = v[r];
         const unsigned short h = f2bf(v[r]);
-        const long fo = (((long)(c >> 4) * 2 + ((c >> 3) & 1)) * 32 + tt) * 8 + (c & 7);     // hiF / loF element of tok[tt][c]
-        hiF[fo] = h;
-        loF[fo] = f2bf(v[r] - bf2f(h));
+        // hi / lo of tok[tt][c] -> [tt][32 channels] images in the wave's (now free) slab image; whole 16-byte fragment
+        // pieces leave below (2-byte scattered global stores, 32 per lane and tile, were ~10 us of this kernel)
+        *reinterpret_cast<unsigned short*>(img + tt * 80 + (lane & 31) * 2) = h;
+        *reinterpret_cast<unsigned short*>(img + 2560 + tt * 80 + (lane & 31) * 2) = f2bf(v[r] - bf2f(h));
       }
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = lane + 64 * i, tt = q & 31, h8 = q >> 5;             // piece: token tt, channels 8 h8 .. + 7 of this tile
+        const int cc = c0 + 32 * j + 8 * h8;
+        const long fo = (((long)(cc >> 4) * 2 + ((cc >> 3) & 1)) * 32 + tt) * 8;
+        *reinterpret_cast<uint4*>(hiF + fo) = *reinterpret_cast<const uint4*>(img + tt * 80 + h8 * 16);
+        *reinterpret_cast<uint4*>(loF + fo) = *reinterpret_cast<const uint4*>(img + 2560 + tt * 80 + h8 * 16);
+      }
+      wave_sync();
       // TF pieces (tile j of this slab, kk = 0 / 1, lane): the lane's registers [8 kk, 8 kk + 8) ARE the piece
       unsigned short* tf = TFo + (((long)((c0 >> 5) + j) * 2) * 64 + lane) * 8;
       *reinterpret_cast<uint4*>(tf) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
