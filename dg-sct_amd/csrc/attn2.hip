@@ -70,6 +70,18 @@ __device__ __forceinline__ void slab_store_lds(const Slab& s, char* img, int row
 // private image rows -> token-major global rows (16-byte stores); `add` (same layout as dst) optional
 __device__ __forceinline__ void slab_copy_out(const char* img, unsigned short* dst, const unsigned short* add, long ld, int rows_valid,
                                               int c0, int C, int lane) {
+  // the optional addend is fetched up front, unconditionally, from clamped addresses: loaded inside the per-chunk
+  // `if (valid) { if (add) ... }` it was one exposed round trip per chunk (8 per slab)
+  uint4 av[8];
+  if (add) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = i * 64 + lane, r = idx >> 4, c = (idx & 15) * 8;
+      const int rr = r < rows_valid ? r : rows_valid - 1;
+      const int cc = c0 + c < C ? c0 + c : C - 8;
+      av[i] = *reinterpret_cast<const uint4*>(add + (long)rr * ld + cc);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = i * 64 + lane, r = idx >> 4, c = (idx & 15) * 8;
@@ -79,7 +91,7 @@ __device__ __forceinline__ void slab_copy_out(const char* img, unsigned short* d
     if (add) {
       float x[8], y[8];
       unpack<DT_BF16, 8>(v, x);
-      unpack<DT_BF16, 8>(*reinterpret_cast<const uint4*>(add + o), y);
+      unpack<DT_BF16, 8>(av[i], y);
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] += y[e];
       stv<DT_BF16, 8>(dst, o, x);
