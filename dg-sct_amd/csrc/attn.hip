@@ -444,6 +444,13 @@ __global__ __launch_bounds__(256) void tokattn_bwd_k(const TokBwdArgs p) {
     const bool nvalid = n0 + 32 * wave + (lane & 31) < p.N;
     char* prow = sP + (32 * wave + (lane & 31)) * PP;
     char* drow = sdS + (32 * wave + (lane & 31)) * PP;
+    float lser[16], Dr[16];            // statistics first, unconditionally (a load inside `ok ? .. : 0` is a serialised round trip each)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), tc = t < p.tk ? t : 0;
+      lser[r] = p.lse[(long)b * p.tk + tc];
+      Dr[r] = p.D[(long)b * p.tk + tc];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float pv[4], dv[4];
@@ -451,10 +458,9 @@ __global__ __launch_bounds__(256) void tokattn_bwd_k(const TokBwdArgs p) {
       for (int e = 0; e < 4; ++e) {
         const int t = 8 * q + 4 * (lane >> 5) + e;
         const bool ok = nvalid && t < p.tk;
-        const int tc = t < p.tk ? t : 0;
-        const float pr = ok ? mexp<MODE>(aS[4 * q + e] - p.lse[(long)b * p.tk + tc]) : 0.f;
+        const float pr = ok ? mexp<MODE>(aS[4 * q + e] - lser[4 * q + e]) : 0.f;
         pv[e] = pr;
-        dv[e] = ok ? pr * (aD[4 * q + e] - p.D[(long)b * p.tk + tc]) : 0.f;
+        dv[e] = ok ? pr * (aD[4 * q + e] - Dr[4 * q + e]) : 0.f;
       }
       stv<MODE, 4>(prow, 8 * q + 4 * (lane >> 5), pv);
       stv<MODE, 4>(drow, 8 * q + 4 * (lane >> 5), dv);
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(256) void tokattn_bwd_k(const TokBwdArgs p) {
         mma_tile<MODE, true, false>(o, sP, PP, 32 * wave, sG, PTB, 32 * jj, 32, lane);
         mma_tile<MODE, true, false>(o, sdS, PP, 32 * wave, sT, PTB, 32 * jj, 32, lane);
         const int c = 32 * jj + (lane & 31);
-        const float bias = cs + c < p.C ? p.da[(long)b * p.C + cs + c] * p.invN : 0.f;
+        const float bias = p.da[(long)b * p.C + (cs + c < p.C ? cs + c : p.C - 1)] * p.invN;      // unconditional, clamped (columns >= C are never copied out)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ste<MODE>(sY + (32 * wave + mt_row(r, lane)) * PS, c, o[r] + bias);
       }

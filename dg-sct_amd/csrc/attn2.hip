@@ -506,13 +506,17 @@ __global__ __launch_bounds__(256) void tokattn_bwd2_k(const TB2Args p) {
   const bool nvalid = active && (lane & 31) < rows;
   float pv[16], dv[16];
 #pragma unroll
+  for (int r = 0; r < 16; ++r) {          // statistics first, unconditionally (a load inside `ok ? .. : 0` is a serialised round trip each)
+    const int t = mt_row(r, lane), tc = t < p.tk ? t : 0;
+    pv[r] = p.lse[(long)b * p.tk + tc];
+    dv[r] = p.D[(long)b * p.tk + tc];
+  }
+#pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int t = mt_row(r, lane);
-    const bool ok = nvalid && t < p.tk;
-    const int tc = t < p.tk ? t : 0;
-    const float pr = ok ? __expf(aS[r] - p.lse[(long)b * p.tk + tc]) : 0.f;
+    const bool ok = nvalid && mt_row(r, lane) < p.tk;
+    const float pr = ok ? __expf(aS[r] - pv[r]) : 0.f;
+    dv[r] = ok ? pr * (aD[r] - dv[r]) : 0.f;
     pv[r] = pr;
-    dv[r] = ok ? pr * (aD[r] - p.D[(long)b * p.tk + tc]) : 0.f;
   }
   const bfx8 pb0 = regs_frag(pv), pb1 = regs_frag(pv + 8), db0 = regs_frag(dv), db1 = regs_frag(dv + 8);
   regs_to_img(dv, imgS, lane);
@@ -826,13 +830,17 @@ __global__ __launch_bounds__(256) void tokattn_bwd3_k(const TB2Args p) {
   const bool nvalid = (lane & 31) < rows;
   float pv[16], dv[16];
 #pragma unroll
+  for (int r = 0; r < 16; ++r) {          // statistics first, unconditionally (a load inside `ok ? .. : 0` is a serialised round trip each)
+    const int t = mt_row(r, lane), tc = t < p.tk ? t : 0;
+    pv[r] = p.lse[(long)b * p.tk + tc];
+    dv[r] = p.D[(long)b * p.tk + tc];
+  }
+#pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int t = mt_row(r, lane);
-    const bool ok = nvalid && t < p.tk;
-    const int tc = t < p.tk ? t : 0;
-    const float pr = ok ? __expf(aS[r] - p.lse[(long)b * p.tk + tc]) : 0.f;
+    const bool ok = nvalid && mt_row(r, lane) < p.tk;
+    const float pr = ok ? __expf(aS[r] - pv[r]) : 0.f;
+    dv[r] = ok ? pr * (aD[r] - dv[r]) : 0.f;
     pv[r] = pr;
-    dv[r] = ok ? pr * (aD[r] - p.D[(long)b * p.tk + tc]) : 0.f;
   }
   const bfx8 pb0 = regs_frag(pv), pb1 = regs_frag(pv + 8), db0 = regs_frag(dv), db1 = regs_frag(dv + 8);
   regs_to_img(dv, imgS, lane);
