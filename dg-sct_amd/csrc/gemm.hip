@@ -606,8 +606,34 @@ void gemm_kernel(const GemmK p) {
     constexpr int CPR = TN * 4;                         // 8-column chunks per row
     float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SP);
     const int ncol0 = n0 + wn * TN * 32;
+    // Loads of the epilogue are issued up front, unconditionally, from clamped indices: inside the per-element / per-chunk
+    // conditionals below each one was a branch + load + s_waitcnt vmcnt(0) (16 serial round trips per tile for the rank-1
+    // row factor of the remap bias, one per chunk for the residual).  Register budget: the residual prefetch only where the
+    // variant has room (the 128 x 128 tiles at 3 workgroups per CU spilled with it).
+    constexpr bool PRE_R_OK = TM * TN < 4 || (TM * TN == 4 && AK != BK && STAGE != 2);
+    const bool pre_r = PRE_R_OK && Rb && !R2b && p.rdt == DT_BF16;   // residual rows as 16-byte chunks (the common case: dX1 += ...)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float r1m[16];
+      if (p.r1_m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          m = m < p.M ? m : p.M - 1;
+          r1m[r] = p.r1_m[p.m_mod > 0 ? m % p.m_mod : m];
+        }
+      }
+      uint4 rpre[PRE_R_OK ? (32 * CPR) / 64 : 1];
+      if (pre_r) {
+#pragma unroll
+        for (int it = 0; it < (PRE_R_OK ? (32 * CPR) / 64 : 1); ++it) {
+          const int c = it * 64 + lane;
+          int m = m0 + (wm * TM + i) * 32 + c / CPR, n = ncol0 + (c % CPR) * 8;
+          m = m < p.M ? m : p.M - 1;
+          n = n + 8 <= p.N ? n : (p.N >= 8 ? p.N - 8 : 0);
+          rpre[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(Rb) + (long)m * p.ldr + n);
+        }
+      }
       __syncthreads();                                  // operand tiles / previous block fully consumed
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -618,12 +644,11 @@ void gemm_kernel(const GemmK p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int m = m0 + (wm * TM + i) * 32 + row;
           float v = alpha * acc[i][j][r] + bn;
-          if ((p.bias_m || p.r1_m) && m < p.M) {
-            const int mm = p.m_mod > 0 ? m % p.m_mod : m;
-            if (p.bias_m) v += p.bias_m[mm];
-            if (p.r1_m) v += p.r1_m[mm] * r1n;
+          if (p.r1_m) v += r1m[r] * r1n;
+          if (p.bias_m) {                               // (no caller in the adapter schedule: left as a guarded load)
+            const int m = m0 + (wm * TM + i) * 32 + row;
+            if (m < p.M) v += p.bias_m[p.m_mod > 0 ? m % p.m_mod : m];
           }
           if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
           else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
@@ -631,7 +656,7 @@ void gemm_kernel(const GemmK p) {
         }
       }
       __syncthreads();
-#pragma unroll 3
+#pragma unroll
       for (int it = 0; it < (32 * CPR) / 64; ++it) {
         const int c = it * 64 + lane;
         const int row = c / CPR, cc = c % CPR;
@@ -646,7 +671,12 @@ void gemm_kernel(const GemmK p) {
         }
         const long od = (long)m * p.ldd + n;
         if (n + 8 <= p.N) {
-          if (Rb) {
+          if (pre_r) {
+            float rv[8];
+            unpack<DT_BF16, 8>(rpre[PRE_R_OK ? it : 0], rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += p.beta * rv[e];
+          } else if (Rb) {
             float rv[8];
             const long orr = (long)m * p.ldr + n;
             if (p.rdt == DT_F32) ldv<DT_F32, 4>(Rb, orr, *reinterpret_cast<float(*)[4]>(rv)), ldv<DT_F32, 4>(Rb, orr + 4, *reinterpret_cast<float(*)[4]>(rv + 4));
