@@ -110,6 +110,12 @@ __device__ __forceinline__ void stv(void* p, long i, const float (&v)[VE]) {
     }
   }
 }
+// run-time element type, ONE branch around a vector load (lde_rt per element is a branch + load + wait each)
+template <int VE>
+__device__ __forceinline__ void ldv_rt(const void* p, int dt, long i, float (&v)[VE]) {
+  if (dt == DT_F32) ldv<DT_F32, VE>(p, i, v);
+  else ldv<DT_BF16, VE>(p, i, v);
+}
 // raw (still packed) VE-element vector in a uint4 -- lets a kernel issue next-row loads early at 4 registers apiece
 template <int DT, int VE>
 __device__ __forceinline__ uint4 ldraw(const void* p, long i) {

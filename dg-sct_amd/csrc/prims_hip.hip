@@ -734,10 +734,12 @@ __global__ __launch_bounds__(256) void rowdot_k(const void* x, long ld, long bs,
   for (int v = 0; v < MAXNV; ++v) {
     const int col = (v * gs + gl) * VE;
     if (v < nv && col < C) {
+      ldv_rt<VE>(w, wdt, (long)b * w_bs + col, ww[v]);
+      if (w2) {
+        float t2[VE];
+        ldv<DT_F32, VE>(w2, col, t2);
 #pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        ww[v][e] = lde_rt(w, wdt, (long)b * w_bs + col + e);
-        if (w2) ww[v][e] *= w2[col + e];
+        for (int e = 0; e < VE; ++e) ww[v][e] *= t2[e];
       }
     }
   }

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long
     if (!(tr < rpp && vc < nvr)) continue;
     float a[VE], bsh[VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) { a[e] = sc ? sc[vc * VE + e] : 1.f; bsh[e] = sc ? sh[vc * VE + e] : 0.f; }
+    for (int e = 0; e < VE; ++e) { a[e] = 1.f; bsh[e] = 0.f; }
+    if (sc) { ldv<DT_F32, VE>(sc, vc * VE, a); ldv<DT_F32, VE>(sh, vc * VE, bsh); }      // one branch, vector loads
     for (long r = r_begin + tr; r < r_end; r += (long)rpp * UNR) {
       float t[UNR][VE];
 #pragma unroll
@@ -512,10 +513,14 @@ __global__ __launch_bounds__(256) void relu_bwd_scale_k(const void* x, void* y, 
     for (int e = 0; e < VE; ++e) acc[0][e] = 0.f;
     if (active) {
       float cw[VE];
+      ldv_rt<VE>(colw, cdt, (long)b * C + vc * VE, cw);
 #pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        const int c = vc * VE + e;
-        cw[e] = scale * lde_rt(colw, cdt, (long)b * C + c) * (colw2 ? colw2[c] : 1.f);
+      for (int e = 0; e < VE; ++e) cw[e] *= scale;
+      if (colw2) {
+        float t2[VE];
+        ldv<DT_F32, VE>(colw2, vc * VE, t2);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) cw[e] *= t2[e];
       }
       for (long n = r_begin + tr; n < r_end; n += (long)rpp * UNR) {
         float t[UNR][VE], rw[UNR];
