@@ -733,6 +733,8 @@ __global__ __launch_bounds__(256) void rowdot_k(const void* x, long ld, long bs,
 #pragma unroll
   for (int v = 0; v < MAXNV; ++v) {
     const int col = (v * gs + gl) * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) ww[v][e] = 0.f;              // columns past C weigh nothing: the row loop loads them clamped
     if (v < nv && col < C) {
       ldv_rt<VE>(w, wdt, (long)b * w_bs + col, ww[v]);
       if (w2) {
@@ -749,9 +751,9 @@ __global__ __launch_bounds__(256) void rowdot_k(const void* x, long ld, long bs,
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
-      if (v < nv && col < C) {
+      if (v < nv) {                                           // (uniform; the lane-dependent `col < C` made each load a wait)
         float t[VE];
-        ldv<DT, VE>(x, (long)b * bs + (long)n * ld + col, t);
+        ldv<DT, VE>(x, (long)b * bs + (long)n * ld + (col < C ? col : 0), t);
 #pragma unroll
         for (int e = 0; e < VE; ++e) s += t[e] * ww[v][e];
       }
@@ -1097,17 +1099,27 @@ __global__ __launch_bounds__(256) void cvt_multi_k(const CvtTable t) {
     const long cols = sg.tr_cols, rows = sg.n / cols, tcols = (cols + 63) / 64;
     const long r0 = (blk / tcols) * 64, c0 = (blk % tcols) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int k = ty; k < 64; k += 4) tile[k][tx] = (r0 + k < rows && c0 + tx < cols) ? sg.src[(r0 + k) * cols + c0 + tx] : 0.f;
+    {   // 16 loads in flight (clamped, unconditional: inside the bounds test each was a serialised round trip)
+      float v[16];
+      const long cc = c0 + tx < cols ? c0 + tx : cols - 1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const long rr = r0 + ty + 4 * i < rows ? r0 + ty + 4 * i : rows - 1; v[i] = sg.src[rr * cols + cc]; }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tile[ty + 4 * i][tx] = v[i];
+    }
     __syncthreads();
     for (int k = ty; k < 64; k += 4)
       if (c0 + k < cols && r0 + tx < rows) ste_rt(sg.dst, sg.odt, (c0 + k) * rows + r0 + tx, tile[tx][k]);
     return;
   }
   const long base = blk * 2048;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const long i = base + k * 256 + threadIdx.x; v[k] = sg.src[i < sg.n ? i : sg.n - 1]; }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const long i = base + k * 256 + threadIdx.x;
-    if (i < sg.n) ste_rt(sg.dst, sg.odt, i, sg.src[i]);
+    if (i < sg.n) ste_rt(sg.dst, sg.odt, i, v[k]);
   }
 }
 void cvt_multi(const Ctx& ctx, const CvtSeg* segs, int nseg) {
