@@ -751,9 +751,9 @@ __global__ __launch_bounds__(256) void rowdot_k(const void* x, long ld, long bs,
 #pragma unroll
     for (int v = 0; v < MAXNV; ++v) {
       const int col = (v * gs + gl) * VE;
-      if (v < nv) {                                           // (uniform; the lane-dependent `col < C` made each load a wait)
+      {                                                       // no condition at all: vectors past nv / C load column 0 and weigh 0
         float t[VE];
-        ldv<DT, VE>(x, (long)b * bs + (long)n * ld + (col < C ? col : 0), t);
+        ldv<DT, VE>(x, (long)b * bs + (long)n * ld + ((v < nv && col < C) ? col : 0), t);
 #pragma unroll
         for (int e = 0; e < VE; ++e) s += t[e] * ww[v][e];
       }
