@@ -354,6 +354,10 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const void* dy, const void
   }
 }
 
+static inline long strip_part_min() {      // tuning hook: below this many atomics the extra finishing launch costs more (A/B: tools/ab_partmin.sh)
+  static const long v = getenv("DGSCT_STRIP_PART_MIN") ? atol(getenv("DGSCT_STRIP_PART_MIN")) : 150000;
+  return v;
+}
 static inline bool strip_part() {
   static const bool on = !(getenv("DGSCT_ROW_PART") && atoi(getenv("DGSCT_ROW_PART")) == 0);
   return on;
@@ -363,7 +367,7 @@ void bn_bwd_stats(const Ctx& ctx, const void* dy, const void* x, long rows, int 
   const int ve = col_ve(ctx, C);
   ColGeom g = col_geom(UNR2, C, ve, rows, 1, 768);
   // (workgroups x channels of atomics below ~150 k cost less than the finishing launch: measured 9.9 -> 9.0 + 4.7 us)
-  if (!strip_part() || (long)g.chunks * 2 * C > part_floats || (long)g.chunks * 2 * C < 150000) part = nullptr;
+  if (!strip_part() || (long)g.chunks * 2 * C > part_floats || (long)g.chunks * 2 * C < strip_part_min()) part = nullptr;
   COL_DISPATCH(ctx, ve, bn_bwd_stats_k, dim3(g.chunks), strip_lds(C, ve), dy, x, rows, C, mean, rstd, sc, sh, relu,
                g.tpr, g.rpp, g.rpc, sums, part);
   if (part) {
@@ -559,7 +563,7 @@ void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C,
   if (colsum_out) COL_CAPACITY(cap, ctx, ve, relu_bwd_scale_k, strip_lds(C, ve));
   ColGeom g = col_geom(UNR1, C, ve, N, B, cap, colsum_out != nullptr);
   // partial sums pay from ~150 k atomics up (480 workgroups x 512 channels: 26.1 -> 16.4 + 4.7 us; x 128 channels: no gain)
-  if (!colsum_out || !strip_part() || (long)g.chunks * B * C > part_floats || (long)g.chunks * B * C < 150000) part = nullptr;
+  if (!colsum_out || !strip_part() || (long)g.chunks * B * C > part_floats || (long)g.chunks * B * C < strip_part_min()) part = nullptr;
   COL_DISPATCH(ctx, ve, relu_bwd_scale_k, dim3(g.chunks, B), strip_lds(C, ve), x, y, N, C, g.tpr, g.rpp, g.rpc, roww,
                colw, cdt, colw2, scale, colsum_out, part);
   if (part) {
