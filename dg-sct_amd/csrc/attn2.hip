@@ -913,7 +913,10 @@ static bool tokattn_bwd3_launch(const Ctx& ctx, TB2Args a, int B) {
 // tokattn_bwd: against the generic kernel (one workgroup per 128 rows) the C-split one pays 2-5x the fp32 atomics of
 // d my_tokens (one contribution per 32-row block: 25 of its 89 us at N = 144, C = 512, measured by switching them off) -- it
 // wins only where the slab chain is long: 126 -> 105 us at N = 36, C = 1024; 99 -> 94 at N = 64, C = 768
-bool tokattn_bwd_csplit(int B, int N, int C) { return C >= 768 && csplit_ok(B, N, C, 3); }
+bool tokattn_bwd_csplit(int B, int N, int C) {
+  static const int min_c = getenv("DGSCT_TOKBWD_CSPLIT_MINC") ? atoi(getenv("DGSCT_TOKBWD_CSPLIT_MINC")) : 768;
+  return C >= min_c && csplit_ok(B, N, C, 3);
+}
 
 // ====================================================================================================================
 // tokattn_fwd for short frames (N <= 256: the stage-2/3 shapes, 32 of the 48 adapter calls of the AVE stack): ONE workgroup
