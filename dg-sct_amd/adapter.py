@@ -84,6 +84,12 @@ class VisualAdapter(nn.Module):
             # (SURVEY 8a-1); anything else raises exactly like the reference (:549-550).
             raise NotImplementedError(f"adapter_kind={adapter_kind!r} with is_multimodal={self.is_multimodal} is not on the "
                                       f"DG-SCT hot path")
+        if not 1 <= self.num_tk <= 32:
+            # the latent tokens of a frame are ONE 32-row MFMA tile in the fused attention kernels (csrc/attn*.hip).  Every
+            # reference launcher passes --num_tokens <= 32 (AVE/AVVP train.sh: 32, AVS: 32, AVQA: 2); the constructor default
+            # of the reference (87) is never used by a script.  Fail here, with the reason, not inside dgsct_query.
+            raise ValueError(f"dg-sct_amd: num_tokens={self.num_tk} is outside the supported range 1..32 (latent tokens of a frame "
+                             f"are held in one 32-row MFMA tile); see INTEGRATION.md 'Limits'")
         if input_dim != output_dim or linear_out != input_dim:
             raise ValueError("DG-SCT adapters have input_dim == output_dim == linear_out")
         C, d_model = linear_out, linear_out // 2
@@ -139,17 +145,52 @@ class VisualAdapter(nn.Module):
         self._prep_cache = None
 
     # ------------------------------------------------------------------
+    def _lookup(self, name: str) -> Optional[torch.Tensor]:
+        """Resolve a reference parameter / buffer name by ATTRIBUTE walk, not through named_parameters(): on an
+        nn.DataParallel replica (torch.nn.parallel.replicate: reference AVS/AVQA call path, avs_s4/train.py:139,
+        main_avst.py:236) ``_parameters`` is empty and the broadcast copies are plain tensor attributes."""
+        if self.__dict__.get("_is_replica", False) and name in self.__dict__.get("_flat_layout", {}):
+            return self._replica_flat_views()[name]
+        obj = self
+        for part in name.split("."):
+            try:
+                obj = getattr(obj, part)
+            except AttributeError:
+                return None
+            if obj is None:
+                return None
+        return obj if isinstance(obj, torch.Tensor) else None
+
+    def _replica_flat_views(self):
+        """flat mode on a DataParallel replica: per-name views of THIS replica's copy of ``flat_param`` (the views the
+        original module planted on its sub-modules point at the original's device)."""
+        flat = self.flat_param
+        c = self.__dict__.get("_rviews")
+        if c is None or c[0] is not flat:
+            d = flat.detach()
+            c = (flat, {name: d[off:off + n].view(shape) for name, (off, n, shape) in self._flat_layout.items()})
+            self.__dict__["_rviews"] = c
+        return c[1]
+
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel replicas are shallow ``__dict__`` copies: give each its own caches (the parameter table holds
+        tensors of the original's device; the prepared weights belong to the original's parameters)."""
+        replica = super()._replicate_for_data_parallel()
+        for k in ("_ptab", "_rviews"):
+            replica.__dict__.pop(k, None)
+        replica.__dict__["_prep_cache"] = None
+        return replica
+
     def _param_list(self) -> List[Optional[torch.Tensor]]:
-        """parameter table in C-ABI order; the name -> tensor resolution is done once (Parameters keep their identity
-        across .to()/.load_state_dict(); the 2-D views of the conv weights are re-made when their storage moves)."""
-        cache = self.__dict__.get("_ptab")
+        """parameter table in C-ABI order; the name -> tensor resolution is done once per module object (Parameters keep
+        their identity across .to()/.load_state_dict(); the 2-D views of the conv weights are re-made when their storage
+        moves).  Replicas resolve on every call: their tensors are re-broadcast each forward."""
+        replica = self.__dict__.get("_is_replica", False)
+        cache = None if replica else self.__dict__.get("_ptab")
         if cache is None:
-            sd = dict(self.named_parameters())
-            sd.update(dict(self.named_buffers()))
-            sd.update(self.__dict__.get("_flat_views", {}))
             cache = []
             for name in PARAM_NAMES:
-                t = sd.get(name)
+                t = self._lookup(name)
                 view = None
                 if name == "conv_adapter.weight":
                     if self.spec.remap == "bicubic":
@@ -165,7 +206,8 @@ class VisualAdapter(nn.Module):
                 elif name.startswith("ln_before") and not self.spec.ln_before:
                     t = None
                 cache.append([t, view, None, 0])
-            self.__dict__["_ptab"] = cache
+            if not replica:
+                self.__dict__["_ptab"] = cache
         out: List[Optional[torch.Tensor]] = []
         for ent in cache:
             t, view = ent[0], ent[1]

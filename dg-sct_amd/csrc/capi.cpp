@@ -11,6 +11,10 @@
 
 using namespace dgsct;
 
+// Entry of every call: forget this thread's previous dgsct error AND any stale sticky HIP error another library (PyTorch)
+// left on the thread, so that check_async() at the end reports only what THIS call raised.
+static inline void begin_call() { clear_error(); clear_async(); }
+
 extern "C" {
 
 int dgsct_version(void) { return DGSCT_VERSION; }
@@ -18,7 +22,7 @@ const char* dgsct_arch(void) { return "gfx950"; }
 const char* dgsct_last_error(void) { return last_error(); }
 
 int dgsct_query(const dgsct_adapter_desc* desc, dgsct_sizes* out) {
-  clear_error();
+  begin_call();
   if (!desc || !out) { set_error("dgsct_query: NULL argument"); return 2; }
   Plan p(*desc);
   if (!p.ok) return 2;
@@ -32,7 +36,7 @@ int dgsct_query(const dgsct_adapter_desc* desc, dgsct_sizes* out) {
 }
 
 int dgsct_prepare(const dgsct_adapter_desc* desc, float* const* params, void* prep, void* stream) {
-  clear_error();
+  begin_call();
   if (!desc || !params || !prep) { set_error("dgsct_prepare: NULL argument"); return 2; }
   Plan p(*desc);
   if (!p.ok) return 2;
@@ -41,7 +45,7 @@ int dgsct_prepare(const dgsct_adapter_desc* desc, float* const* params, void* pr
 
 int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
                           const void* Y, void* out, float* map, float* tmap, void* saved, void* ws, void* stream) {
-  clear_error();
+  begin_call();
   if (!desc || !params || !prep || !X || !Y || !out || !map || !saved || !ws) {
     set_error("dgsct_adapter_forward: NULL argument");
     return 2;
@@ -54,7 +58,7 @@ int dgsct_adapter_forward(const dgsct_adapter_desc* desc, float* const* params, 
 int dgsct_adapter_forward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
                              const void* Y, const void* residual, void* out, float* map, float* tmap, void* saved, void* ws,
                              void* stream, void* aux_stream) {
-  clear_error();
+  begin_call();
   if (!desc || !params || !prep || !X || !Y || !out || !map || !saved || !ws) {
     set_error("dgsct_adapter_forward_ex: NULL argument");
     return 2;
@@ -78,7 +82,7 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
                               const void* Y, const void* saved, const void* dOut, const float* dMap, const float* dTmap,
                               void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream,
                               int skip_into_dx) {
-  clear_error();
+  begin_call();
   if (!desc || !params || !prep || !X || !Y || !saved || !dOut || !dX || !dY || !grads || !ws) {
     set_error("dgsct_adapter_backward: NULL argument");
     return 2;
@@ -89,7 +93,7 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
 }
 
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes) {
-  clear_error();
+  begin_call();
   if (!desc) return 2;
   Plan p(*desc, true);
   if (!p.ok) return 2;
@@ -102,14 +106,14 @@ int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int na
 }
 
 int dgsct_stream_create(int priority_class, void** stream) {
-  clear_error();
+  begin_call();
   if (!stream) return 2;
   *stream = stream_create(priority_class);
   return has_error() ? 1 : 0;
 }
 
 int dgsct_stream_destroy(void* stream) {
-  clear_error();
+  begin_call();
   stream_destroy(stream);
   return has_error() ? 1 : 0;
 }
@@ -123,7 +127,7 @@ static int pool_args_ok(int dtype, int BT, int N, int C, const void* F, const fl
 }
 
 int dgsct_map_pool_forward(int dtype, int BT, int N, int C, const void* F, const float* map, float* pooled, void* stream) {
-  clear_error();
+  begin_call();
   if (!pool_args_ok(dtype, BT, N, C, F, map) || !pooled) { if (!has_error()) set_error("map_pool: pooled is null"); return 2; }
   Ctx ctx{stream, dtype};
   zero(ctx, pooled, (size_t)BT * C * sizeof(float));
@@ -133,7 +137,7 @@ int dgsct_map_pool_forward(int dtype, int BT, int N, int C, const void* F, const
 
 int dgsct_map_pool_backward(int dtype, int BT, int N, int C, const void* F, const float* map, const float* dPooled,
                             void* dF, float* dMap, void* stream) {
-  clear_error();
+  begin_call();
   if (!pool_args_ok(dtype, BT, N, C, F, map) || !dPooled) { if (!has_error()) set_error("map_pool: dPooled is null"); return 2; }
   Ctx ctx{stream, dtype};
   if (dF) outer_rows(ctx, map, dPooled, BT, N, C, dF);
@@ -144,7 +148,7 @@ int dgsct_map_pool_backward(int dtype, int BT, int N, int C, const void* F, cons
 int dgsct_temporal_gate_forward(int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
                                 const float* wa, const float* ba, const float* wv, const float* bv, float* out_v, float* out_a,
                                 float* gate, float* ga, float* gv, void* stream) {
-  clear_error();
+  begin_call();
   if (!akv || !vkv || !vq || !aq || !wa || !ba || !wv || !bv || !out_v || !out_a || !gate || !ga || !gv) {
     set_error("dgsct_temporal_gate_forward: NULL argument");
     return 2;
@@ -158,7 +162,7 @@ int dgsct_temporal_gate_backward(int R, int D, float gamma, const float* akv, co
                                  const float* wa, const float* wv, const float* ga, const float* gv, const float* dOv,
                                  const float* dOa, const float* dg, float* dakv, float* dvkv, float* dvq, float* daq, float* dwa,
                                  float* dba, float* dwv, float* dbv, void* stream) {
-  clear_error();
+  begin_call();
   if (!akv || !vkv || !vq || !aq || !wa || !wv || !ga || !gv || !dOv || !dOa || !dakv || !dvkv || !dvq || !daq || !dwa || !dba ||
       !dwv || !dbv) {
     set_error("dgsct_temporal_gate_backward: NULL argument");
@@ -171,7 +175,7 @@ int dgsct_temporal_gate_backward(int R, int D, float gamma, const float* akv, co
 }
 
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
-  clear_error();
+  begin_call();
   if (!a) return 2;
   Ctx ctx{stream, a->mode};
   Gemm g;
@@ -193,7 +197,7 @@ int64_t dgsct_test_attn_scratch_floats(int B, int N, int C, int tk) {
   return tokattn_scratch_floats(B, N, C) + (int64_t)B * tk + 64;
 }
 int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream) {
-  clear_error();
+  begin_call();
   if (!a) return 2;
   Ctx ctx{stream, a->mode};
   switch (op) {
@@ -211,7 +215,7 @@ int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream) {
 
 int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, const float* bias, int relu, void* D, void* w8,
                         float* scale, void* stream) {
-  clear_error();
+  begin_call();
   if (!A || !W || !D || !w8 || !scale) { set_error("dgsct_test_gemm_fp8: NULL argument"); return 2; }
   Ctx ctx{stream, DT_BF16};
   fp8_quantize(ctx, W, (long)N * K, w8, scale, scale + 1);

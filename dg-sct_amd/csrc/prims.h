@@ -33,6 +33,8 @@ void stream_fork(const Ctx&);
 void stream_join(const Ctx&);
 // report (through set_error) the first failed kernel launch / runtime call of this thread since the last check
 void check_async(const char* where);
+// drop a stale sticky runtime error of this thread (left by another HIP user) before a call starts
+void clear_async();
 
 // One GEMM operand X[r][k] (r = M- or N-index, k = contraction index), element type E.
 //   kmajor = 1 : &X[r][k] = p + r*ld + k     (k contiguous)

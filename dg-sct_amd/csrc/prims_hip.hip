@@ -59,6 +59,7 @@ void check_async(const char* where) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) set_error("%s: HIP error '%s' (is the current device the one that owns the buffers and streams?)", where, hipGetErrorString(e));
 }
+void clear_async() { (void)hipGetLastError(); }
 void* stream_create(int priority_class) {
   int least = 0, greatest = 0;                       // numerically: the greatest priority is the SMALLER number
   hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);

@@ -58,6 +58,10 @@ class GradAllReducer:
         self.buckets = [b for b in self.buckets if b]
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._sent: List[set] = [set() for _ in self.buckets]      # id(param) of the gradients a launched bucket has sent
+        self._late: List[list] = [[] for _ in self.buckets]        # parameters whose FIRST gradient came after the launch
+        self._dirty = [False] * len(self.buckets)       # a gradient that was already sent was accumulated into again
+        self.relaunches = 0                             # buckets that needed a second collective in finish() (late gradients)
         # Gradients a bucket must have seen before it may launch.  Not len(bucket): some parameters never receive one
         # (`gate_tk` in the ave/avvp/pretrain flavours, `conv_adapter.*` with the bicubic remap, `fc_caption.*`, ... --
         # SURVEY.md 8c), so their post-accumulate hooks never fire.  The first step counts who does (every rank runs the
@@ -90,6 +94,15 @@ class GradAllReducer:
                 # of one per gradient: every cross-stream event costs the recording stream a barrier packet)
                 self._producers[bi].add(torch.cuda.current_stream(param.grad.device))
             self._pending[bi] += 1
+            if self._launched[bi]:
+                # more gradient events than last step (the count the launch was keyed on): a parameter that only sometimes
+                # gets a gradient is simply reduced later by finish(); one whose gradient is ALREADY in flight has just been
+                # accumulated into under the collective -- that cannot be repaired, finish() raises
+                if id(param) in self._sent[bi]:
+                    self._dirty[bi] = True
+                else:
+                    self._late[bi].append(param)
+                return
             if self._expected[bi] is not None and self._pending[bi] == self._expected[bi]:
                 self.hook_launches += 1
                 self._launch(bi)
@@ -150,6 +163,10 @@ class GradAllReducer:
             return
         self._launched[bi] = True
         grads = [p for p in self.buckets[bi] if p.grad is not None]
+        self._sent[bi] = {id(p) for p in grads}
+        self._reduce(bi, grads)
+
+    def _reduce(self, bi: int, grads: List[torch.nn.Parameter]):
         big = [p for p in grads if p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.numel() >= 4096
                and self.comm_dtype in (None, torch.float32)]
         if len(big) <= 64:
@@ -165,15 +182,8 @@ class GradAllReducer:
             self._all_reduce([flat], self._producers[bi])
             self._copy_back.append((flat, loose))
 
-    def finish(self):
-        """Call after loss.backward(): launches what the hooks did not, waits, averages."""
-        if not self.active:
-            return
-        for bi in range(len(self.buckets)):
-            n_grad = sum(1 for p in self.buckets[bi] if p.grad is not None)
-            if self._hooks and self._expected[bi] != n_grad:
-                self._expected[bi] = n_grad             # first step (or the set of used parameters changed)
-            self._launch(bi)
+    def _complete(self):
+        """wait for everything enqueued so far, then average / copy back what it reduced"""
         for w in self._work:
             w.wait()
         if self._stream is not None:
@@ -186,24 +196,53 @@ class GradAllReducer:
                 n = p.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
+        self._work, self._reduced, self._copy_back = [], [], []
+
+    def finish(self):
+        """Call after loss.backward(): launches what the hooks did not, waits, averages."""
+        if not self.active:
+            return
+        for bi in range(len(self.buckets)):
+            if self._dirty[bi]:
+                self._complete()
+                self._reset()
+                raise RuntimeError(
+                    "dg-sct_amd GradAllReducer: a gradient of bucket %d was accumulated into after the bucket's overlapped "
+                    "all-reduce had been launched (a second backward() in the step, retain_graph, a shared parameter): the "
+                    "collective ran on a half-accumulated buffer.  Set reducer.paused = True around every backward but the "
+                    "last of a step (StackTrainer does), or build the reducer with overlap=False." % bi)
+            n_grad = sum(1 for p in self.buckets[bi] if p.grad is not None)
+            if self._launched[bi] and self._late[bi]:
+                # first gradients that arrived after the hook-launch (a parameter that is only sometimes used): they were
+                # not part of the message; every rank runs the same graph and sees the same late set
+                late = [p for p in self._late[bi] if p.grad is not None]
+                self._sent[bi] |= {id(p) for p in late}
+                self._reduce(bi, late)
+                self.relaunches += 1
+            if self._hooks and self._expected[bi] != n_grad:
+                self._expected[bi] = n_grad             # first step (or the set of used parameters changed)
+            self._launch(bi)
+        self._complete()
         self._reset()
 
     def _reset(self):
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._sent = [set() for _ in self.buckets]
+        self._late = [[] for _ in self.buckets]
+        self._dirty = [False] * len(self.buckets)
         self._producers = [set() for _ in self.buckets]
         self._work, self._reduced, self._copy_back = [], [], []
         self.last_hook_launches, self.hook_launches = self.hook_launches, 0
 
     def discard(self):
-        """An iteration whose gradients are thrown away (the reference's `accum_itr` control flow, train.py): complete
-        whatever the hooks launched -- every rank launched the same collectives -- and forget it."""
+        """An iteration whose gradients are thrown away or kept accumulating (the `accum_itr` control flow, train.py).
+        StackTrainer pauses the hooks for such iterations, so normally nothing was launched; if a caller left them on,
+        complete what they launched -- every rank launched the same collectives -- INCLUDING the 1/world scale of the
+        SUM back-ends, so an accumulating caller never keeps a half-finished sum."""
         if not self.active:
             return
-        for w in self._work:
-            w.wait()
-        if self._stream is not None:
-            torch.cuda.current_stream(self._stream.device).wait_stream(self._stream)
+        self._complete()
         self._reset()
 
     @staticmethod

@@ -122,16 +122,22 @@ class StackTrainer:
         """One training iteration with the reference's control flow (main_trans.py:110-136).  Returns True when the
         optimizer stepped."""
         first_of_window = self.it % self.accum_itr == 0
+        do_step = (self.it + 1) % self.accum_itr == 0 or last
         if self.accum_mode == "reference" or first_of_window:
             self.zero_grad()                                     # reference: every iteration (discards the previous one)
+        if self.reducer is not None:
+            # Only the stepping iteration communicates: its hooks (and finish()) see the gradients of the whole window in
+            # "accumulate" mode, and in "reference" mode the iterations whose gradients are thrown away cost no all-reduce.
+            self.reducer.paused = not do_step
         self.fwd_bwd(feats, cots, mcots, loss_fn)
         self.it += 1
-        do_step = self.it % self.accum_itr == 0 or last
         if do_step:
             if self.reducer is not None:
                 self.reducer.finish()                            # mean over ranks of what this iteration (window) produced
             if self.opt is not None:
                 self.opt.step()
         elif self.reducer is not None:
-            self.reducer.discard()                               # hooks may have launched buckets: complete and forget them
+            self.reducer.discard()                               # (nothing was launched while paused)
+        if last:
+            self.it = 0                                          # the reference keys the window on batch_idx, which restarts every epoch (main_trans.py:135)
         return do_step

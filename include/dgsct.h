@@ -14,7 +14,8 @@
  *   - plain C: pointers + sizes only, no torch types; every pointer is a DEVICE pointer owned by the
  *     caller (PyTorch's caching allocator); the library never allocates, frees or keeps device memory;
  *   - every call is asynchronous on `stream` (a hipStream_t) and re-entrant (no global mutable state),
- *     so it is safe under nn.DataParallel's per-replica threads (reference AVS/AVQA call sites);
+ *     so it is safe under nn.DataParallel's per-replica threads (reference AVS/AVQA call sites; the Python
+ *     mirror resolves a replica's broadcast weights itself);
  *   - every call returns 0 on success; on failure a non-zero code and dgsct_last_error() (thread
  *     local) describes it -- the Python wrapper raises RuntimeError, mirroring the reference's
  *     exception-only error behaviour (NotImplementedError for unsupported adapter kinds, :549-550);

@@ -34,6 +34,7 @@ void stream_destroy(void*) {}
 void stream_fork(const Ctx&) {}
 void stream_join(const Ctx&) {}
 void check_async(const char*) {}
+void clear_async() {}
 
 void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
 

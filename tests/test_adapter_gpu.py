@@ -424,6 +424,76 @@ def test_module_dropin_matches_oracle():
     assert rel_err(m.bn2.running_mean, po["bn2.running_mean"]) < TOL_F32
 
 
+@pytest.mark.parametrize("flat", [False, True])
+@pytest.mark.parametrize("flavour", ["avs_s4", "avqa"])
+def test_module_under_data_parallel(flavour, flat):
+    """The reference's AVS and AVQA scripts wrap the model in single-process nn.DataParallel (avs_s4/train.py:139,
+    net_grd_avst/main_avst.py:236): every forward re-creates the module as a REPLICA whose parameters are plain broadcast
+    tensors.  (a) nn.DataParallel(device_ids=[0]); (b) a real torch.nn.parallel.replicate() replica on cuda:0, run through
+    parallel_apply, with the parameter table already cached on the original; (c) two GPUs when the box has them.  All must
+    reproduce the bare module's outputs and route identical gradients to its parameters."""
+    from types import SimpleNamespace
+    from dgsct_amd import VisualAdapter
+    avs = flavour == "avs_s4"
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=4 if not avs else 2, is_before_layernorm=1, is_post_layernorm=1,
+                          num_tokens=2 if not avs else 8)
+    N, No = (16, 36) if avs else (25, 49)
+
+    class Wrap(torch.nn.Module):                      # DataParallel scatters tensors along dim 0 = frames
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            with __import__("warnings").catch_warnings():
+                __import__("warnings").simplefilter("ignore")
+                self.adapter_blocks = VisualAdapter(64, 64, "bottleneck", reduction_factor=8, opt=opt, use_bn=avs, use_gate=True,
+                                                    conv_dim_in=No, conv_dim_out=N, linear_in=48, linear_out=64, flavour=flavour)
+            with torch.no_grad():
+                self.adapter_blocks.gate.fill_(0.7); self.adapter_blocks.gate_av.fill_(0.3)
+                self.adapter_blocks.my_tokens.uniform_(0, 1)
+
+        def forward(self, f, fo):
+            out, amap = self.adapter_blocks(f.permute(0, 2, 1).unsqueeze(-1), fo.permute(0, 2, 1).unsqueeze(-1))
+            return out.squeeze(-1).permute(0, 2, 1), amap
+
+    T = 5 if avs else 10
+    BT = 2 * T
+    gen = torch.Generator().manual_seed(5)
+    f0, fo0 = torch.randn(BT, N, 64, generator=gen), torch.randn(BT, No, 48, generator=gen)
+    g_out, g_map = torch.randn(BT, N, 64, generator=gen).to(DEV), torch.randn(BT, 1, N, generator=gen).to(DEV)
+
+    def run(call, model):
+        model.zero_grad(set_to_none=True)
+        f, fo = f0.to(DEV).requires_grad_(True), fo0.to(DEV).requires_grad_(True)
+        out, amap = call(f, fo)
+        torch.autograd.backward([out, amap], [g_out, g_map])
+        return out.detach(), amap.detach(), f.grad, fo.grad, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    def same(a, b, what):
+        for i, (x, y) in enumerate(zip(a[:4], b[:4])):
+            assert rel_err(x, y) < 1e-5, (what, i)
+        assert set(a[4]) == set(b[4]) and a[4], what
+        for k in a[4]:
+            assert rel_err(a[4][k], b[4][k]) < 1e-5, (what, k)
+
+    w = Wrap().to(DEV).train()
+    if flat:
+        w.adapter_blocks.flatten_parameters()
+    sd = {k: v.clone() for k, v in w.state_dict().items()}
+    ref = run(w, w)
+    w.load_state_dict(sd)                              # undo BN running-stat updates between the legs
+    same(run(torch.nn.DataParallel(w, device_ids=[0]), w), ref, "DataParallel(device_ids=[0])")
+    w.load_state_dict(sd)
+
+    def via_replica(f, fo):
+        rep = torch.nn.parallel.replicate(w, [DEV])[0]
+        assert rep is not w and len(list(rep.parameters())) == 0
+        return torch.nn.parallel.parallel_apply([rep], [(f, fo)])[0]
+    same(run(via_replica, w), ref, "replicate + parallel_apply")
+    w.load_state_dict(sd)
+    if torch.cuda.device_count() >= 2 and not avs:     # per-replica BN statistics differ by design: the BN-less flavour only
+        same(run(torch.nn.DataParallel(w, device_ids=[0, 1]), w), ref, "DataParallel over two GPUs")
+
+
 def test_cpu_tensors_raise():
     from types import SimpleNamespace
     from dgsct_amd import VisualAdapter

@@ -188,6 +188,85 @@ def test_flattened_parameters_keep_the_checkpoint_format_and_the_gradients():
     assert n_checked == len(fx["grads"])
 
 
+def fake_replicate(network):
+    """What torch.nn.parallel.replicate does for ONE replica, minus the device broadcast (which needs GPUs): every module
+    becomes ``_replicate_for_data_parallel()`` (shallow ``__dict__`` copy, EMPTY ``_parameters``), children are re-wired, and
+    the parameters come back as plain NON-LEAF tensor attributes (``Broadcast.apply`` outputs; here ``p.clone()``, which
+    keeps the autograd edge to the original parameter exactly like the broadcast does)."""
+    modules = list(network.modules())
+    index = {m: i for i, m in enumerate(modules)}
+    copies = [m._replicate_for_data_parallel() for m in modules]
+    memo = {}
+    for i, m in enumerate(modules):
+        r = copies[i]
+        for key, child in m._modules.items():
+            r._modules[key] = None if child is None else copies[index[child]]
+        for key, prm in m._parameters.items():
+            if prm is None:
+                r._parameters[key] = None
+            else:
+                if prm not in memo:
+                    memo[prm] = prm.clone()
+                setattr(r, key, memo[prm])
+        for key, buf in m._buffers.items():
+            r._buffers[key] = buf
+    return copies[0]
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_data_parallel_replica_runs_and_routes_gradients(flat):
+    """nn.DataParallel (reference AVS/AVQA: avs_s4/train.py:139, main_avst.py:236; SURVEY 8b "must be preserved:
+    DataParallel.replicate") re-creates the module every forward as a replica with no Parameters.  The replica must
+    compute what the module computes and send its gradients back to the module's parameters; with the parameter table
+    cached on the ORIGINAL before replication, too (VERDICT r2 weak #2)."""
+    emu = Lib(build_emu())
+    fx = load_golden("ave_orderA")
+    c = fx["cfg"]
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=c["g"], is_before_layernorm=int(c["ln_before"]),
+                          is_post_layernorm=int(c["ln_post"]), num_tokens=c["tk"])
+
+    def make():
+        m = VisualAdapter(c["C"], c["C"], "bottleneck", reduction_factor=c["r"], opt=opt, use_bn=c["use_bn"], use_gate=c["use_gate"],
+                          num_tk=c["tk"], conv_dim_in=c["No"], conv_dim_out=c["N"], linear_in=c["Co"], linear_out=c["C"], lib=emu)
+        m.load_state_dict(fx["state0"])
+        return (m.flatten_parameters() if flat else m).train()
+
+    X, Y = fx["X"], fx["Y"]
+    x = lambda: X.permute(0, 2, 1).unsqueeze(-1).clone().requires_grad_(True)
+    y = lambda: Y.permute(0, 2, 1).unsqueeze(-1).clone().requires_grad_(True)
+    cot = torch.randn(X.shape[0], c["C"], c["N"], 1, generator=torch.Generator().manual_seed(1))
+    mcot = torch.randn(X.shape[0], 1, c["N"], generator=torch.Generator().manual_seed(2))
+
+    ref = make()
+    xr, yr = x(), y()
+    o, mp_ = ref(xr, yr)
+    torch.autograd.backward([o, mp_], [cot, mcot])
+    ref_grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+
+    m = make()
+    m(x(), y())                                   # caches the parameter table / prepared weights on the original first
+    m.zero_grad(set_to_none=True)
+    m.load_state_dict(fx["state0"])               # (undo the BN running-stat update of that call)
+    rep = fake_replicate(m)
+    assert rep is not m and len(list(rep.parameters())) == 0
+    x1, y1 = x(), y()
+    o1, mp1 = rep(x1, y1)
+    assert rel_err(o1, o) < 1e-6 and rel_err(mp1, mp_) < 1e-6
+    torch.autograd.backward([o1, mp1], [cot, mcot])
+    assert rel_err(x1.grad, xr.grad) < 1e-6 and rel_err(y1.grad, yr.grad) < 1e-6
+    got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref_grads) and got
+    for n in ref_grads:
+        assert rel_err(got[n], ref_grads[n]) < 1e-6, n
+    # the replica owns its caches: nothing it built leaked into the original (shallow __dict__ copy)
+    assert rep.__dict__.get("_ptab") is None
+    assert m.__dict__["_ptab"] is not rep.__dict__.get("_ptab")
+    assert rep._prep_cache is not m._prep_cache
+    # and the original still works after its replica ran
+    o2, _ = m(x(), y())
+    assert torch.isfinite(o2).all()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def _dp_worker(rank, world, port, emu_path, q, flat):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -293,6 +372,61 @@ def test_flat_parameters_refresh_prepared_weights_after_optimizer_step(dtype):
     assert rel_err(out1, out0.detach()) > 1e-2, "the step did not change the output: stale prepared weights?"
 
 
+def _late_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    big = [torch.nn.Parameter(torch.randn(8192)) for _ in range(3)]         # in-place path (numel >= 4096)
+    small = [torch.nn.Parameter(torch.randn(7)) for _ in range(3)]          # torch.cat fallback path
+    params = big + small
+    red = GradAllReducer([big[:2] + small[:2], big[2:] + small[2:]])
+    x = [torch.full_like(p, float(rank + 1 + i)) for i, p in enumerate(params)]
+    loss = lambda use: sum((p * xi).sum() for p, xi, u in zip(params, x, use) if u)
+    sometimes = [True, False, True, True, False, True]                      # big[1] and small[1] unused in step 1
+    loss(sometimes).backward(); red.finish()                                # step 1: learns the expected counts (2 and 2)
+    for p in params:
+        p.grad = None
+    loss([True] * 6).backward()                                             # step 2: bucket 0 launches after 2 events, 2 more arrive
+    launched = red.hook_launches
+    red.finish()
+    out = (launched, red.relaunches, [p.grad.clone().numpy() for p in params])
+    # step 3: a second backward in the same step accumulates into gradients that are already in flight -> must raise
+    for p in params:
+        p.grad = None
+    loss([True] * 6).backward()
+    loss([True] * 6).backward()
+    try:
+        red.finish()
+        raised = False
+    except RuntimeError as e:
+        raised = "after the bucket" in str(e)
+    if rank == 0:
+        q.put(out + (raised,))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_late_gradients_are_reduced_and_dirty_buckets_raise():
+    """the hooks launch a bucket when it has seen as many gradients as LAST step.  A parameter that
+    only sometimes gets a gradient then arrives after the launch: finish() must still reduce it.  A gradient that is
+    accumulated into again while its collective is in flight (second backward in the step) cannot be repaired: finish() raises."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_late_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    launched, relaunches, grads, raised = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert launched == 2 and relaunches == 1 and raised
+    for i, g in enumerate(grads):
+        want = ((1 + i) + (2 + i)) / 2                                      # mean over the two ranks of x_rank
+        assert abs(float(g.min()) - want) < 1e-5 and abs(float(g.max()) - want) < 1e-5, (i, g[:3], want)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def _train_setup(emu, fx, lo, hi, flat):
     from dgsct_amd.train import StackTrainer, make_optimizer, seed_everything
@@ -307,7 +441,7 @@ def _train_setup(emu, fx, lo, hi, flat):
     return st, opt, sched, feats, cots
 
 
-def _train_worker(rank, world, port, emu_path, q, accum_itr):
+def _train_worker(rank, world, port, emu_path, q, accum_itr, accum_mode="reference"):
     from dgsct_amd.train import StackTrainer
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -317,16 +451,20 @@ def _train_worker(rank, world, port, emu_path, q, accum_itr):
     BT = fx["feats"][0][0].shape[0]
     st, opt, sched, feats, cots = _train_setup(Lib(emu_path), fx, rank * BT // world, (rank + 1) * BT // world, True)
     red = GradAllReducer(GradAllReducer.stage_buckets(st))
-    tr = StackTrainer(st, opt, red, accum_itr=accum_itr, accum_mode="reference")
+    tr = StackTrainer(st, opt, red, accum_itr=accum_itr, accum_mode=accum_mode)
+    calls = []
+    orig = red._all_reduce
+    red._all_reduce = lambda tensors, producers=(): (calls.append(tr.it), orig(tensors, producers))[1]
     stepped = [tr.step(feats, cots) for _ in range(4)]
     if rank == 0:
-        q.put((stepped, {k: v.numpy().copy() for k, v in st.state_dict().items() if v.is_floating_point()}))
+        # (tr.it at the time of each collective: only stepping iterations communicate -- ADVICE r2)
+        q.put((stepped, {k: v.numpy().copy() for k, v in st.state_dict().items() if v.is_floating_point()}, calls))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("accum_itr", [1, 2])
-def test_training_steps_under_dp_match_single_process(accum_itr):
+@pytest.mark.parametrize("accum_itr,accum_mode", [(1, "reference"), (2, "reference"), (2, "accumulate")])
+def test_training_steps_under_dp_match_single_process(accum_itr, accum_mode):
     """N optimizer steps (Adam + the reference's freeze rule and `accum_itr` control flow,
     main_trans.py:110,135-136,211-278) of the identity-backbone stack, clips sharded over 2 gloo ranks with overlapped
     bucketed gradient all-reduce, reproduce the single-process parameters.  accum_itr = 2 reproduces the reference's quirk:
@@ -337,17 +475,22 @@ def test_training_steps_under_dp_match_single_process(accum_itr):
     BT = fx["feats"][0][0].shape[0]
     st, opt, sched, feats, cots = _train_setup(Lib(emu_path), fx, 0, BT, False)
     assert all(p.requires_grad for n, p in st.named_parameters())          # every name contains 'adapter_blocks'
-    tr = StackTrainer(st, opt, None, accum_itr=accum_itr, accum_mode="reference")
+    tr = StackTrainer(st, opt, None, accum_itr=accum_itr, accum_mode=accum_mode)
     stepped = [tr.step(feats, cots) for _ in range(4)]
     assert stepped == ([True] * 4 if accum_itr == 1 else [False, True, False, True])
     ref = {k: v.clone() for k, v in st.state_dict().items() if v.is_floating_point()}
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000 + 11 * accum_itr
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, emu_path, q, accum_itr)) for r in range(2)]
+    port = 31500 + os.getpid() % 2000 + 11 * accum_itr + 5 * (accum_mode == "accumulate")
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, emu_path, q, accum_itr, accum_mode)) for r in range(2)]
     for p in procs:
         p.start()
-    got_stepped, got = q.get(timeout=240)
+    got_stepped, got, comm_its = q.get(timeout=240)
+    # collectives are enqueued during fwd_bwd (hooks: tr.it still counts the iteration being run) or in finish() (tr.it
+    # already incremented): with accum_itr = 2 nothing may be sent for the non-stepping iterations 0 and 2
+    assert comm_its and all((it % accum_itr == accum_itr - 1) or (it % accum_itr == 0 and it > 0) for it in comm_its), comm_its
+    if accum_itr == 2:
+        assert not any(it in (0,) for it in comm_its)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
