@@ -64,7 +64,7 @@ class AttnArgs(C.Structure):
 
 
 EXPORTS = ["dgsct_test_gemm_fp8", "dgsct_temporal_gate_forward", "dgsct_temporal_gate_backward", "dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
-           "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_prof_enable", "dgsct_prof_collect",
+           "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_test_tune", "dgsct_prof_enable", "dgsct_prof_collect",
            "dgsct_stream_create", "dgsct_stream_destroy", "dgsct_map_pool_forward", "dgsct_map_pool_backward"]
 
 _PP = C.POINTER(C.c_void_p)
@@ -183,6 +183,11 @@ class Lib:
 
     def test_attn(self, op: int, args: "AttnArgs", stream: int):
         self._check(self.c.dgsct_test_attn(int(op), C.byref(args), stream), "dgsct_test_attn")
+
+    def test_tune(self, key: str, value: int) -> int:
+        self.c.dgsct_test_tune.argtypes = [C.c_char_p, C.c_int]
+        self.c.dgsct_test_tune.restype = C.c_int
+        return int(self.c.dgsct_test_tune(key.encode(), int(value)))
 
     def test_gemm(self, args: GemmArgs, stream: int):
         self._check(self.c.dgsct_test_gemm(C.byref(args), stream), "dgsct_test_gemm")

@@ -8,6 +8,7 @@
 #include "err.h"
 #include "plan.h"
 #include "prims.h"
+#include "gemm_int.h"
 
 using namespace dgsct;
 
@@ -222,6 +223,11 @@ int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, cons
   gemm_fp8(ctx, M, N, K, A, K, w8, scale, bias, relu, D, N);
   check_async("dgsct_test_gemm_fp8");
   return has_error() ? 1 : 0;
+}
+
+int dgsct_test_tune(const char* key, int value) {
+  if (key && !strcmp(key, "gemm8")) return gemm8_mode(value);
+  return -1;
 }
 
 int dgsct_prof_enable(int on) { gemm_prof_enable(on); return 0; }

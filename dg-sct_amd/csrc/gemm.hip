@@ -27,6 +27,7 @@
 #include <cmath>
 
 #include "err.h"
+#include "gemm_int.h"
 
 namespace dgsct {
 
@@ -769,6 +770,13 @@ static ProfRec* prof_begin(hipStream_t s, double flops, const ProfRec& shape) {
 static void prof_end(ProfRec* r, hipStream_t s) {
   if (r) (void)hipEventRecord(r->e1, s);
 }
+void* gemm_prof_begin(void* stream, double flops, const GemmProfShape& h) {
+  ProfRec shp{};
+  shp.M = h.M; shp.N = h.N; shp.K = h.K; shp.KB = h.KB; shp.batch = h.batch; shp.splitk = h.splitk; shp.cfg = h.cfg;
+  shp.ak = h.ak; shp.bk = h.bk; shp.atomic = h.atomic; shp.wide = h.wide; shp.bytes = h.bytes;
+  return prof_begin((hipStream_t)stream, flops, shp);
+}
+void gemm_prof_end(void* rec, void* stream) { prof_end((ProfRec*)rec, (hipStream_t)stream); }
 void gemm_prof_enable(int on) { g_prof_on.store(on != 0); }
 // Synchronises on the recorded events; returns launches, sum of durations (ms) and of useful FLOPs; clears the log.
 void gemm_prof_collect(long* launches, double* total_ms, double* total_flops) {
@@ -835,6 +843,9 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   k.mask = (const char*)g.mask; k.ldmask = g.ldmask; k.maskbs = g.maskbs;
   k.sm_scale = g.sm_scale; k.sm_dot = g.sm_dot;
   k.atomic = g.atomic;
+  if constexpr (MODE == DT_BF16) {
+    if (gemm8_try(ctx, g)) return;                              // deep products: 8-wave LDS-DMA pipelined kernel (gemm8.hip)
+  }
   const bool rowwise = g.act == ACT_SOFTMAX || g.act == ACT_SOFTMAX_BWD;
   {
     const int dv = g.ddt == DT_F32 ? 4 : 8, rv = g.rdt == DT_F32 ? 4 : 8;

@@ -1,0 +1,19 @@
+// Internal seam between the two GEMM translation units (gemm.hip: the 4-wave tiled engine; gemm8.hip: the 8-wave
+// LDS-DMA pipelined kernel for the deep products).  Not part of prims.h: plan.cpp only ever calls gemm().
+#pragma once
+#include "prims.h"
+
+namespace dgsct {
+
+// per-launch event timing of the GEMM family (bench.py's roofline leg); rec == nullptr when profiling is off
+struct GemmProfShape { int M, N, K, KB, batch, splitk, cfg, ak, bk, atomic, wide; double bytes; };
+void* gemm_prof_begin(void* stream, double flops, const GemmProfShape& shape);
+void gemm_prof_end(void* rec, void* stream);
+
+// Launches `g` on the 8-wave kernel when it qualifies (bf16, deep contraction, 256-row tiles, plain epilogue) and
+// returns true; false = not eligible, the caller runs the tiled engine.
+bool gemm8_try(const Ctx& ctx, const Gemm& g);
+// 0: off, 1: on for shapes that fill the chip (default; DGSCT_GEMM8), 2: on for every eligible shape (tests).  set < 0: query.
+int gemm8_mode(int set);
+
+}  // namespace dgsct

@@ -234,6 +234,11 @@ int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, cons
  * While enabled, every launch of the MFMA GEMM family issued from the calling thread is bracketed by
  * HIP events on its own stream; collect() synchronises them and returns the number of launches, the sum
  * of their durations and the sum of their useful FLOPs (2*M*N*K per batch), then clears the log. */
+/* Test / tuning hook: set an internal switch, returns its previous value (-1: unknown key).
+ *   "gemm8": 0 = 8-wave deep-product GEMM kernel off, 1 = on for shapes that fill the chip (default), 2 = on for every
+ *   eligible shape (lets the unit tests reach it with small matrices); value < 0 only queries. */
+int dgsct_test_tune(const char* key, int value);
+
 int dgsct_prof_enable(int on);
 int dgsct_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../dg-sct_amd/csrc/prims.h"
+#include "../../dg-sct_amd/csrc/gemm_int.h"
 
 namespace dgsct {
 
@@ -35,6 +36,7 @@ void stream_fork(const Ctx&) {}
 void stream_join(const Ctx&) {}
 void check_async(const char*) {}
 void clear_async() {}
+int gemm8_mode(int) { return 0; }                 // (the 8-wave GEMM kernel is a device-side choice: nothing to emulate)
 
 void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
 

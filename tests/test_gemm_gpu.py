@@ -222,3 +222,59 @@ def test_gemm_softmax_epilogues(mode, tk):
     scale = max(1.0, dS_ref.abs().max().item())
     assert (dS[..., :tk].double().cpu() - dS_ref).abs().max().item() / scale < (2e-2 if mode == 1 else 2e-5)
     assert abs(acc.item() - dot.sum().item()) < (2e-2 if mode == 1 else 1e-4) * max(1.0, abs(dot.sum().item()))
+
+
+# ---- gemm8.hip: the 8-wave LDS-DMA pipelined kernel of the deep products -------------------------------------------------
+@pytest.fixture
+def gemm8_all():
+    """route every eligible shape to the 8-wave kernel (its size gates would send these small test matrices to the tiled engine)"""
+    lib = default_lib()
+    old = lib.test_tune("gemm8", 2)
+    yield lib
+    lib.test_tune("gemm8", old)
+
+
+@pytest.mark.parametrize("ak,bk", LAYOUTS)
+def test_gemm8_batched_shared_a(gemm8_all, ak, bk):
+    """remap products Wn . Y[b] / Wn^T . dT[b]: one A for every frame, frames side by side in the column tiles (256 x 192
+    tiles over 96-wide frames: two frames per tile; 128-wide frames: 256-column tiles)"""
+    run_case(1, 512, 96, 1024, ak, bk, batch=6, shared_a=True, out_bf16=True)
+    run_case(1, 256, 192, 1088, ak, bk, batch=3, shared_a=True, out_bf16=True)
+    run_case(1, 256, 128, 1024, ak, bk, batch=4, shared_a=True, out_bf16=True)
+    run_case(1, 256, 96, 1152, ak, bk, batch=8, shared_a=True, out_bf16=False)           # fp32 rows through the staged epilogue
+    run_case(1, 256, 48, 1024, ak, bk, batch=8, shared_a=True, out_bf16=True)            # four 48-wide frames per 192-column tile
+
+
+def test_gemm8_remap_bias_epilogue(gemm8_all):
+    """Yp[b] = Wn . T2[b] + rowb (x) colb + colb2 (plan.cpp F1, association B): rank-1 + column bias in the staged epilogue"""
+    run_case(1, 512, 96, 1024, 1, 1, batch=4, shared_a=True, out_bf16=True, epi=dict(r1=True, bias_n=True))
+    run_case(1, 256, 128, 1024, 1, 1, batch=2, shared_a=True, out_bf16=True, epi=dict(r1=True, bias_n=True))
+
+
+@pytest.mark.parametrize("ak,bk", LAYOUTS)
+def test_gemm8_split_k_atomic(gemm8_all, ak, bk):
+    """weight gradients: plain big output, deep one- or two-level contraction, split-K with fp32 atomics"""
+    run_case(1, 256, 256, 96, ak, bk, batch=1, KB=24, atomic=True, splitk=0)              # dWn: contraction over (frame, channel)
+    run_case(1, 512, 192, 2304, ak, bk, batch=1, atomic=True, splitk=0)
+    run_case(1, 256, 512, 6400, ak, bk, batch=1, atomic=True, splitk=0)                   # C x C over token rows
+
+
+def test_gemm8_is_actually_used(gemm8_all):
+    """the shapes above must reach gemm8.hip (and a shape it cannot take must still be served by the tiled engine)"""
+    lib = gemm8_all
+    lib.prof_enable(True)
+    try:
+        run_case(1, 512, 96, 1024, 1, 0, batch=6, shared_a=True, out_bf16=True)
+        import os, tempfile, csv
+        path = os.path.join(tempfile.mkdtemp(), "g.csv")
+        os.environ["DGSCT_PROF_DUMP"] = path
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] in ("8", "9"), rows[-1]
+        run_case(1, 500, 96, 1024, 1, 0, batch=6, shared_a=True, out_bf16=True)           # M % 256 != 0: tiled engine
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] not in ("8", "9"), rows[-1]
+    finally:
+        os.environ.pop("DGSCT_PROF_DUMP", None)
+        lib.prof_enable(False)

@@ -41,6 +41,19 @@ def test_header_symbols_are_exported():
     assert lib.dgsct_arch() == b"gfx950"
 
 
+def test_gemm8_isa_keeps_the_hand_ordered_reads_intact():
+    """gemm8.hip orders inline-asm LDS reads by hand; hipcc does not know their results arrive late.  The checker compiles
+    the file to gfx950 ISA (no GPU needed) and verifies nothing touches an in-flight register, no spill and no
+    compiler-made vmcnt wait sits in the k-loop (a register-allocation change once broke exactly this: DESIGN.md 3.1b)."""
+    import shutil
+    import subprocess
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_gemm8_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok   ") >= 20
+
+
 def test_query_rejects_bad_descriptor():
     emu = Lib(build_emu())
     from dgsct_amd.ops import AdapterSpec
