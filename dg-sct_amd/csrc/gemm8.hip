@@ -456,6 +456,9 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
     // Few output tiles = many splits of a handful of k-tiles each: prologue / epilogue bound and 60-way atomics per address.
     // Measured (tools/gemm8_ab_all.sh): 512 x 512 x 23 040 36.7 -> 61 us, 1024 x 1024 x 5 760 35.9 -> 59 us -- the tiled engine keeps them.
     if (mode < 2 && tiles < 96) return false;
+    // dWn with both operands K-major (2304 x 4096 x (160 x 96)): 434 vs 443 us alone, 455 vs 515 us inside the step (seven 256 x 256
+    // fp32 atomic slabs per tile against the tiled engine's two) -- stays on the tiled engine; the K-major x MN-major one gains 12 %
+    if (mode < 2 && two && g.A.kmajor && g.B.kmajor) return false;
     // enough splits for >= ~2 full rounds, each walking >= 6 k-tiles; among those the best-filled last round
     int smax = kt_total / 6; if (smax < 1) smax = 1; if (smax > 64) smax = 64;
     double be = -1;
