@@ -68,18 +68,37 @@ def rel_err(a, b):
     return ((a - b).abs().max() / max(1.0, b.abs().max().item())).item()
 
 
-def grad_close_fp32(g, go, tol=1e-3):
-    """fp32 parity of one parameter gradient: max|err| / max(1, max|ref|) < tol.  One exception, for weight MATRICES
-    downstream of a ReLU: a unit whose pre-activation lies within fp32 rounding of zero may take the other side of the
-    ReLU than the oracle does (different summation order), which moves ONE row (or column) of that layer's weight
-    gradient by that unit's whole contribution.  Up to two such rows/columns are accepted when the matrix as a whole
-    still agrees to 5 tol in relative L2 (observed: fc_affine_video_2.weight, 495 of 131072 elements = one row, 1.3e-3)."""
+def fp32_err(a, b):
+    """fp32 parity metric: max(relative L2, worst element / max|ref|) -- NO absolute floor, so a tensor
+    whose values are all far below 1 (the returned attention map at N = 4096 is <= 1/N everywhere) is held to 1e-3 of ITS scale."""
+    a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+    d = a - b
+    return max((d.norm() / b.norm().clamp_min(1e-30)).item(), (d.abs().max() / b.abs().max().clamp_min(1e-30)).item())
+
+
+# Gradients that are analytically zero or eps-sized residues of large cancelling sums: ln_before.bias (zero whenever ln_post
+# follows), gate in the gate-before-LayerNorm flavours (LayerNorm is scale invariant: only its eps term survives), the spatial
+# bias (sum of softmax-backward rows, which sum to zero) and fc.bias (sum of dYp over rows whose softmax parts cancel).  Their
+# reference value is itself rounding noise relative to the summands, so they keep round 2's criterion
+# max|err| / max(1, max|ref|) < tol; everything else is held to its own scale.
+FP32_RESIDUES = ("ln_before.bias", "gate", "fc_affine_v_s_att.bias", "fc.bias")
+
+
+def grad_close_fp32(g, go, tol=1e-3, name=None):
+    """fp32 parity of one parameter gradient: fp32_err < tol.  One exception, for weight MATRICES downstream of a ReLU: a unit
+    whose pre-activation lies within fp32 rounding of zero may take the other side of the ReLU than the oracle does
+    (different summation order), which moves ONE row (or column) of that layer's weight gradient by that unit's whole
+    contribution.  Up to two such rows/columns are accepted when the matrix as a whole still agrees to 5 tol in relative L2
+    (observed: fc_affine_video_2.weight, 495 of 131072 elements = one row, 1.3e-3)."""
     g, go = g.detach().float().cpu().reshape(go.shape), go.detach().float().cpu()
-    scale = max(1.0, go.abs().max().item())
+    if name in FP32_RESIDUES:
+        return (g - go).abs().max().item() / max(1.0, go.abs().max().item()) < tol
+    scale = go.abs().max().clamp_min(1e-30).item()
     d = (g - go).abs()
-    if d.max().item() / scale < tol:
+    l2 = ((g - go).norm() / go.norm().clamp_min(1e-30)).item()
+    if d.max().item() / scale < tol and l2 < tol:
         return True
-    if go.dim() == 2 and ((g - go).norm() / go.norm().clamp_min(1e-20)).item() < 5 * tol:
+    if go.dim() == 2 and l2 < 5 * tol:
         bad = d > tol * scale
         return min(int(bad.any(1).sum()), int(bad.any(0).sum())) <= 2
     return False
@@ -113,3 +132,22 @@ def run_library(lib, fx, device, dtype=torch.float32, training=True, residual=No
         dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, dTmap, skip_into_dx=skip)
         res.update(dX=dX, dY=dY, grads={PARAM_NAMES[i]: g for i, g in enumerate(grads) if g is not None})
     return res
+
+
+def device_relu_masks(lib, desc, saved, spec, BT, dtype):
+    """The ReLU decisions the device forward actually took, read from its saved-activation buffer (dgsct_saved_region)
+    BEFORE backward runs (backward overwrites vq1 / vq2 in place).  Keys match oracle.backward(masks=...)."""
+    regs = lib.saved_regions(desc)
+    es = 2 if dtype == torch.bfloat16 else 4
+    N, C = spec.N, spec.C
+    shapes = {"vq1": (BT, N, C), "vq2": (BT, N, C // 2), "Z": (BT, N, C // spec.r), "q": (BT, C // 2), "aq1": (BT, C),
+              "aq2": (BT, C // 2)}
+    out = {}
+    for name, shape in shapes.items():
+        off, nb = regs[name]
+        n = 1
+        for v in shape:
+            n *= v
+        assert nb >= n * es, (name, nb, n * es)
+        out[name] = (saved[off:off + n * es].view(dtype).view(shape).float() > 0).cpu()
+    return out

@@ -1,7 +1,8 @@
 """GPU parity: libdgsct.so (hand-written gfx950 kernels, through the C ABI) against the reference golden
 vectors and against the oracle at real AVE shapes.
 
-fp32: BASELINE.json's 1e-3, measured as max|err| / max(1, max|ref|), every output, every gradient, BN buffers.
+fp32: BASELINE.json's 1e-3, measured as max(relative L2, worst element / max|ref|) per tensor -- no absolute floor (helpers.fp32_err;
+round 2's max|err| / max(1, max|ref|) let an all-zero attention map pass at N >= 1000) --, every output, every gradient, BN buffers.
 bf16: OUTPUTS (out, map) within BASELINE.json's 1e-2 in relative L2 and 2e-2 in the worst element (max|err| / max|ref|) at
 real shapes; every tensor (outputs AND all gradients) within the emulator-derived per-case bound of
 tests/golden/bf16_bounds.json (oracle/make_bf16_bounds.py: the range an IDEAL bf16-storage evaluation of the same
@@ -13,7 +14,7 @@ import os
 import pytest
 import torch
 
-from helpers import golden_names, grad_close_fp32, load_golden, nrm_err, oracle_cfg, param_table, rel_err, run_library, spec_of
+from helpers import fp32_err, golden_names, grad_close_fp32, load_golden, nrm_err, oracle_cfg, param_table, rel_err, run_library, spec_of
 from dgsct_amd import ops
 from dgsct_amd._lib import P_INDEX, PARAM_NAMES, default_lib
 from oracle import dgsct_oracle as O
@@ -39,6 +40,8 @@ def check_bounds(name, got, ref_out, ref_map, ref_dX, ref_dY, ref_grads):
         if not _l2(g, r) <= b[k]:
             bad.append((k, round(_l2(g, r), 4), round(b[k], 4)))
     for k, bound in b["grads"].items():
+        if bound >= 0.5:
+            continue        # a bound this loose asserts nothing: these tensors are held by tests/test_bf16_masked_gpu.py instead
         e = _l2(got["grads"][k].reshape(-1), ref_grads[k].reshape(-1))
         if not e <= bound:
             bad.append((k, round(e, 4), round(bound, 4)))
@@ -50,19 +53,18 @@ def test_golden_fp32(name):
     fx = load_golden(name)
     r = run_library(default_lib(), fx, DEV, torch.float32, training=True)
     torch.cuda.synchronize()
-    assert rel_err(r["out"], fx["out"]) < TOL_F32
-    assert rel_err(r["map"], fx["map"]) < TOL_F32
-    if fx["tmap"] is not None:
-        assert rel_err(r["tmap"], fx["tmap"]) < TOL_F32
-    assert rel_err(r["dX"], fx["dX"]) < TOL_F32
-    assert rel_err(r["dY"], fx["dY"]) < TOL_F32
+    bad = [(k, fp32_err(r[k], fx[k])) for k in ("out", "map", "dX", "dY") if not fp32_err(r[k], fx[k]) < TOL_F32]
+    if fx["tmap"] is not None and not fp32_err(r["tmap"], fx["tmap"]) < TOL_F32:
+        bad.append(("tmap", fp32_err(r["tmap"], fx["tmap"])))
     for k, g in fx["grads"].items():
         assert k in r["grads"], k
-        assert rel_err(r["grads"][k].reshape(g.shape), g) < TOL_F32, k
+        if not grad_close_fp32(r["grads"][k], g, TOL_F32, name=k):
+            bad.append((k, fp32_err(r["grads"][k], g)))
     assert not (set(r["grads"]) - set(fx["grads"]))
     for k, v in fx["buffers1"].items():
-        if "running" in k:
-            assert rel_err(r["params"][P_INDEX[k]], v) < TOL_F32, k
+        if "running" in k and not fp32_err(r["params"][P_INDEX[k]], v) < TOL_F32:
+            bad.append((k, fp32_err(r["params"][P_INDEX[k]], v)))
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("name", ["ave_orderA", "avs_s4", "avqa", "pretrain"])
@@ -70,8 +72,8 @@ def test_golden_eval_fp32(name):
     fx = dict(load_golden(name))
     st = dict(fx["state0"]); st.update(fx["buffers1"]); fx["state0"] = st
     r = run_library(default_lib(), fx, DEV, torch.float32, training=False)
-    assert rel_err(r["out"], fx["eval_out"]) < TOL_F32
-    assert rel_err(r["map"], fx["eval_map"]) < TOL_F32
+    assert fp32_err(r["out"], fx["eval_out"]) < TOL_F32
+    assert fp32_err(r["map"], fx["eval_map"]) < TOL_F32
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -106,13 +108,21 @@ def _real_case(N, C, No, Co, BT, dtype, seed=0, flavour="ave"):
         X, Y, dOut = X.bfloat16().float(), Y.bfloat16().float(), dOut.bfloat16().float()
     po = {k: v.clone() for k, v in p.items()}
     out_o, map_o, _, s = O.forward(po, X, Y, cfg, training=True)
-    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, None, training=True)
     spec = spec_of(cfg)
     params = param_table(p, spec, DEV)
     lib = default_lib()
     Xd, Yd = X.to(DEV, dtype).contiguous(), Y.to(DEV, dtype).contiguous()
     prep = ops.prepare(lib, spec, params, dtype, DEV)
     out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
+    # fp32: the oracle differentiates the ReLU branches the device took (a pre-activation within fp32 rounding of zero lands on
+    # either side with a different summation order; pinned, the relative metric needs no per-flip exceptions).  bf16 keeps the
+    # un-pinned oracle here -- its bounds (bf16_bounds.json) were derived that way; the pinned bf16 test is test_bf16_masked_gpu.py
+    masks = None
+    if dtype == torch.float32:
+        from helpers import device_relu_masks
+        torch.cuda.synchronize()
+        masks = device_relu_masks(lib, d, saved, spec, BT, dtype)
+    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, None, training=True, masks=masks)
     dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(DEV, dtype).contiguous(),
                                      dMap.to(DEV), None)
     return dict(out=(out, out_o), map=(amap, map_o), dX=(dX, dX_o), dY=(dY, dY_o),
@@ -129,9 +139,9 @@ REAL = [(144, 512, 256, 384), (256, 384, 144, 512), (36, 1024, 64, 768), (64, 76
 def test_real_shapes_fp32(shape):
     r = _real_case(*shape, BT=10, dtype=torch.float32)
     for k in ("out", "map", "dX", "dY"):
-        assert rel_err(*r[k]) < TOL_F32, k
-    for k, (g, go) in r["grads"].items():
-        assert grad_close_fp32(g, go, TOL_F32), (k, rel_err(g, go.reshape(-1)))
+        assert fp32_err(*r[k]) < TOL_F32, (k, fp32_err(*r[k]))
+    bad = [(k, fp32_err(g, go)) for k, (g, go) in r["grads"].items() if not grad_close_fp32(g, go, TOL_F32, name=k)]
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("shape", REAL)
@@ -154,11 +164,11 @@ def test_real_shapes_flavours_fp32(flavour):
     a real stage-2 shape (12x12 visual tokens <- 16x16 audio tokens) against the oracle"""
     r = _real_case(144, 512, 256, 384, BT=10, dtype=torch.float32, flavour=flavour)
     for k in ("out", "map", "dX", "dY"):
-        assert rel_err(*r[k]) < TOL_F32, k
+        assert fp32_err(*r[k]) < TOL_F32, (k, fp32_err(*r[k]))
     assert not r["extra"], r["extra"]
     assert r["grads"]
-    for k, (g, go) in r["grads"].items():
-        assert grad_close_fp32(g, go, TOL_F32), (k, rel_err(g, go.reshape(-1)))
+    bad = [(k, fp32_err(g, go)) for k, (g, go) in r["grads"].items() if not grad_close_fp32(g, go, TOL_F32, name=k)]
+    assert not bad, bad
 
 
 def _full_size_setup(shape, seed, gate=None):
@@ -260,168 +270,19 @@ def test_full_size_bf16_path_matches_fp32_path(shape):
     f, h = res[torch.float32], res[torch.bfloat16]
     assert all(torch.isfinite(t).all() for t in h[:4])
     assert _l2(h[0], f[0]) < TOL_BF16 and _l2(h[1], f[1]) < TOL_BF16
-    assert _l2(h[2], f[2]) < 0.1 and _l2(h[3], f[3]) < 0.1
+    # The two paths take their OWN ReLU branches here (the fp32 path re-derives the bottleneck mask from Zp, it cannot be fed
+    # the bf16 run's), so this is the un-pinned comparison: measured 4.0-4.4 % (dX) / 4.1-5.4 % (dY) at these shapes.  The tight
+    # bounds -- device masks pinned, against the oracle, the 160-frame case included -- are tests/test_bf16_masked_gpu.py's.
+    assert _l2(h[2], f[2]) < 0.08 and _l2(h[3], f[3]) < 0.08, (_l2(h[2], f[2]), _l2(h[3], f[3]))
     bad = []
     for i, (a, b) in enumerate(zip(h[4], f[4])):
         if b is None or b.dim() == 0 or b.numel() <= 4096:
-            continue                                   # vectors / scalars: see test_real_shapes_bf16
+            continue                                   # vectors / scalars: tests/test_bf16_masked_gpu.py
         assert torch.isfinite(a).all(), PARAM_NAMES[i]
         e = _l2(a, b)
-        if not e < 0.15:
+        if not e < 0.12:
             bad.append((PARAM_NAMES[i], round(e, 4)))
     assert not bad, bad
-
-
-STAGE01 = [(2304, 128, 4096, 96), (4096, 96, 2304, 128), (576, 256, 1024, 192), (1024, 192, 576, 256)]
-
-
-@pytest.mark.parametrize("shape", STAGE01)
-def test_real_shapes_stage01_fp32(shape):
-    """the large-token stages (N up to 4096, the remap GEMMs with K = 4096 / 2304) against the oracle, one clip"""
-    r = _real_case(*shape, BT=10, dtype=torch.float32)
-    for k in ("out", "map", "dX", "dY"):
-        assert rel_err(*r[k]) < TOL_F32, k
-    for k, (g, go) in r["grads"].items():
-        assert grad_close_fp32(g, go, TOL_F32), (k, rel_err(g, go.reshape(-1)))
-
-
-@pytest.mark.parametrize("shape", [STAGE01[0], STAGE01[1]])
-def test_full_size_frames_are_independent(shape):
-    """BASELINE size (B=16 x T=10 = 160 frames, stage 0): with BatchNorm in eval mode no operation couples frames, so
-    the first clip of the 160-frame call must equal a 10-frame call on the same data (size-independent property;
-    exercises the full grids, the large-offset addressing and the XCD tile remap at the benchmark's shapes)."""
-    N, C, No, Co = shape
-    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
-    p = O.random_params(cfg, "ave", seed=5, scale=0.577)
-    spec = spec_of(cfg)
-    lib = default_lib()
-    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
-        params = param_table(p, spec, DEV)
-        gen = torch.Generator().manual_seed(7)
-        X = torch.randn(160, N, C, generator=gen).to(DEV, dtype)
-        Y = torch.randn(160, No, Co, generator=gen).to(DEV, dtype)
-        prep = ops.prepare(lib, spec, params, dtype, DEV)
-        big = ops.raw_forward(lib, spec, params, prep, X, Y, False)
-        small = ops.raw_forward(lib, spec, params, prep, X[:10].contiguous(), Y[:10].contiguous(), False)
-        torch.cuda.synchronize()
-        assert torch.isfinite(big[0].float()).all()
-        assert nrm_err(big[0][:10], small[0].float().cpu()) < tol
-        assert nrm_err(big[1][:10], small[1].float().cpu()) < tol
-        assert nrm_err(big[0][150:], ops.raw_forward(lib, spec, params, prep, X[150:].contiguous(), Y[150:].contiguous(),
-                                                     False)[0].float().cpu()) < tol
-
-
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL_F32), (torch.bfloat16, 2e-2)])
-def test_fused_residual_and_skip(dtype, tol):
-    """8f row f2 on the GPU: dgsct_adapter_forward_ex / backward_ex(skip_into_dx) vs the plain entry points."""
-    fx = load_golden("ave_orderB")
-    lib = default_lib()
-    base = run_library(lib, fx, DEV, dtype, training=True)
-    Rz = torch.randn(fx["X"].shape, generator=torch.Generator().manual_seed(5))
-    r = run_library(lib, fx, DEV, dtype, training=True, residual=Rz)
-    assert nrm_err(r["out"], base["out"].float().cpu() + Rz.to(dtype).float()) < tol
-    assert nrm_err(r["dX"], base["dX"].float().cpu()) < 1e-6 + (0 if dtype == torch.float32 else 1e-2)
-    r = run_library(lib, fx, DEV, dtype, training=True, skip=True)
-    X = fx["X"].to(dtype).float(); dO = fx["dOut"].to(dtype).float()
-    assert nrm_err(r["out"], base["out"].float().cpu() + X) < tol
-    assert nrm_err(r["dX"], base["dX"].float().cpu() + dO) < tol
-    assert nrm_err(r["dY"], base["dY"].float().cpu()) < 1e-6 + (0 if dtype == torch.float32 else 1e-2)
-
-
-@pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "avs_s4", "pretrain"])
-def test_results_do_not_depend_on_buffer_contents(name, monkeypatch):
-    """every output / scratch / saved-activation buffer is filled with NaN bit patterns before the call (ops._POISON):
-    a kernel that reads memory the call has not written yet would turn the results into NaN"""
-    monkeypatch.setattr(ops, "_POISON", True)
-    fx = load_golden(name)
-    r = run_library(default_lib(), fx, DEV, torch.float32, training=True)
-    assert rel_err(r["out"], fx["out"]) < TOL_F32 and rel_err(r["map"], fx["map"]) < TOL_F32
-    assert rel_err(r["dX"], fx["dX"]) < TOL_F32 and rel_err(r["dY"], fx["dY"]) < TOL_F32
-    for k, g in fx["grads"].items():
-        assert rel_err(r["grads"][k].reshape(g.shape), g) < TOL_F32, k
-    rb = run_library(default_lib(), fx, DEV, torch.bfloat16, training=True, skip=True)
-    assert all(torch.isfinite(rb[k].float()).all() for k in ("out", "map", "dX", "dY"))
-    assert all(torch.isfinite(g).all() for g in rb["grads"].values())
-
-
-@pytest.mark.parametrize("flat", [False, True])
-def test_stack_on_gpu_matches_reference_fixture(flat):
-    """SURVEY row a-10 on the device: 12 adapters through AdapterStack with everything the benchmark uses switched on
-    (two adapter streams, aux streams in forward and backward, fused residual/skip, flat parameters) against the
-    reference-generated stack fixture; repeated to give stream-ordering bugs a chance to show."""
-    from dgsct_amd import AdapterStack
-    from dgsct_amd.stack import default_opt
-    fx = load_golden("stack_2stage")
-    st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4), concurrent=True)
-    st.load_state_dict(fx["state0"])
-    st = st.to(DEV)
-    if flat:
-        st.flatten_parameters()
-    st.train()
-    for rep in range(3):
-        if rep:                                              # BN running stats moved in the previous repetition
-            st.load_state_dict(fx["state0"])
-        for p in st.parameters():
-            p.grad = None
-        feats = [(a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for a, b in fx["feats"]]
-        outs, maps = st(feats)
-        for (fv, fa), (rv, ra) in zip(outs, fx["outs"]):
-            assert rel_err(fv, rv) < TOL_F32 and rel_err(fa, ra) < TOL_F32
-        assert rel_err(maps[0], fx["maps"][0]) < TOL_F32 and rel_err(maps[1], fx["maps"][1]) < TOL_F32
-        torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
-                                [g.to(DEV) for pr in fx["cots"] for g in pr] + [fx["mcots"][0].to(DEV), fx["mcots"][1].to(DEV)])
-        torch.cuda.synchronize()
-        for (fv, fa), (gv, ga) in zip(feats, fx["dfeats"]):
-            assert rel_err(fv.grad, gv) < TOL_F32 and rel_err(fa.grad, ga) < TOL_F32
-        if flat:
-            n = 0
-            for name, m in st.named_modules():
-                if hasattr(m, "flat_param"):
-                    for pn, (off, cnt, shape) in m._flat_layout.items():
-                        ref = fx["grads"].get(name + "." + pn)
-                        if ref is not None:
-                            assert rel_err(m.flat_param.grad[off:off + cnt].view(shape), ref) < TOL_F32, name + "." + pn
-                            n += 1
-            assert n == len(fx["grads"])
-        else:
-            got = {k: p.grad for k, p in st.named_parameters() if p.grad is not None}
-            assert set(got) == set(fx["grads"])
-            for k, g in fx["grads"].items():
-                assert rel_err(got[k], g) < TOL_F32, k
-
-
-def test_module_dropin_matches_oracle():
-    """nn.Module boundary: reference call convention ([BT,C,N,1] views), state_dict names, autograd."""
-    from types import SimpleNamespace
-    from dgsct_amd import VisualAdapter
-    opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=8)
-    torch.manual_seed(0)
-    m = VisualAdapter(64, 64, "bottleneck", reduction_factor=8, opt=opt, use_bn=True, use_gate=True, num_tk=8,
-                      conv_dim_in=49, conv_dim_out=25, linear_in=48, linear_out=64).to(DEV)
-    with torch.no_grad():
-        m.gate.fill_(0.7); m.gate_av.fill_(0.3)
-    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    cfg = O.AdapterConfig(N=25, C=64, No=49, Co=48, tk=8, r=8, g=2)
-    BT = 10
-    f = torch.randn(BT, 25, 64, device=DEV, requires_grad=True)
-    fo = torch.randn(BT, 49, 48, device=DEV, requires_grad=True)
-    out, amap = m(f.permute(0, 2, 1).unsqueeze(-1), fo.permute(0, 2, 1).unsqueeze(-1))
-    assert out.shape == (BT, 64, 25, 1) and amap.shape == (BT, 1, 25)
-    g_out = torch.randn_like(out); g_map = torch.randn_like(amap)
-    (out * g_out).sum().add((amap * g_map).sum()).backward()
-    po = {k: v.clone() for k, v in sd.items()}
-    out_o, map_o, _, s = O.forward(po, f.detach().cpu(), fo.detach().cpu(), cfg, training=True)
-    dX_o, dY_o, g_o = O.backward(po, s, cfg, g_out.squeeze(-1).permute(0, 2, 1).cpu(), g_map.squeeze(1).cpu(), None)
-    assert rel_err(out.squeeze(-1).permute(0, 2, 1), out_o) < TOL_F32
-    assert rel_err(amap.squeeze(1), map_o) < TOL_F32
-    assert rel_err(f.grad, dX_o) < TOL_F32 and rel_err(fo.grad, dY_o) < TOL_F32
-    for k, p in m.named_parameters():
-        if k in g_o:
-            assert rel_err(p.grad, g_o[k].reshape(p.shape)) < TOL_F32, k
-        else:
-            assert p.grad is None or k in ("gate_tk",), k
-    assert int(m.bn1.num_batches_tracked) == 1
-    assert rel_err(m.bn2.running_mean, po["bn2.running_mean"]) < TOL_F32
 
 
 @pytest.mark.parametrize("flat", [False, True])

@@ -16,7 +16,7 @@ import os
 import pytest
 import torch
 
-from helpers import grad_close_fp32, nrm_err, param_table, rel_err, spec_of
+from helpers import fp32_err, grad_close_fp32, nrm_err, param_table, rel_err, spec_of
 from dgsct_amd import ops
 from dgsct_amd._lib import PARAM_NAMES, default_lib
 from oracle import dgsct_oracle as O
@@ -47,13 +47,18 @@ def run_case(N, C, No, Co, BT, dtype, flavour="ave", seed=0, over=None):
         X, Y, dOut = X.bfloat16().float(), Y.bfloat16().float(), dOut.bfloat16().float()
     po = {k: v.clone() for k, v in p.items()}
     out_o, map_o, _, s = O.forward(po, X, Y, cfg, training=True)
-    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, dTmap, training=True)
     spec = spec_of(cfg)
     params = param_table(p, spec, DEV)
     lib = default_lib()
     Xd, Yd = X.to(DEV, dtype).contiguous(), Y.to(DEV, dtype).contiguous()
     prep = ops.prepare(lib, spec, params, dtype, DEV)
     out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
+    masks = None
+    if dtype == torch.float32:          # fp32: the oracle differentiates the ReLU branches the device took (see test_adapter_gpu._real_case)
+        from helpers import device_relu_masks
+        torch.cuda.synchronize()
+        masks = device_relu_masks(lib, d, saved, spec, BT, dtype)
+    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, dTmap, training=True, masks=masks)
     dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(DEV, dtype).contiguous(),
                                      dMap.to(DEV), dTmap.to(DEV) if dTmap is not None else None)
     torch.cuda.synchronize()
@@ -65,12 +70,11 @@ def run_case(N, C, No, Co, BT, dtype, flavour="ave", seed=0, over=None):
 
 
 def check_fp32(r):
-    for k in ("out", "map", "dX", "dY"):
-        assert rel_err(*r[k]) < TOL_F32, (k, rel_err(*r[k]))
+    bad = [(k, fp32_err(*r[k])) for k in ("out", "map", "dX", "dY") if not fp32_err(*r[k]) < TOL_F32]
     assert not r["extra"] and not r["missing"], (r["extra"], r["missing"])
     assert r["grads"]
-    for k, (g, go) in r["grads"].items():
-        assert grad_close_fp32(g, go, TOL_F32), (k, rel_err(g, go.reshape(-1)))
+    bad += [(k, fp32_err(g, go)) for k, (g, go) in r["grads"].items() if not grad_close_fp32(g, go, TOL_F32, name=k)]
+    assert not bad, bad
 
 
 _B = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bounds.json")))
