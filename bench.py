@@ -128,7 +128,7 @@ def cpu_baseline(backbone, max_seconds=30.0):
 
     t_warm = one_pass()
     times = []
-    budget = max_seconds - t_warm
+    budget = max_seconds / 2 - t_warm
     while budget > 0 and len(times) < 3:
         t = one_pass()
         times.append(t)
@@ -136,6 +136,32 @@ def cpu_baseline(backbone, max_seconds=30.0):
     if not times:
         times = [t_warm]
     t = sorted(times)[len(times) // 2]
+
+    # B = 16 (the batch the GPU number is quoted on; SURVEY.md 8d: "B=16 ... fall back to per-stage timing and sum"): ONE
+    # forward+backward of each of the 8 distinct adapter shapes at BT = 160, scaled by how often the stack runs that shape --
+    # about a fifth of a full 48-adapter pass of CPU work (a full pass holds ~40 GB of saved activations and takes ~30 s)
+    t16, n16 = 0.0, 0
+    seen = {}
+    for cfg, p in adapters:
+        key = (cfg.N, cfg.C, cfg.No, cfg.Co)
+        seen.setdefault(key, [cfg, p, 0])[2] += 1
+    t_budget = time.perf_counter() + max_seconds
+    for key, (cfg, p, cnt) in seen.items():
+        if time.perf_counter() > t_budget:
+            t16 = None
+            break
+        X = torch.randn(160, cfg.N, cfg.C, requires_grad=True)
+        Y = torch.randn(160, cfg.No, cfg.Co, requires_grad=True)
+        t0 = time.perf_counter()
+        out, amap, _ = O.forward_autograd(p, X, Y, cfg, training=True)
+        torch.autograd.backward([out, amap], [torch.randn_like(out), torch.randn_like(amap)])
+        dt = time.perf_counter() - t0
+        for v in p.values():
+            if v.requires_grad:
+                v.grad = None
+        del out, amap, X, Y
+        t16 += cnt * dt
+        n16 += 1
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -144,11 +170,15 @@ def cpu_baseline(backbone, max_seconds=30.0):
                 break
     except OSError:
         pass
-    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=torch.get_num_threads(), kind="port", cpu_model=model,
-                logical_cpus=ncpu,
-                sample=f"1 clip (BT=10) x 48 adapters fwd+bwd, fp32, oracle.forward_autograd (ATen op-for-op port of the "
-                       f"reference adapter on token-major maps: at least as fast as the reference's permuted-view path), "
-                       f"thread count picked by a sweep, median of {len(times)} passes after 1 warm-up; {t:.2f} s/pass")
+    b1 = round(1.0 / t, 4)
+    b16 = round(16.0 / t16, 4) if t16 else None
+    return dict(value=b16 if b16 is not None else b1, unit="clips/s", cores=torch.get_num_threads(), kind="port", cpu_model=model,
+                logical_cpus=ncpu, value_b1=b1, value_b16=b16,
+                sample=(f"B=16: one fwd+bwd of each of the {n16} distinct adapter shapes at BT=160, weighted by the stack's call "
+                        f"counts (= {t16:.1f} s for the 48-adapter step; `value`); " if b16 is not None else "B=16 sample skipped (time budget); ") +
+                       f"B=1: 1 clip (BT=10) x 48 adapters, median of {len(times)} passes after 1 warm-up ({t:.2f} s/pass; `value_b1`).  "
+                       f"fp32, oracle.forward_autograd (ATen op-for-op port of the reference adapter on token-major maps: at least as fast "
+                       f"as the reference's permuted-view path), thread count picked by a sweep")
 
 
 def main():
@@ -157,6 +187,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU (T=10 frames each)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch clips on EVERY GPU (the driver's default); strong: --batch is the GLOBAL batch (BASELINE's fixed "
+                         "B=16), split over the ranks (must divide)")
     ap.add_argument("--backbone", default="swinv2_base", choices=["swinv2_base", "swinv2_large"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +221,12 @@ def main():
         init_process_group(device)       # "nccl" IS RCCL on ROCm (one process per GPU, bound to its device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     T = 10
-    BT = args.batch * T
+    per_gpu_batch = args.batch
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit(f"--scaling strong: the global batch {args.batch} is not divisible by {world} ranks")
+        per_gpu_batch = args.batch // world                 # clips of the fixed global batch that land on this rank
+    BT = per_gpu_batch * T
 
     stages, stack = build_stack(args.backbone, dtype, device, concurrent=not args.serial)
     stack.train()
@@ -312,7 +350,7 @@ def main():
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
     host_ms = [round(x / args.steps * 1e3, 2) for x in host_parts]
-    clips_per_s = args.batch * world / (elapsed / args.steps)
+    clips_per_s = per_gpu_batch * world / (elapsed / args.steps)
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -376,7 +414,7 @@ def main():
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
         tsrc = None
-        if tfiles and args.backbone == "swinv2_base" and args.batch == 16 and args.dtype == "bf16":
+        if tfiles and args.backbone == "swinv2_base" and per_gpu_batch == 16 and args.dtype == "bf16":
             # bytes through the L2's memory-side port (FETCH_SIZE x2 + WRITE_SIZE; separate rocprofv3 --pmc passes over the 8
             # adapter shapes of this exact workload, scaled by the schedule: tools/pmc_stack.sh + pmc_stack_summary.py)
             tj = json.load(open(tfiles[-1]))
@@ -390,6 +428,8 @@ def main():
                 step_block["bound_by_data"] = "hbm" if step_block["frac_of_hbm_peak"] > step_block["frac_of_mfma_peak"] else "mfma"
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                         traffic=traffic, traffic_unit=f"bytes/launch (PMC, {tsrc})" if tsrc else None,
+                        traffic_source=("committed: separate rocprofv3 --pmc passes over this workload's 8 adapter shapes "
+                                        "(tools/pmc_stack.sh), not measured in this run") if tsrc else None,
                         alg_bytes_per_launch=round(alg_bytes_per_step(stages, BT) / max(launches // nprof, 1)), kernel="dgsct::gemm_kernel<*> (all MFMA GEMM launches of a step)",
                         launches_per_step=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
@@ -404,11 +444,11 @@ def main():
             cpu = cpu_baseline(args.backbone)
         line = dict(
             metric="adapter_fwd_bwd_clips_per_sec", value=round(clips_per_s, 2), unit="clips/s", n_gpus=world,
-            steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak",
+            steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling=args.scaling,
             vs_baseline=None, dtype="bf16" if dtype == torch.bfloat16 else "f32", data="synthetic",
             config=dict(workload=f"AVE fine-tune adapter stack (BASELINE configs[1]): {args.backbone} + HTS-AT token/width "
-                                 f"shapes, 48 DG-SCT adapters, B={args.batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on",
-                        global_batch=args.batch * world, frames_per_clip=T, parallelism=f"dp{world}",
+                                 f"shapes, 48 DG-SCT adapters, B={per_gpu_batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on",
+                        global_batch=per_gpu_batch * world, frames_per_clip=T, parallelism=f"dp{world}",
                         step="fwd+bwd" + ("+allreduce" if dp else "") + ("" if args.no_optim else "+adam"),
                         streams=1 if args.serial else 2, hip_graph=use_graph, host_enqueue_ms_per_step=round(host_s / args.steps * 1e3, 2),
                         host_ms_fwdbwd_allreduce_optim=host_ms,
