@@ -64,7 +64,7 @@ class AttnArgs(C.Structure):
 
 
 EXPORTS = ["dgsct_test_gemm_fp8", "dgsct_temporal_gate_forward", "dgsct_temporal_gate_backward", "dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
-           "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_test_tune", "dgsct_prof_enable", "dgsct_prof_collect",
+           "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_test_tune", "dgsct_frame_scale_forward", "dgsct_frame_scale_backward", "dgsct_prof_enable", "dgsct_prof_collect",
            "dgsct_stream_create", "dgsct_stream_destroy", "dgsct_map_pool_forward", "dgsct_map_pool_backward"]
 
 _PP = C.POINTER(C.c_void_p)
@@ -103,6 +103,8 @@ class Lib:
         c.dgsct_test_gemm_fp8.argtypes = [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4
         c.dgsct_temporal_gate_forward.argtypes = [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 14
         c.dgsct_temporal_gate_backward.argtypes = [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 20
+        c.dgsct_frame_scale_forward.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_float] + [C.c_void_p] * 4
+        c.dgsct_frame_scale_backward.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_float] + [C.c_void_p] * 6
         c.dgsct_test_attn_scratch_floats.argtypes = [C.c_int] * 4
         c.dgsct_test_attn_scratch_floats.restype = C.c_int64
         c.dgsct_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -171,6 +173,12 @@ class Lib:
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         self.c.dgsct_prof_collect(C.byref(n), C.byref(ms), C.byref(fl))
         return n.value, ms.value, fl.value
+
+    def frame_scale_forward(self, dtype, rows, inner, gamma, x, g, y, stream):
+        self._check(self.c.dgsct_frame_scale_forward(dtype, rows, inner, gamma, x, g, y, stream), "dgsct_frame_scale_forward")
+
+    def frame_scale_backward(self, dtype, rows, inner, gamma, x, g, dy, dx, dg, stream):
+        self._check(self.c.dgsct_frame_scale_backward(dtype, rows, inner, gamma, x, g, dy, dx, dg, stream), "dgsct_frame_scale_backward")
 
     def temporal_gate_forward(self, R, D, gamma, *ptrs):
         self._check(self.c.dgsct_temporal_gate_forward(R, D, gamma, *ptrs), "dgsct_temporal_gate_forward")

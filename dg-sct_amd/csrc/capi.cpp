@@ -175,6 +175,26 @@ int dgsct_temporal_gate_backward(int R, int D, float gamma, const float* akv, co
   return has_error() ? 1 : 0;
 }
 
+int dgsct_frame_scale_forward(int dtype, int rows, int64_t inner, float gamma, const void* x, const float* g, void* y, void* stream) {
+  begin_call();
+  if (!x || !g || !y) { set_error("dgsct_frame_scale_forward: NULL argument"); return 2; }
+  if (dtype != DGSCT_F32 && dtype != DGSCT_BF16) { set_error("dgsct_frame_scale_forward: dtype"); return 2; }
+  Ctx ctx{stream, dtype};
+  frame_scale_fwd(ctx, rows, (long)inner, gamma, x, g, y);
+  check_async("dgsct_frame_scale_forward");
+  return has_error() ? 1 : 0;
+}
+int dgsct_frame_scale_backward(int dtype, int rows, int64_t inner, float gamma, const void* x, const float* g, const void* dy, void* dx,
+                               float* dg, void* stream) {
+  begin_call();
+  if (!x || !g || !dy) { set_error("dgsct_frame_scale_backward: NULL argument"); return 2; }
+  if (dtype != DGSCT_F32 && dtype != DGSCT_BF16) { set_error("dgsct_frame_scale_backward: dtype"); return 2; }
+  Ctx ctx{stream, dtype};
+  frame_scale_bwd(ctx, rows, (long)inner, gamma, x, g, dy, dx, dg);
+  check_async("dgsct_frame_scale_backward");
+  return has_error() ? 1 : 0;
+}
+
 int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
   begin_call();
   if (!a) return 2;

@@ -205,6 +205,12 @@ void temporal_gate_bwd(const Ctx&, int R, int D, float gamma, const float* akv, 
                        const float* wa, const float* wv, const float* ga, const float* gv, const float* dOv, const float* dOa,
                        const float* dg, float* dakv, float* dvkv, float* dvq, float* daq, float* dwa, float* dba, float* dwv, float* dbv);
 
+// Per-frame scalar gate on a feature block (TemporalAttention of AVVP mgn.py:155-156 / AVS PVT_AVSModel.py:572-577), dtype ctx.mode:
+//   y[r][i] = x[r][i] * (1 + gamma * g[r])                       r < rows, i < inner (inner * sizeof(E) a multiple of 16)
+//   dx = dy * (1 + gamma * g[r]) (optional);  dg[r] = gamma * sum_i dy[r][i] * x[r][i] (optional)
+void frame_scale_fwd(const Ctx&, int rows, long inner, float gamma, const void* x, const float* g, void* y);
+void frame_scale_bwd(const Ctx&, int rows, long inner, float gamma, const void* x, const float* g, const void* dy, void* dx, float* dg);
+
 // Small fp32/E elementwise helpers on [n]-sized vectors (n <= a few 100k).
 enum EwOp : int {
   EW_MUL = 0,          // o = a*b

@@ -128,4 +128,77 @@ void temporal_gate_bwd(const Ctx& ctx, int R, int D, float gamma, const float* a
   hipLaunchKernelGGL(tgate_bwd_k, dim3(wgs), dim3(256), 0, s, p);
 }
 
+// ---- per-frame scalar gate on a feature block (TemporalAttention of AVVP mgn.py:155-156 and of the AVS decoder scales
+// PVT_AVSModel.py:572-577): y[r][i] = x[r][i] * (1 + gamma * g[r]), x one frame's [inner] block ([128] features or a [C,H,W] map).
+// Forward: one pass, 16-byte accesses.  Backward: dx = dy * (1 + gamma g[r]) and dg[r] = gamma * sum_i dy x in the same pass
+// (a frame is split over `chunks` workgroups; one fp32 atomic per workgroup into the pre-zeroed dg).
+template <int DT>
+__global__ __launch_bounds__(256) void frame_scale_fwd_k(const void* x, const float* g, void* y, long inner, float gamma, int chunks) {
+  constexpr int V = El<DT>::VMAX;
+  const long r = blockIdx.y;
+  const float sc = 1.f + gamma * g[r];
+  const long n = inner / V, per = (n + chunks - 1) / chunks;
+  const long i0 = (long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+    float v[V];
+    ldv<DT, V>(x, r * inner + i * V, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] *= sc;
+    stv<DT, V>(y, r * inner + i * V, v);
+  }
+  if (blockIdx.x == chunks - 1)
+    for (long i = n * V + threadIdx.x; i < inner; i += 256) ste<DT>(y, r * inner + i, lde<DT>(x, r * inner + i) * sc);
+}
+template <int DT>
+__global__ __launch_bounds__(256) void frame_scale_bwd_k(const void* x, const float* g, const void* dy, void* dx, float* dg, long inner,
+                                                         float gamma, int chunks) {
+  constexpr int V = El<DT>::VMAX;
+  __shared__ float red[8];
+  const long r = blockIdx.y;
+  const float sc = 1.f + gamma * g[r];
+  const long n = inner / V, per = (n + chunks - 1) / chunks;
+  const long i0 = (long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+  float acc = 0.f;
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+    float a[V], b[V];
+    ldv<DT, V>(dy, r * inner + i * V, a);
+    ldv<DT, V>(x, r * inner + i * V, b);
+#pragma unroll
+    for (int e = 0; e < V; ++e) { acc += a[e] * b[e]; a[e] *= sc; }
+    if (dx) stv<DT, V>(dx, r * inner + i * V, a);
+  }
+  if (blockIdx.x == chunks - 1)
+    for (long i = n * V + threadIdx.x; i < inner; i += 256) {
+      const float a = lde<DT>(dy, r * inner + i);
+      acc += a * lde<DT>(x, r * inner + i);
+      if (dx) ste<DT>(dx, r * inner + i, a * sc);
+    }
+  const float t = block_sum(acc, red);
+  if (threadIdx.x == 0 && dg) unsafeAtomicAdd(dg + r, gamma * t);
+}
+static int fs_chunks(int rows, long inner, int V) {
+  long c = (1024 + rows - 1) / rows;                    // >= ~1024 workgroups, each with >= 2048 vectors
+  const long maxc = inner / V / 2048 + 1;
+  if (c > maxc) c = maxc;
+  return (int)(c < 1 ? 1 : c);
+}
+void frame_scale_fwd(const Ctx& ctx, int rows, long inner, float gamma, const void* x, const float* g, void* y) {
+  if (rows <= 0 || inner <= 0) return;
+  const bool al = (inner % (ctx.mode == DT_BF16 ? 8 : 4)) == 0;
+  if (!al) { set_error("frame_scale: the per-frame block (%ld elements) must be a multiple of 16 bytes", inner); return; }
+  const int ch = fs_chunks(rows, inner, ctx.mode == DT_BF16 ? 8 : 4);
+  if (ctx.mode == DT_BF16) hipLaunchKernelGGL(frame_scale_fwd_k<DT_BF16>, dim3(ch, rows), dim3(256), 0, (hipStream_t)ctx.stream, x, g, y, inner, gamma, ch);
+  else hipLaunchKernelGGL(frame_scale_fwd_k<DT_F32>, dim3(ch, rows), dim3(256), 0, (hipStream_t)ctx.stream, x, g, y, inner, gamma, ch);
+}
+void frame_scale_bwd(const Ctx& ctx, int rows, long inner, float gamma, const void* x, const float* g, const void* dy, void* dx, float* dg) {
+  if (rows <= 0 || inner <= 0) return;
+  const bool al = (inner % (ctx.mode == DT_BF16 ? 8 : 4)) == 0;
+  if (!al) { set_error("frame_scale: the per-frame block (%ld elements) must be a multiple of 16 bytes", inner); return; }
+  hipStream_t s = (hipStream_t)ctx.stream;
+  if (dg) (void)hipMemsetAsync(dg, 0, (size_t)rows * 4, s);
+  const int ch = fs_chunks(rows, inner, ctx.mode == DT_BF16 ? 8 : 4);
+  if (ctx.mode == DT_BF16) hipLaunchKernelGGL(frame_scale_bwd_k<DT_BF16>, dim3(ch, rows), dim3(256), 0, s, x, g, dy, dx, dg, inner, gamma, ch);
+  else hipLaunchKernelGGL(frame_scale_bwd_k<DT_F32>, dim3(ch, rows), dim3(256), 0, s, x, g, dy, dx, dg, inner, gamma, ch);
+}
+
 }  // namespace dgsct

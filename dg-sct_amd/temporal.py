@@ -227,3 +227,144 @@ class TemporalAttention(nn.Module):
         al, vl = self.audio_gated[0], self.video_gated[0]
         return _TemporalGateFn.apply(lib, self.gamma, audio_key_value_feature, video_key_value_feature, video_query_output,
                                      audio_query_output, al.weight, al.bias, vl.weight, vl.bias)
+
+
+# ---- the other two copies of the class -----------------------------------------------------------
+class _FrameScaleFn(torch.autograd.Function):
+    """y[r] = x[r] * (1 + gamma * g[r]) for per-frame gates g [rows]: one HIP kernel each way (dgsct_frame_scale_*)."""
+
+    @staticmethod
+    def forward(ctx, lib, gamma, x, g):
+        xc = x.contiguous()
+        gc = g.reshape(-1).contiguous().float()
+        rows = gc.numel()
+        inner = xc.numel() // rows
+        y = torch.empty_like(xc)
+        dt = _lib.BF16 if xc.dtype == torch.bfloat16 else _lib.F32
+        with _dev_guard(xc):
+            lib.frame_scale_forward(dt, rows, inner, float(gamma), xc.data_ptr(), gc.data_ptr(), y.data_ptr(),
+                                    torch.cuda.current_stream(xc.device).cuda_stream if xc.is_cuda else None)
+        ctx.lib, ctx.gamma, ctx.gshape, ctx.gdtype = lib, float(gamma), g.shape, g.dtype
+        ctx.save_for_backward(xc, gc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, gc = ctx.saved_tensors
+        dyc = dy.contiguous()
+        rows = gc.numel()
+        inner = xc.numel() // rows
+        dx = torch.empty_like(xc) if ctx.needs_input_grad[2] else None
+        dg = torch.empty(rows, dtype=torch.float32, device=xc.device) if ctx.needs_input_grad[3] else None
+        dt = _lib.BF16 if xc.dtype == torch.bfloat16 else _lib.F32
+        with _dev_guard(xc):
+            ctx.lib.frame_scale_backward(dt, rows, inner, ctx.gamma, xc.data_ptr(), gc.data_ptr(), dyc.data_ptr(),
+                                         dx.data_ptr() if dx is not None else None, dg.data_ptr() if dg is not None else None,
+                                         torch.cuda.current_stream(xc.device).cuda_stream if xc.is_cuda else None)
+        return None, None, dx, (dg.view(ctx.gshape).to(ctx.gdtype) if dg is not None else None)
+
+
+def frame_scale(x: torch.Tensor, g: torch.Tensor, gamma: float, lib=None) -> torch.Tensor:
+    """``x + g * x * gamma`` with ONE gate per leading-dimension frame of ``x`` (g broadcast over everything else)."""
+    if not x.is_cuda and lib is None:
+        raise RuntimeError("dg-sct_amd.frame_scale runs on MI355X through libdgsct.so; there is no CPU path")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("dg-sct_amd.frame_scale supports float32 and bfloat16")
+    return _FrameScaleFn.apply(lib or _lib.default_lib(), gamma, x, g)
+
+
+class _RNNEncoderFull(nn.Module):
+    """AVVP/nets/mgn.py:39-52: unlike the AVE / AVS copies, BOTH bi-LSTMs have d_model hidden units."""
+
+    def __init__(self, audio_dim, video_dim, d_model, num_layers):
+        super().__init__()
+        self.d_model = d_model
+        self.audio_rnn = nn.LSTM(audio_dim, d_model, num_layers=num_layers, batch_first=True, bidirectional=True, dropout=0.2)
+        self.visual_rnn = nn.LSTM(video_dim, d_model, num_layers=num_layers, batch_first=True, bidirectional=True, dropout=0.2)
+
+    def forward(self, audio_feature, visual_feature):
+        return self.audio_rnn(audio_feature)[0], self.visual_rnn(visual_feature)[0]
+
+
+class TemporalAttentionAVVP(nn.Module):
+    """AVVP copy, ``DG-SCT/AVVP/nets/mgn.py:107-159``: 128-wide features both ways, d_model 64, no input FCs, no decoders; the
+    gates (computed from the OTHER modality's encoder output) scale the INPUT features: ``x + gate * x * gamma``, gamma 0.05."""
+
+    def __init__(self, lib=None):
+        super().__init__()
+        self._lib = lib
+        self.beta = 0.4
+        self.video_input_dim = 128
+        self.audio_input_dim = 128
+        self.video_fc_dim = 128
+        self.audio_fc_dim = 128
+        self.d_model = 64
+        self.video_encoder = InternalTemporalRelationModule(input_dim=self.video_input_dim, d_model=self.d_model, feedforward_dim=1024)
+        self.audio_encoder = InternalTemporalRelationModule(input_dim=self.audio_input_dim, d_model=self.d_model, feedforward_dim=1024)
+        self.audio_visual_rnn_layer = _RNNEncoderFull(audio_dim=self.audio_input_dim, video_dim=self.video_input_dim,
+                                                      d_model=self.d_model, num_layers=1)
+        self.audio_gated = nn.Sequential(nn.Linear(self.d_model, 1), nn.Sigmoid())
+        self.video_gated = nn.Sequential(nn.Linear(self.d_model, 1), nn.Sigmoid())
+        self.alpha = 0.05
+        self.gamma = 0.05
+
+    def forward(self, visual_feature, audio_feature):
+        """[B, 10, 128] each -> (video_query_output, audio_query_output), same shapes"""
+        a_rnn, v_rnn = self.audio_visual_rnn_layer(audio_feature, visual_feature)
+        video_kv = self.video_encoder(v_rnn.transpose(1, 0).contiguous())
+        audio_kv = self.audio_encoder(a_rnn.transpose(1, 0).contiguous())
+        audio_gate = self.audio_gated(audio_kv).transpose(1, 0)             # [B, T, 1]
+        video_gate = self.video_gated(video_kv).transpose(1, 0)
+        return (frame_scale(visual_feature, audio_gate, self.gamma, self._lib),
+                frame_scale(audio_feature, video_gate, self.gamma, self._lib))
+
+
+class TemporalAttentionAVS(nn.Module):
+    """AVS copy, ``avs_s4/model/PVT_AVSModel.py:447-582``: one set of blocks per decoder scale (``ModuleList`` x 4), the visual
+    inputs are the four [B*5, 256, H, W] maps (average-pooled to per-frame vectors for the gates), the audio gate of a scale
+    scales that scale's whole MAP per frame, the four video gates are averaged and scale the audio feature; gamma 0.05.
+    (`video_decoder` / `audio_decoder` outputs are computed by the reference and never used; they are constructed here for
+    the checkpoint format and skipped in forward -- they receive no gradient in the reference either.)"""
+
+    def __init__(self, lib=None):
+        super().__init__()
+        self._lib = lib
+        self.gamma = 0.05
+        self.video_input_dim = 256
+        self.audio_input_dim = 128
+        self.video_fc_dim = 256
+        self.audio_fc_dim = 128
+        self.d_model = 256
+        self.v_fc = nn.ModuleList([nn.Linear(self.video_input_dim, self.video_fc_dim) for _ in range(4)])
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(0.2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.video_encoder = nn.ModuleList([InternalTemporalRelationModule(input_dim=512, d_model=self.d_model, feedforward_dim=1024) for _ in range(4)])
+        self.video_decoder = nn.ModuleList([CrossModalRelationAttModule(input_dim=512, d_model=self.d_model, feedforward_dim=1024) for _ in range(4)])
+        self.audio_encoder = nn.ModuleList([InternalTemporalRelationModule(input_dim=self.d_model, d_model=self.d_model, feedforward_dim=1024) for _ in range(4)])
+        self.audio_decoder = nn.ModuleList([CrossModalRelationAttModule(input_dim=self.d_model, d_model=self.d_model, feedforward_dim=1024) for _ in range(4)])
+        self.audio_visual_rnn_layer = nn.ModuleList([RNNEncoder(audio_dim=self.audio_input_dim, video_dim=self.video_input_dim,
+                                                                d_model=self.d_model, num_layers=1) for _ in range(4)])
+        self.audio_gated = nn.ModuleList([nn.Sequential(nn.Linear(self.d_model, 1), nn.Sigmoid()) for _ in range(4)])
+        self.video_gated = nn.ModuleList([nn.Sequential(nn.Linear(self.d_model, 1), nn.Sigmoid()) for _ in range(4)])
+
+    def forward(self, visual_feature_list, audio_feature):
+        """visual_feature_list: four [B*5, 256, H_i, W_i] maps; audio_feature [B, 5, 128] ->
+        ([x1, x2, x3, x4] gated maps, audio_feature [B*5, 128] gated)"""
+        bs = audio_feature.size(0)
+        T = 5
+        audio_rnn_input = audio_feature
+        audio_flat = audio_feature.reshape(-1, audio_feature.size(-1))
+        outs, vgates = [], []
+        for i, x in enumerate(visual_feature_list):
+            xv = self.dropout(self.relu(self.v_fc[i](self.avgpool(x).reshape(bs, T, -1))))
+            a_rnn, v_rnn = self.audio_visual_rnn_layer[i](audio_rnn_input, xv)
+            a_in = a_rnn.transpose(1, 0).contiguous()                      # [5, B, 256]
+            v_in = v_rnn.transpose(1, 0).contiguous()                      # [5, B, 512]
+            video_kv = self.video_encoder[i](v_in)
+            audio_kv = self.audio_encoder[i](a_in)
+            audio_gate = self.audio_gated[i](audio_kv).transpose(1, 0).reshape(bs * T)
+            vgates.append(self.video_gated[i](video_kv).transpose(1, 0).reshape(bs * T, 1))
+            outs.append(frame_scale(x, audio_gate, self.gamma, self._lib))
+        video_gate = (vgates[0] + vgates[1] + vgates[2] + vgates[3]) / 4
+        return outs, frame_scale(audio_flat, video_gate, self.gamma, self._lib)

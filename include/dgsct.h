@@ -184,6 +184,16 @@ int dgsct_temporal_gate_backward(int R, int D, float gamma, const float* akv, co
                                  const float* dOa, const float* dg, float* dakv, float* dvkv, float* dvq, float* daq, float* dwa,
                                  float* dba, float* dwv, float* dbv, void* stream);
 
+/* Per-frame scalar gate on a feature block: the tail of the AVVP / AVS copies of TemporalAttention
+ * (`x + gate * x * gamma` with one gate per frame: AVVP/nets/mgn.py:155-156 on [B*10][128] features,
+ * avs_s4/model/PVT_AVSModel.py:572-577 on the four [B*5][256][H][W] decoder maps).
+ *   forward : y[r][i] = x[r][i] * (1 + gamma * g[r])                       r < rows, i < inner
+ *   backward: dx = dy * (1 + gamma * g[r]) (NULL: skipped);  dg[r] = gamma * sum_i dy[r][i] x[r][i] (NULL: skipped)
+ * dtype DGSCT_F32 | DGSCT_BF16 for x / y / dy / dx; g, dg fp32; inner * element size must be a multiple of 16 bytes. */
+int dgsct_frame_scale_forward(int dtype, int rows, int64_t inner, float gamma, const void* x, const float* g, void* y, void* stream);
+int dgsct_frame_scale_backward(int dtype, int rows, int64_t inner, float gamma, const void* x, const float* g, const void* dy,
+                               void* dx, float* dg, void* stream);
+
 /* ---- introspection / test hooks (used by tests/ only) ------------------------------------------ */
 /* i-th named region of the `saved` buffer; returns 0 and fills name/offset/bytes, or 1 past the end. */
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes);

@@ -83,5 +83,95 @@ def main():
     print("temporal.pt written:", len(sd), "tensors,", sum(v.numel() for v in sd.values()), "parameters;", len(never), "never get a gradient")
 
 
+def _ns():
+    import copy
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch.nn import Dropout, LayerNorm, Linear, Module, ModuleList, MultiheadAttention
+    ns = dict(torch=torch, nn=nn, F=F, copy=copy, Dropout=Dropout, LayerNorm=LayerNorm, Linear=Linear, Module=Module,
+              ModuleList=ModuleList, MultiheadAttention=MultiheadAttention)
+    exec(extract(os.path.join(REF, "models.py"), {"Encoder", "Decoder", "EncoderLayer", "DecoderLayer", "_get_clones",
+                                                   "_get_activation_fn"}), ns)
+    ns["CMBS_Encoder"] = ns["Encoder"]                 # AVVP/nets/mgn.py:28 imports it under this name
+    return ns
+
+
+def _variant(ref_cls, mine_cls, inputs, out_name, flatten):
+    """seeded construction must reproduce the reference's parameters; outputs / input gradients / gradient norms are stored"""
+    SEED = 4321
+    torch.manual_seed(SEED)
+    ref = ref_cls().eval()
+    torch.manual_seed(SEED)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    from build_emu import build_emu                      # the host-emulated kernel library (test infrastructure)
+    from dgsct_amd._lib import Lib
+    mine = mine_cls(lib=Lib(build_emu())).eval()
+    sd = ref.state_dict()
+    assert list(sd) == list(mine.state_dict()), "state_dict keys / order differ from the reference"
+    for k, v in mine.state_dict().items():
+        assert torch.equal(v, sd[k]), f"seeded construction differs from the reference at {k}"
+    ins = [t.clone().requires_grad_(True) for t in flatten(inputs)]
+    outs = flatten(ref(*_pack(inputs, ins)))
+    g = torch.Generator().manual_seed(11)
+    cots = [torch.randn(o.shape, generator=g) for o in outs]
+    torch.autograd.backward(outs, cots)
+    pg = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+    # the drop-in (host-emulated gate kernel) against the reference, here, before anything is written
+    ins2 = [t.detach().clone().requires_grad_(True) for t in ins]
+    outs2 = flatten(mine(*_pack(inputs, ins2)))
+    torch.autograd.backward(outs2, cots)
+    for a, b in zip(outs2, outs):
+        assert (a - b).abs().max() < 2e-5, (out_name, float((a - b).abs().max()))
+    for a, b in zip(ins2, ins):
+        assert (a.grad - b.grad).abs().max() < 2e-5 * max(1.0, float(b.grad.abs().max())), out_name
+    never = sorted(k for k, p in ref.named_parameters() if p.grad is None)
+    assert never == sorted(k for k, p in mine.named_parameters() if p.grad is None), "different parameters go without a gradient"
+    fx = dict(seed=SEED, inputs=[t.detach() for t in ins], cots=cots, outs=[o.detach() for o in outs], d_inputs=[t.grad.clone() for t in ins],
+              keys=list(sd), param_sum={k: float(v.double().sum()) for k, v in sd.items()},
+              grad_norm={k: float(v.double().norm()) for k, v in pg.items()}, grad_sum={k: float(v.double().sum()) for k, v in pg.items()},
+              no_grad=never)
+    torch.save(fx, os.path.join(ROOT, "tests", "golden", out_name))
+    print(out_name, "written:", len(sd), "tensors,", sum(v.numel() for v in sd.values()), "parameters;", len(never), "never get a gradient")
+
+
+def _pack(template, flat):
+    """re-nest `flat` like `template` (a tuple whose first element may be a list of tensors)"""
+    out, i = [], 0
+    for t in template:
+        if isinstance(t, (list, tuple)):
+            out.append(list(flat[i:i + len(t)])); i += len(t)
+        else:
+            out.append(flat[i]); i += 1
+    return out
+
+
+def _flat(x):
+    out = []
+    for t in (x if isinstance(x, (list, tuple)) else [x]):
+        out += list(t) if isinstance(t, (list, tuple)) else [t]
+    return out
+
+
+def main_variants():
+    """the AVVP and AVS copies of the class: DG-SCT/AVVP/nets/mgn.py:107-159,
+    DG-SCT/AVS/avs_scripts/avs_s4/model/PVT_AVSModel.py:447-582"""
+    import dgsct_amd  # noqa: F401
+    from dgsct_amd.temporal import TemporalAttentionAVS, TemporalAttentionAVVP
+    g = torch.Generator().manual_seed(5)
+    ns = _ns()
+    exec(extract("/root/reference/DG-SCT/AVVP/nets/mgn.py", {"RNNEncoder", "InternalTemporalRelationModule",
+                                                             "CrossModalRelationAttModule", "TemporalAttention"}), ns)
+    B = 3
+    _variant(ns["TemporalAttention"], TemporalAttentionAVVP,
+             (torch.randn(B, 10, 128, generator=g), torch.randn(B, 10, 128, generator=g)), "temporal_avvp.pt", _flat)
+    ns = _ns()
+    exec(extract("/root/reference/DG-SCT/AVS/avs_scripts/avs_s4/model/PVT_AVSModel.py",
+                 {"RNNEncoder", "InternalTemporalRelationModule", "CrossModalRelationAttModule", "TemporalAttention"}), ns)
+    B = 2
+    maps = [torch.randn(B * 5, 256, hw, hw, generator=g) for hw in (4, 3, 2, 1)]      # (56, 28, 14, 7 in the model: same code path)
+    _variant(ns["TemporalAttention"], TemporalAttentionAVS, (maps, torch.randn(B, 5, 128, generator=g)), "temporal_avs.pt", _flat)
+
+
 if __name__ == "__main__":
     main()
+    main_variants()

@@ -637,6 +637,21 @@ void colsum_multi(const Ctx&, const ColsumSeg* segs, int nseg) {
       segs[s].out[c] += (float)a;
     }
 }
+void frame_scale_fwd(const Ctx& ctx, int rows, long inner, float gamma, const void* x, const float* g, void* y) {
+  for (int r = 0; r < rows; ++r)
+    for (long i = 0; i < inner; ++i) st(y, ctx.mode, (long)r * inner + i, ld(x, ctx.mode, (long)r * inner + i) * (1.f + gamma * g[r]));
+}
+void frame_scale_bwd(const Ctx& ctx, int rows, long inner, float gamma, const void* x, const float* g, const void* dy, void* dx, float* dg) {
+  for (int r = 0; r < rows; ++r) {
+    double acc = 0;
+    for (long i = 0; i < inner; ++i) {
+      const float a = ld(dy, ctx.mode, (long)r * inner + i);
+      acc += (double)a * ld(x, ctx.mode, (long)r * inner + i);
+      if (dx) st(dx, ctx.mode, (long)r * inner + i, a * (1.f + gamma * g[r]));
+    }
+    if (dg) dg[r] = (float)(gamma * acc);
+  }
+}
 void temporal_gate_fwd(const Ctx&, int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
                        const float* wa, const float* ba, const float* wv, const float* bv, float* out_v, float* out_a, float* gate,
                        float* ga, float* gv) {

@@ -101,3 +101,79 @@ def test_temporal_gate_kernel_vs_torch(R, D):
         assert (a.detach().cpu() - b.detach()).abs().max().item() < 1e-5
     for a, b in zip(dins, ins):
         assert (a.grad.cpu() - b.grad).abs().max().item() < 1e-4 * max(1.0, b.grad.abs().max().item())
+
+
+# ---- the AVVP and AVS copies of the class (mgn.py:107-159, avs_s4/model/PVT_AVSModel.py:447-582) -------------------------------
+def _variant(name):
+    from dgsct_amd.temporal import TemporalAttentionAVS, TemporalAttentionAVVP
+    fx = torch.load(os.path.join(GOLDEN, f"temporal_{name}.pt"), weights_only=False)
+    return fx, (TemporalAttentionAVVP if name == "avvp" else TemporalAttentionAVS)
+
+
+def _flat(x):
+    out = []
+    for t in (x if isinstance(x, (list, tuple)) else [x]):
+        out += list(t) if isinstance(t, (list, tuple)) else [t]
+    return out
+
+
+def _run_variant(name, lib, device, tol):
+    fx, cls = _variant(name)
+    torch.manual_seed(fx["seed"])
+    m = cls(lib=lib).eval()
+    sd = m.state_dict()
+    assert list(sd) == fx["keys"]                                       # reference names, reference order
+    for k, v in sd.items():
+        assert abs(float(v.double().sum()) - fx["param_sum"][k]) <= 1e-9 * max(1.0, abs(fx["param_sum"][k])), k
+    m = m.to(device)
+    ins = [t.to(device).requires_grad_(True) for t in fx["inputs"]]
+    args = (ins[0], ins[1]) if name == "avvp" else (ins[:4], ins[4])
+    outs = _flat(m(*args))
+    assert len(outs) == len(fx["outs"])
+    for got, ref in zip(outs, fx["outs"]):
+        assert got.shape == ref.shape and (got.detach().cpu() - ref).abs().max().item() < tol
+    torch.autograd.backward(outs, [c.to(device) for c in fx["cots"]])
+    for t, ref in zip(ins, fx["d_inputs"]):
+        assert (t.grad.cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(fx["grad_norm"])
+    assert sorted(k for k, p in m.named_parameters() if p.grad is None) == fx["no_grad"]
+    for k, g in got.items():
+        n = float(g.double().norm())
+        assert abs(n - fx["grad_norm"][k]) <= 10 * tol * max(1e-3, fx["grad_norm"][k]), (k, n, fx["grad_norm"][k])
+
+
+@pytest.mark.parametrize("name", ["avvp", "avs"])
+def test_temporal_variants_match_reference_cpu(name):
+    """state_dict keys / seeded parameters / outputs / input gradients / every parameter-gradient norm of the reference's AVVP and
+    AVS `TemporalAttention`, with the per-frame gate application on the host emulation of the HIP kernel"""
+    _run_variant(name, Lib(build_emu()), torch.device("cpu"), 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["avvp", "avs"])
+def test_temporal_variants_match_reference_gpu(name):
+    _run_variant(name, default_lib(), torch.device("cuda:0"), 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(50, 256, 14, 14), (10, 256, 56, 56), (320, 128), (7, 8)])
+def test_frame_scale_kernel(dtype, shape):
+    """dgsct_frame_scale_*: y = x (1 + gamma g[frame]) on [B*5, C, H, W] decoder maps / [B*10, 128] features, both ways"""
+    from dgsct_amd.temporal import frame_scale
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=gen).to(dtype)
+    g = torch.rand(shape[0], generator=gen)
+    cot = torch.randn(*shape, generator=gen).to(dtype)
+    xd, gd = x.to(dev).requires_grad_(True), g.to(dev).requires_grad_(True)
+    y = frame_scale(xd, gd, 0.05)
+    y.backward(cot.to(dev))
+    xr, gr = x.float().requires_grad_(True), g.clone().requires_grad_(True)
+    yr = xr * (1 + 0.05 * gr.view(-1, *([1] * (len(shape) - 1))))
+    yr.backward(cot.float())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert (y.float().cpu() - yr).abs().max().item() <= tol * max(1.0, yr.abs().max().item())
+    assert (xd.grad.float().cpu() - xr.grad).abs().max().item() <= tol * max(1.0, xr.grad.abs().max().item())
+    assert (gd.grad.cpu() - gr.grad).abs().max().item() <= (1e-4 if dtype == torch.float32 else 2e-2) * max(1.0, gr.grad.abs().max().item())
