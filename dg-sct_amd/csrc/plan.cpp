@@ -742,13 +742,13 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       outE(g3, dY, E, Co, (long)No * Co);
       gemm(ctx, g3);
     }
-    if (conv) {
-      rowdot_batched(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), DT_F32, 0, nullptr, nullptr, b.Wk<float>(wb.rowtmp));
-      sum_batch(ctx, b.Wk<float>(wb.rowtmp), N, B, N, G(DGSCT_P_BN), 1.f, 1);                            // dbn
-      colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, b.Wk<float>(wb.dwcsum), 0);   // d rowsum(Wc)
-    } else {
-      colsum_batched(ctx, dYp, C, (long)N * C, B, N, C, b.rowb(), 0, 1.f, G(DGSCT_P_BC), 0);
-    }
+    // both bias-side reductions of dYp in one pass (they were rowdot -> sum_batch and colsum: two more reads of the cotangent)
+    if (conv)                                                    // dbn[n] = sum dYp . colb;  d rowsum(Wc)[c] = sum rowb[n] dYp
+      rowdot_colsum(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), b.rowb(), G(DGSCT_P_BN), b.Wk<float>(wb.dwcsum),
+                    b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+    else
+      rowdot_colsum(ctx, dYp, C, (long)N * C, B, N, C, nullptr, b.rowb(), nullptr, G(DGSCT_P_BC), b.Wk<float>(wb.rowpart),
+                    row_part_floats(B, C));
   }
   side_flush();
   stream_join(ctx);

@@ -93,6 +93,11 @@ void colsum_batched(const Ctx&, const void* x, long ld, long bs, int B, int N, i
 // out[b][n] = sum_c x[b][n][c] * w[b*w_bs + c] * (w2 ? w2[c] : 1) + (bias ? *bias : 0).   w dtype wdt.
 void rowdot_batched(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const void* w, int wdt, long w_bs,
                     const float* w2, const float* bias, float* out);
+// Both reductions of one [B][N][C] tensor (E) in a single pass; outputs fp32, PRE-ZEROED, either may be null:
+//   out_row[n] += sum_{b,c} x[b][n][c] * w[c]          out_col[c] += sum_{b,n} roww[n] * x[b][n][c]    (roww null -> 1)
+// part / part_floats: optional scratch (>= row_part_floats(B, C)) for the per-workgroup partial column sums.
+void rowdot_colsum(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const float* w, const float* roww,
+                   float* out_row, float* out_col, float* part = nullptr, long part_floats = 0);
 // out[i] = (accumulate ? out[i] : 0) + scale * sum_b in[b*bs + i]
 void sum_batch(const Ctx&, const float* in, long bs, int B, long n, float* out, float scale, int accumulate);
 // y[b][n][c] = x[b][n][c] * (add + colw[b][c])         x,y are E (may alias)

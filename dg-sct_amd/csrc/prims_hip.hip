@@ -778,6 +778,96 @@ void rowdot_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int 
 }
 
 // ================================================================================================
+// rowdot_colsum: the two bias-gradient reductions of the remap backward in ONE pass over dYp (plan.cpp B1)
+//   out_row[n] += sum_b sum_c x[b][n][c] * w[c]            (d conv_adapter.bias;  optional)
+//   out_col[c] += sum_b sum_n roww[n] * x[b][n][c]         (d rowsum(Wc) / d fc.bias of the bicubic flavour;  optional)
+// They were rowdot_batched -> sum_batch and colsum_batched: two full reads of the [R, C] cotangent plus a third launch at
+// the very end of every adapter backward (214 us of a 6 ms stage-0 adapter call).  A lane group owns token row n for FPG
+// frames in turn, so the row dot is summed over those frames in registers before its single atomic (one per (n, frame
+// group) instead of one per (n, frame): atomics on one address serialise at the memory side), and the per-channel sums
+// stay in registers for the whole walk.  FPG frames' loads are issued together (independent addresses).
+// ================================================================================================
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256) void rowdot_colsum_k(const void* x, long ld, long bs, int B, int N, int C, const float* w,
+                                                       const float* roww, int gs, int nv, int rpc, int fpg, float* out_row,
+                                                       float* out_col, float* part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
+  const int b0 = blockIdx.y * fpg, b1 = imin_d(B, b0 + fpg);
+  float ww[MAXNV][VE], acc[1][MAXNV][VE];
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v) {
+    const int col = (v * gs + gl) * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { ww[v][e] = 0.f; acc[0][v][e] = 0.f; }
+    if (w && v < nv && col < C) ldv<DT_F32, VE>(w, col, ww[v]);
+  }
+  constexpr int FU = 4;                                       // frames in flight per row
+  for (int n = blockIdx.x * rpc + sub; n < n_end; n += rpp) {
+    const float rw = roww ? roww[n] : 1.f;
+    float s = 0.f;
+    for (int bb = b0; bb < b1; bb += FU) {
+      float t[FU][MAXNV][VE];
+#pragma unroll
+      for (int u = 0; u < FU; ++u) {
+        const int bc = bb + u < b1 ? bb + u : b1 - 1;         // unconditional, clamped loads; masked below
+#pragma unroll
+        for (int v = 0; v < MAXNV; ++v) {
+          const int col = (v * gs + gl) * VE;
+          ldv<DT, VE>(x, (long)bc * bs + (long)n * ld + ((v < nv && col < C) ? col : 0), t[u][v]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < FU; ++u) {
+        const float m = bb + u < b1 ? 1.f : 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXNV; ++v) {
+          const int col = (v * gs + gl) * VE;
+          const float mv = (v < nv && col < C) ? m : 0.f;
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            s += mv * t[u][v][e] * ww[v][e];
+            acc[0][v][e] += mv * rw * t[u][v][e];
+          }
+        }
+      }
+    }
+    if (out_row) {
+      s = group_sum(s, gs);
+      if (gl == 0) unsafeAtomicAdd(out_row + n, s);
+    }
+  }
+  float* const dst[1] = {out_col};
+  if (out_col) flush_cols<1, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst, part);
+}
+
+void rowdot_colsum(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const float* w, const float* roww,
+                   float* out_row, float* out_col, float* part, long part_floats) {
+  int ve = row_ve(ctx, C);
+  if (ld % ve != 0 || bs % ve != 0) { set_error("rowdot_colsum: unaligned ld/bs"); return; }
+  if (!out_row && !out_col) return;
+  const int fpg = B >= 8 ? 8 : B;                              // frames per lane group: 8 x fewer atomics per out_row address
+  const int groups = (B + fpg - 1) / fpg;
+  RowGeom g = row_geom(C, ve, N, groups);
+  const size_t sh = (size_t)(256 / g.gs) * C * sizeof(float);  // flush_cols: one row of C floats per row-group
+  {
+    int cap = 1024;
+    ROW_CAPACITY(cap, ctx, C, g.nv, rowdot_colsum_k, sh);
+    g = row_geom(C, ve, N, groups, cap, 1, true);
+  }
+  static const int use_part = env_int("DGSCT_ROW_PART", 1);
+  if (!use_part || !out_col || (long)g.chunks * groups * C > part_floats) part = nullptr;
+  ROW_DISPATCH_SH(ctx, C, g.nv, rowdot_colsum_k, dim3(g.chunks, groups), sh, x, ld, bs, B, N, C, w, roww, g.gs, g.nv, g.rpc, fpg,
+                  out_row, out_col, part);
+  if (part) {
+    PartTable t; t.NQ = 1; t.C = C;
+    t.d[0] = PartDesc{0, 1, g.chunks * groups, 1, out_col, 0, 1.f};
+    part_reduce(ctx.stream, part, t, 1);
+  }
+}
+
+// ================================================================================================
 // softmax over rows (fp32 logits in, E/fp32 probabilities out)
 // ================================================================================================
 // short rows (L <= 64): a group of GS lanes per row

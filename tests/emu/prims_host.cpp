@@ -157,6 +157,24 @@ void rowdot_batched(const Ctx& ctx, const void* x, long ldx, long bs, int B, int
     }
 }
 
+void rowdot_colsum(const Ctx& ctx, const void* x, long ldx, long bs, int B, int N, int C, const float* w, const float* roww,
+                   float* out_row, float* out_col, float*, long) {
+  if (out_row)
+    for (int n = 0; n < N; ++n) {
+      double s = 0;
+      for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) s += (double)ld(x, ctx.mode, (long)b * bs + (long)n * ldx + c) * w[c];
+      out_row[n] += (float)s;
+    }
+  if (out_col)
+    for (int c = 0; c < C; ++c) {
+      double s = 0;
+      for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) s += (double)(roww ? roww[n] : 1.f) * ld(x, ctx.mode, (long)b * bs + (long)n * ldx + c);
+      out_col[c] += (float)s;
+    }
+}
+
 void sum_batch(const Ctx&, const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
   for (long i = 0; i < n; ++i) {
     double s = 0;
