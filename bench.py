@@ -430,7 +430,7 @@ def main():
                         traffic=traffic, traffic_unit=f"bytes/launch (PMC, {tsrc})" if tsrc else None,
                         traffic_source=("committed: separate rocprofv3 --pmc passes over this workload's 8 adapter shapes "
                                         "(tools/pmc_stack.sh), not measured in this run") if tsrc else None,
-                        alg_bytes_per_launch=round(alg_bytes_per_step(stages, BT) / max(launches // nprof, 1)), kernel="dgsct::gemm_kernel<*> (all MFMA GEMM launches of a step)",
+                        alg_bytes_per_launch=round(alg_bytes_per_step(stages, BT) / max(launches // nprof, 1)), kernel="dgsct::gemm_kernel<*> + gemm8_kernel<*> (all MFMA GEMM launches of a step)",
                         launches_per_step=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
                         gemm_ms_per_step=round(gemm_ms / nprof, 3), heaviest_launch=heaviest,

@@ -1,5 +1,5 @@
 # Regenerates the measured artefacts of a round on the GPU box:  bash tools/profile_round.sh r02
-tag=${1:-r02}
+tag=${1:-r03}
 python bench.py --steps 20 --warmup 5 2>/dev/null | grep "^{" | tail -1 > gpurun_out/${tag}_bench.json
 bash tools/pmc_stack.sh 2>&1 | tail -1
 python tools/pmc_stack_summary.py $tag gpurun_out/${tag}_bench.json

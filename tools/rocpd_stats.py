@@ -23,7 +23,7 @@ def main(path, top=40):
     # family roll-up
     fam = {}
     for name, n, tot, mn, mx in rows:
-        k = "gemm_kernel<*>" if "gemm_kernel" in name else ("torch/other" if "dgsct" not in name else re.sub(r"<.*", "", short(name)))
+        k = "gemm_kernel<*>" if ("gemm_kernel" in name or "gemm8_kernel" in name) else ("torch/other" if "dgsct" not in name else re.sub(r"<.*", "", short(name)))
         a = fam.setdefault(k, [0, 0])
         a[0] += n; a[1] += tot
     print("# by family")

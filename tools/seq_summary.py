@@ -17,6 +17,8 @@ for f in glob.glob(os.path.join(sys.argv[1], "seq_*.txt")):
             continue
         us, grid, name = float(m.group(1)), m.group(2), m.group(3)
         fam = re.sub(r"<.*", "", name)
+        if fam == "gemm8_kernel":
+            fam = "gemm8 (deep products)"
         if fam == "gemm_kernel":
             g = [int(x) for x in grid.split(",")]
             wgs = g[0] * g[1] * g[2]
