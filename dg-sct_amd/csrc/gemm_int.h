@@ -16,4 +16,9 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g);
 // 0: off, 1: on for shapes that fill the chip (default; DGSCT_GEMM8), 2: on for every eligible shape (tests).  set < 0: query.
 int gemm8_mode(int set);
 
+// Skinny products (M <= 256 rows, both operands K-major: the per-frame gate MLPs): one 32 x 32 tile per workgroup, contraction split
+// over its four waves, operands straight to registers (gemm_skinny.hip).  Same contract as gemm8_try.
+bool gemm_skinny_try(const Ctx& ctx, const Gemm& g);
+int gemm_skinny_mode(int set);      // 0: off, 1: on (default; DGSCT_GEMM_SKINNY).  set < 0: query.
+
 }  // namespace dgsct

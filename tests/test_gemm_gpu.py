@@ -278,3 +278,39 @@ def test_gemm8_is_actually_used(gemm8_all):
     finally:
         os.environ.pop("DGSCT_PROF_DUMP", None)
         lib.prof_enable(False)
+
+
+# ---- gemm_skinny.hip: [BT, C] x [C, C] gate-MLP products, contraction split over the four waves of a 32 x 32 tile ---------------
+def test_gemm_skinny_epilogues_and_edges():
+    """every epilogue the adapter schedule uses on these products (plan.cpp F2, F4-F6, B4, B6): bias + ReLU / sigmoid, fp32 or bf16
+    out, the ReLU mask of another tensor, an fp32 residual; ragged M (not a multiple of 32), N = 48, K from 64 to 1536"""
+    run_case(1, 160, 512, 512, 1, 1, epi=dict(bias_n=True, act=1), out_bf16=True)          # aq1 / q
+    run_case(1, 160, 256, 512, 1, 1, epi=dict(bias_n=True, act=2))                          # ch (fp32 out, sigmoid)
+    run_case(1, 160, 256, 512, 1, 1, epi=dict(mask=True), out_bf16=True)                    # dq = (dpre . Wcatt) * (q > 0)
+    run_case(1, 160, 512, 256, 1, 1, epi=dict(R=True, rdt=0))                               # da += dpa2 . Wa2 (fp32 residual)
+    run_case(1, 160, 1024, 1024, 1, 1, epi=dict(bias_n=True, act=1), out_bf16=True)
+    run_case(1, 160, 1536, 1536, 1, 1, epi=dict(bias_n=True, act=1), out_bf16=True)
+    run_case(1, 50, 48, 64, 1, 1)                                                           # one k-step per wave, ragged M, N = 48
+    run_case(1, 7, 96, 192, 1, 1, out_bf16=True)
+    run_case(1, 256, 384, 768, 1, 1, epi=dict(bias_n=True))
+
+
+def test_gemm_skinny_is_actually_used():
+    import csv, os, tempfile
+    lib = default_lib()
+    assert lib.test_tune("skinny", -1) == 1
+    lib.prof_enable(True)
+    try:
+        path = os.path.join(tempfile.mkdtemp(), "g.csv")
+        os.environ["DGSCT_PROF_DUMP"] = path
+        run_case(1, 160, 512, 512, 1, 1, epi=dict(bias_n=True, act=1), out_bf16=True)
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] == "10", rows[-1]
+        run_case(1, 160, 512, 96, 1, 1, out_bf16=True)                                      # K % 64 != 0: tiled engine
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] != "10", rows[-1]
+    finally:
+        os.environ.pop("DGSCT_PROF_DUMP", None)
+        lib.prof_enable(False)

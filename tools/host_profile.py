@@ -16,7 +16,8 @@ for name in acc:
 dev = torch.device("cuda:0")
 stages, stack = bench.build_stack("swinv2_base", torch.bfloat16, dev, concurrent="--serial" not in sys.argv)
 stack.train()
-feats, cots, mcots = bench.make_inputs(stages, 160, torch.bfloat16, dev, 1)
+BT = int(os.environ.get("BT", "160"))
+feats, cots, mcots = bench.make_inputs(stages, BT, torch.bfloat16, dev, 1)
 params = [p for p in stack.parameters()]
 def step():
     outs, maps = stack(feats)
