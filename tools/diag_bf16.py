@@ -1,3 +1,4 @@
+import os
 """GPU diagnostic: bf16 errors (relative L2) of every output / gradient at a real shape."""
 import sys
 import torch

@@ -1,7 +1,9 @@
+import os
 """diagnostic (not a test): margins of test_full_size_bf16_path_matches_fp32_path over repeated runs"""
 import sys
 import torch
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import param_table, spec_of
 from dgsct_amd import ops
 from dgsct_amd._lib import PARAM_NAMES, default_lib

@@ -1,5 +1,6 @@
+import os
 """GPU diagnostic (not a pytest file): run one golden case through libdgsct.so and print, per saved
-intermediate / output / gradient, the error against the oracle.  `python tests/diag_gpu.py [case] [bf16]`."""
+intermediate / output / gradient, the error against the oracle.  `python tools/diag_gpu.py [case] [bf16]`."""
 import sys
 
 import torch

@@ -1,8 +1,10 @@
+import os
 """diagnostic (not a test): repeat one full-size forward+backward many times and report the largest run-to-run deviation
 (atomic summation order alone gives ~1e-6; anything larger is a race)"""
 import sys
 import torch
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import param_table, spec_of
 from dgsct_amd import ops
 from dgsct_amd._lib import PARAM_NAMES, default_lib
