@@ -1,6 +1,8 @@
-import os
 """GPU diagnostic: bf16 errors (relative L2) of every output / gradient at a real shape."""
+import os
 import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from test_adapter_gpu import _real_case, _l2
 shape = [int(x) for x in sys.argv[1:5]] if len(sys.argv) > 4 else [144, 512, 256, 384]

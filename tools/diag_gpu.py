@@ -1,7 +1,9 @@
-import os
 """GPU diagnostic (not a pytest file): run one golden case through libdgsct.so and print, per saved
 intermediate / output / gradient, the error against the oracle.  `python tools/diag_gpu.py [case] [bf16]`."""
+import os
 import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch
 
