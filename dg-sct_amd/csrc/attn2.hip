@@ -40,7 +40,7 @@ __device__ __forceinline__ void wave_sync() {
 }
 __device__ __forceinline__ bfx8 ldg8(const unsigned short* p) { return __builtin_bit_cast(bfx8, *reinterpret_cast<const uint4*>(p)); }
 __device__ __forceinline__ bfx8 lds8(const char* p) { return *reinterpret_cast<const bfx8*>(p); }
-__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned pack2(float a, float b) { return f2bf2(a, b); }
 // accumulator registers [8k, 8k + 8) of a [latent token x token] tile as the bf16 B-operand fragment of k-step k
 __device__ __forceinline__ bfx8 regs_frag(const float* v) {
   uint4 u = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void tok_pack_k(const PackArgs p) {
       for (int e = 0; e < 8; e += 2) {
         const unsigned short h0 = f2bf(x[e]), h1 = f2bf(x[e + 1]);
         hw[e >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
-        lw[e >> 1] = (unsigned)f2bf(x[e] - bf2f(h0)) | ((unsigned)f2bf(x[e + 1] - bf2f(h1)) << 16);
+        lw[e >> 1] = f2bf2(x[e] - bf2f(h0), x[e + 1] - bf2f(h1));
       }
       *reinterpret_cast<uint4*>(hiF + f * 8) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
       *reinterpret_cast<uint4*>(loF + f * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void tok_pack_k(const PackArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         const int t0 = 16 * kk + 4 * h + (e & 3) + 8 * (e >> 2);
-        w[e >> 1] = (unsigned)f2bf(t0 < p.tk ? x[e] : 0.f) | ((unsigned)f2bf(t0 + 1 < p.tk ? x[e + 1] : 0.f) << 16);
+        w[e >> 1] = f2bf2(t0 < p.tk ? x[e] : 0.f, t0 + 1 < p.tk ? x[e + 1] : 0.f);
       }
       *reinterpret_cast<uint4*>(TF + f * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }

@@ -25,13 +25,15 @@ inline int wg_capacity(const void* fn, size_t shmem) {
 }
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-// round-to-nearest-even, NaN preserved (same rounding as torch.Tensor.to(torch.bfloat16))
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+// round-to-nearest-even (same rounding as torch.Tensor.to(torch.bfloat16)): gfx950's v_cvt_pk_bf16_f32, one instruction per PAIR --
+// the integer add-and-shift version was 5-6 VALU instructions per element, a third of the instruction stream of the row kernels
+typedef __attribute__((ext_vector_type(2))) float du_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 du_bf16x2_t;
+__device__ __forceinline__ unsigned f2bf2(float lo, float hi) {
+  const du_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, du_bf16x2_t));
 }
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
 template <int DT> struct El;
 template <> struct El<DT_F32>  { static constexpr int ES = 4; static constexpr int VMAX = 4; };
@@ -97,12 +99,12 @@ __device__ __forceinline__ void stv(void* p, long i, const float (&v)[VE]) {
     if (VE == 8) {
       unsigned w[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+      for (int e = 0; e < 4; ++e) w[e] = f2bf2(v[2 * e], v[2 * e + 1]);
       *reinterpret_cast<uint4*>(q) = make_uint4(w[0], w[1], w[2], w[3]);
     } else if (VE == 4) {
       unsigned w[2];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) w[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+      for (int e = 0; e < 2; ++e) w[e] = f2bf2(v[2 * e], v[2 * e + 1]);
       *reinterpret_cast<uint2*>(q) = make_uint2(w[0], w[1]);
     } else {
 #pragma unroll

@@ -579,8 +579,8 @@ void gemm_kernel(const GemmK p) {
               *reinterpret_cast<float4*>(drow + (long)t0 * 4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
             } else {
               uint2 w;
-              w.x = (unsigned)f2bf(v[4 * q]) | ((unsigned)f2bf(v[4 * q + 1]) << 16);
-              w.y = (unsigned)f2bf(v[4 * q + 2]) | ((unsigned)f2bf(v[4 * q + 3]) << 16);
+              w.x = f2bf2(v[4 * q], v[4 * q + 1]);
+              w.y = f2bf2(v[4 * q + 2], v[4 * q + 3]);
               *reinterpret_cast<uint2*>(drow + (long)t0 * 2) = w;
             }
           } else {

@@ -413,6 +413,14 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     }
   }
   // F8 ---- modulation + ln_before                                       :611-627
+  // (stages 0-1: one pass with the down-projection and the BN1 sums, see modln_gproj)
+  const bool fuse89 = modln_gproj_supported(ctx.mode, C, ds, g);
+  if (fuse89)
+    modln_gproj(ctx, b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta, d.gamma,
+                d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C, ds, g,
+                b.F(DGSCT_P_WD), (long)(ds / g) * (C / g), C / g, 1, b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S(s.Zp),
+                d.use_bn && d.training ? b.S<float>(s.bnacc1) : nullptr);
+  else
   modln_fwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta,
             d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C,
             b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b));
@@ -424,7 +432,8 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     // dimensions -> vector-unit row kernels (prims_proj.hip) instead of 80 %-padded MFMA tiles
     const bool vproj = gproj_supported(ctx.mode, C, ds, g);
     const long cgl = C / g, dgl = ds / g;
-    if (vproj) {
+    if (fuse89) {
+    } else if (vproj) {
       gproj_narrow(ctx, b.S(s.X3), R, C, ds, g, b.F(DGSCT_P_WD), dgl * cgl, cgl, 1, b.S(s.Zp));     // Zp = X3 (x)_g Wd
     } else {
       Gemm g1 = mk((int)R, ds / g, C / g, g);                    // Zp = X3 (x)_g Wd
@@ -434,7 +443,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       gemm(ctx, g1);
     }
     if (d.use_bn) {
-      if (d.training) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
+      if (d.training && !fuse89) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
       bn_finalize(ctx, b.S<float>(s.bnacc1), R, ds, b.F(DGSCT_P_BN1_W), b.F(DGSCT_P_BN1_B), b.Fm(DGSCT_P_BN1_RM),
                   b.Fm(DGSCT_P_BN1_RV), d.bn_momentum, d.eps, d.training, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds);
     }

@@ -138,6 +138,11 @@ long row_part_floats(int B, int C);
 // wide + stats (3*C floats, pre-zeroed): also accumulates bn_stats(y) in the same pass.
 bool gproj_supported(int mode, int C, int ds, int g);
 void gproj_narrow(const Ctx&, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc, void* y);
+// modln_fwd + gproj_narrow + bn_stats(y) in one pass over X1 (lnw may be null; stats null = no sums)
+bool modln_gproj_supported(int mode, int C, int ds, int g);
+void modln_gproj(const Ctx&, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta, float gamma,
+                 const float* lnw, const float* lnb, float eps, int B, int N, int C, int ds, int g, const float* W, long wsg, long wsj,
+                 long wsc, void* X3, float* mu, float* rstd, void* y, float* stats);
 void gproj_wide(const Ctx&, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc, void* y,
                 float* stats);
 

@@ -937,8 +937,8 @@ __global__ __launch_bounds__(256) void softmax_long_vec_k(const float* in, long 
     const float4 o = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);   // exp(-inf) = 0 beyond L
     if (OBF) {
       uint2 w;
-      w.x = (unsigned)f2bf(o.x) | ((unsigned)f2bf(o.y) << 16);
-      w.y = (unsigned)f2bf(o.z) | ((unsigned)f2bf(o.w) << 16);
+      w.x = f2bf2(o.x, o.y);
+      w.y = f2bf2(o.z, o.w);
       reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + r * ld_out)[c4] = w;
     } else {
       reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * ld_out)[c4] = o;
@@ -974,8 +974,8 @@ __global__ __launch_bounds__(256) void softmax_bwd_long_vec_k(const void* P, lon
     const int c4 = threadIdx.x + i * 256;
     if (c4 * 4 >= ldo) continue;
     uint2 w;
-    w.x = (unsigned)f2bf(sc * p[i].x * (g[i].x - pd)) | ((unsigned)f2bf(sc * p[i].y * (g[i].y - pd)) << 16);
-    w.y = (unsigned)f2bf(sc * p[i].z * (g[i].z - pd)) | ((unsigned)f2bf(sc * p[i].w * (g[i].w - pd)) << 16);
+    w.x = f2bf2(sc * p[i].x * (g[i].x - pd), sc * p[i].y * (g[i].y - pd));
+    w.y = f2bf2(sc * p[i].z * (g[i].z - pd), sc * p[i].w * (g[i].w - pd));
     reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + r * ldo)[c4] = w;
   }
   if (dot_accum && threadIdx.x == 0) unsafeAtomicAdd(dot_accum, pd);

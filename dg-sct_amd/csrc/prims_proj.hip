@@ -144,6 +144,243 @@ void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g
 #undef NARROW_
 }
 
+// ---- modulation + ln_before + narrow + BatchNorm sums in ONE pass ------------------------------------------------------
+// F8 + F9a of the forward schedule (net_trans.py:611-613, 626-631) for the vector-projection shapes (stages 0-1):
+//   X2 = X1 * (alpha ch + beta sg + gamma tg + 1 - alpha);  X3 = LN_C(X2) [optional];  Zp = X3 (x)_g Wd;  BN1 sums of Zp
+// were three launches (modln_fwd, gproj_narrow, bn_stats: 74 + 55 + 29 us at 655 360 x 96) that read X1, X3 and Zp from HBM;
+// here the row stays in the registers of its lane group from the X1 load to the Zp store: X1 is read once, X3 / mu / rstd /
+// Zp are written (the backward needs them), nothing is re-read.  The projection consumes X3 AS STORED (rounded to E) and the
+// statistics are those of Zp AS STORED, so the numbers are the three-launch path's.  stats layout = bn_stats' (shift = row 0
+// of the tensor, which every lane group recomputes for itself: one extra row per group).
+template <int DT, int VE, int PROJ_DG, int PROJ_UNR, int GS>
+__global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void modln_gproj_k(const void* X1, const float* ch, const float* sg, const float* tg,
+                                                     float alpha, float beta, float gamma, const float* lnw, const float* lnb, float eps,
+                                                     int N, int C, int ds, int g, const float* W, long wsg, long wsj, long wsc,
+                                                     int rpc, void* X3, float* mu, float* rstd, void* y, float* stats) {
+  constexpr int gs = GS;
+  __shared__ __attribute__((aligned(16))) float lds[PROJ_UNR * (256 * PROJ_DG + 128 * 8)];
+  const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const int cg = C / g, dg = ds / g, lpg = cg / VE;
+  const int col = gl * VE;
+  const bool valid = col < C;
+  const int colc = valid ? col : 0;
+  const int gi = colc / cg, cl0 = colc - gi * cg;
+  for (int i = threadIdx.x; i < ds * cg; i += 256) {
+    const int cl = i % cg, j = i / cg, gq = j / dg, jl = j - gq * dg;
+    lds[i] = W[gq * wsg + jl * wsj + (long)cl * wsc];
+  }
+  __syncthreads();
+  float w[PROJ_DG][VE];
+#pragma unroll
+  for (int jl = 0; jl < PROJ_DG; ++jl)
+#pragma unroll
+    for (int e = 0; e < VE; ++e) w[jl][e] = (valid && jl < dg) ? lds[(gi * dg + jl) * cg + cl0 + e] : 0.f;
+  __syncthreads();
+  float lw[VE], lb[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { lw[e] = 1.f; lb[e] = 0.f; }
+  if (lnw) { ldf<VE>(lnw, colc, lw); ldf<VE>(lnb, colc, lb); }
+  const int slot_stride = gs * PROJ_DG + 8;
+  float* const slot0 = lds + sub * slot_stride;
+  const int unr_stride = 256 * PROJ_DG + 128 * 8;
+  const int oq = gl / dg, ojl = gl - oq * dg;
+  const float invC = 1.f / (float)C;
+  auto modulation = [&](int b, float (&cm)[VE]) {
+    float t[VE];
+    ldf<VE>(ch + (long)b * C, colc, t);
+    const float tgv = tg ? gamma * tg[b] : 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) cm[e] = alpha * t[e] + 1.f - alpha + tgv;
+  };
+  // PROJ_UNR rows of this lane group: load, modulate, normalise, (store X3, mu, rstd), project; out[u] = Zp[row u][gl] in
+  // the lanes gl < ds
+  // a row vector is 16 bytes in either mode (8 bf16 / 4 fp32): kept raw while in flight
+  auto rowload = [&](const long (&row)[PROJ_UNR], uint4 (&raw)[PROJ_UNR], float (&sgv)[PROJ_UNR]) {
+#pragma unroll
+    for (int u = 0; u < PROJ_UNR; ++u) {
+      raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(X1) + (row[u] * C + colc) * (DT == DT_BF16 ? 2 : 4));
+      sgv[u] = beta * sg[row[u]];
+    }
+  };
+  auto rowpass = [&](const long (&row)[PROJ_UNR], const bool (&ok)[PROJ_UNR], const float (&cm)[VE], bool store, const uint4 (&raw)[PROJ_UNR],
+                     const float (&sgv)[PROJ_UNR], float (&out)[PROJ_UNR]) {
+    float t[PROJ_UNR][VE];
+#pragma unroll
+    for (int u = 0; u < PROJ_UNR; ++u) {
+      const unsigned r4[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (DT == DT_BF16) { t[u][(2 * i) % VE] = __uint_as_float(r4[i] << 16); t[u][(2 * i + 1) % VE] = __uint_as_float(r4[i] & 0xffff0000u); }
+        else t[u][i % VE] = __uint_as_float(r4[i]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PROJ_UNR; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { t[u][e] = valid ? t[u][e] * (cm[e] + sgv[u]) : 0.f; s += t[u][e]; }
+      if (lnw) {
+        const float mean = group_sum(s, gs) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { const float d = valid ? t[u][e] - mean : 0.f; q += d * d; }
+        const float rs = rsqrtf(group_sum(q, gs) * invC + eps);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) t[u][e] = (t[u][e] - mean) * rs * lw[e] + lb[e];
+        if (store && ok[u] && gl == 0) { mu[row[u]] = mean; rstd[row[u]] = rs; }
+      }
+      if (DT == DT_BF16) {                              // round once: the stored X3 and the projection operand are the same bits
+        unsigned pk[VE / 2];
+#pragma unroll
+        for (int i = 0; i < VE / 2; ++i) pk[i] = f2bf2(t[u][2 * i], t[u][2 * i + 1]);
+        if (store && ok[u] && valid)
+          *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(X3) + row[u] * C + col) = make_uint4(pk[0], pk[1], pk[2 % (VE / 2)], pk[3 % (VE / 2)]);
+#pragma unroll
+        for (int i = 0; i < VE / 2; ++i) { t[u][2 * i] = __uint_as_float(pk[i] << 16); t[u][2 * i + 1] = __uint_as_float(pk[i] & 0xffff0000u); }
+      } else if (store && ok[u] && valid) {
+        stv<DT, VE>(X3, row[u] * C + col, t[u]);
+      }
+      if (!(valid && ok[u])) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) t[u][e] = 0.f;
+      }
+      float p[PROJ_DG];
+#pragma unroll
+      for (int jl = 0; jl < PROJ_DG; ++jl) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) a += t[u][e] * w[jl][e];
+        p[jl] = a;
+      }
+      float4* dst = reinterpret_cast<float4*>(slot0 + u * unr_stride + gl * PROJ_DG);
+#pragma unroll
+      for (int q4 = 0; q4 < PROJ_DG / 4; ++q4) dst[q4] = make_float4(p[4 * q4], p[4 * q4 + 1], p[4 * q4 + 2], p[4 * q4 + 3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < PROJ_UNR; ++u) {
+      float s = 0.f;
+      if (gl < ds) {
+        const float* src = slot0 + u * unr_stride + oq * lpg * PROJ_DG + ojl;
+        for (int i = 0; i < lpg; ++i) s += src[i * PROJ_DG];
+      }
+      out[u] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto rounded = [](float v) { return DT == DT_BF16 ? bf2f(f2bf(v)) : v; };
+
+  float sft = 0.f, acc0 = 0.f, acc1 = 0.f;
+  float cm[VE];
+  if (stats) {                                        // shift = Zp[0][gl] (row 0 of frame 0), recomputed by every lane group
+    long row[PROJ_UNR]; bool ok[PROJ_UNR]; float out[PROJ_UNR];
+#pragma unroll
+    for (int u = 0; u < PROJ_UNR; ++u) { row[u] = 0; ok[u] = true; }
+    uint4 t[PROJ_UNR]; float sgv[PROJ_UNR];
+    modulation(0, cm);
+    rowload(row, t, sgv);
+    rowpass(row, ok, cm, false, t, sgv, out);
+    sft = rounded(out[0]);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && sub == 0 && gl < ds) stats[gl] = sft;
+  }
+  const int b = blockIdx.y;
+  modulation(b, cm);
+  const int n0 = blockIdx.x * rpc;
+  const int n_end = imin_d(N, n0 + rpc);
+  const long base = (long)b * N;
+  // the next trip's rows are in flight while this one is normalised and projected (unconditional loads from clamped rows)
+  auto rows_of = [&](int nb, long (&row)[PROJ_UNR], bool (&ok)[PROJ_UNR]) {
+#pragma unroll
+    for (int u = 0; u < PROJ_UNR; ++u) {
+      const int n = nb + u * rpp + sub;
+      ok[u] = n < n_end;
+      row[u] = base + (ok[u] ? n : n_end - 1);
+    }
+  };
+  uint4 tc[PROJ_UNR]; float sc_[PROJ_UNR];
+  {
+    long row[PROJ_UNR]; bool ok[PROJ_UNR];
+    rows_of(n0, row, ok);
+    rowload(row, tc, sc_);
+  }
+  for (int nb = n0; nb < n_end; nb += rpp * PROJ_UNR) {
+    long row[PROJ_UNR], rown[PROJ_UNR]; bool ok[PROJ_UNR], okn[PROJ_UNR]; float out[PROJ_UNR];
+    uint4 tn[PROJ_UNR]; float sn[PROJ_UNR];
+    rows_of(nb, row, ok);
+    rows_of(nb + rpp * PROJ_UNR, rown, okn);
+    rowload(rown, tn, sn);
+    rowpass(row, ok, cm, true, tc, sc_, out);
+#pragma unroll
+    for (int u = 0; u < PROJ_UNR; ++u) {
+      if (gl < ds && ok[u]) {
+        ste<DT>(y, row[u] * ds + gl, out[u]);
+        const float d = rounded(out[u]) - sft;
+        acc0 += d; acc1 += d * d;
+      }
+      tc[u] = tn[u];
+      sc_[u] = sn[u];
+    }
+  }
+  if (stats) {                                        // combine the row slots of the workgroup, one atomic per channel and sum
+    __syncthreads();
+    if (gl < ds) { lds[sub * ds + gl] = acc0; lds[256 + sub * ds + gl] = acc1; }      // rpp * ds <= 256 (ds <= gs)
+    __syncthreads();
+    if (threadIdx.x < 2 * ds) {
+      const int q = threadIdx.x / ds, c = threadIdx.x - q * ds;
+      float s = 0.f;
+      for (int r = 0; r < rpp; ++r) s += lds[q * 256 + r * ds + c];
+      unsafeAtomicAdd(stats + ds + q * ds + c, s);
+    }
+  }
+}
+
+bool modln_gproj_supported(int mode, int C, int ds, int g) {
+  static const int off = getenv("DGSCT_NO_ROWFUSE") ? atoi(getenv("DGSCT_NO_ROWFUSE")) : 0;
+  ProjGeom pg;
+  return !off && proj_geom(mode, C, ds, g, 1 << 20, 1024, pg) && (pg.gs == 16 || pg.gs == 32);
+}
+
+void modln_gproj(const Ctx& ctx, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta, float gamma,
+                 const float* lnw, const float* lnb, float eps, int B, int N, int C, int ds, int g, const float* W, long wsg, long wsj,
+                 long wsc, void* X3, float* mu, float* rstd, void* y, float* stats) {
+  ProjGeom pg;
+  if (!proj_geom(ctx.mode, C, ds, g, N, 1, pg) || (pg.gs != 16 && pg.gs != 32)) {
+    set_error("modln_gproj: unsupported shape C=%d ds=%d g=%d", C, ds, g);
+    return;
+  }
+  const bool big = ds / g > 8, bf = ctx.mode == DT_BF16, g32 = pg.gs == 32;
+  const int unr = big ? 2 : 4;
+  const int trip = pg.rpp * unr;
+  int rpc = 0;
+  long chunks = 0;
+#define MG_(DT_, VE_, DG_, UNR_, GS_)                                                                                                   \
+  do {                                                                                                                                  \
+    if (!rpc) {                                     /* a reduction (BN sums): one round of resident workgroups */                        \
+      long cap = wg_capacity(reinterpret_cast<const void*>(&modln_gproj_k<DT_, VE_, DG_, UNR_, GS_>), 0);                                \
+      if (cap > 2048) cap = 2048;                                                                                                       \
+      chunks = cap / B;                                                                                                                 \
+      const long maxc = cdivl(N, trip);                                                                                                 \
+      if (chunks > maxc) chunks = maxc;                                                                                                 \
+      if (chunks < 1) chunks = 1;                                                                                                       \
+      rpc = (int)(cdivl(cdivl(N, chunks), trip) * trip);                                                                                \
+      chunks = cdivl(N, rpc);                                                                                                           \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL((modln_gproj_k<DT_, VE_, DG_, UNR_, GS_>), dim3((unsigned)chunks, B), dim3(256), 0, STREAM(ctx), X1, ch, sg, tg,  \
+                       alpha, beta, gamma, lnw, lnb, eps, N, C, ds, g, W, wsg, wsj, wsc, rpc, X3, mu, rstd, y, stats);                   \
+  } while (0)
+  if (bf) {
+    if (big) { if (g32) MG_(DT_BF16, 8, 16, 2, 32); else MG_(DT_BF16, 8, 16, 2, 16); }
+    else     { if (g32) MG_(DT_BF16, 8, 8, 4, 32);  else MG_(DT_BF16, 8, 8, 4, 16); }
+  } else {
+    if (big) { if (g32) MG_(DT_F32, 4, 16, 2, 32); else MG_(DT_F32, 4, 16, 2, 16); }
+    else     { if (g32) MG_(DT_F32, 4, 8, 4, 32);  else MG_(DT_F32, 4, 8, 4, 16); }
+  }
+#undef MG_
+}
+
 // ---- wide -----------------------------------------------------------------------------------------------------------
 // stats != null: the bn_stats accumulators of y AS STORED (rounded to E): stats[0..C) = y[0][c] (shift),
 // stats[C..2C) += sum (y - shift), stats[2C..3C) += sum (y - shift)^2.

@@ -338,6 +338,16 @@ void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g
         st(y, ctx.mode, r * ds + gi * dg + jl, (float)s);
       }
 }
+bool modln_gproj_supported(int mode, int C, int ds, int g) { return gproj_supported(mode, C, ds, g); }
+
+void modln_gproj(const Ctx& ctx, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta, float gamma,
+                 const float* lnw, const float* lnb, float eps, int B, int N, int C, int ds, int g, const float* W, long wsg, long wsj,
+                 long wsc, void* X3, float* mu, float* rstd, void* y, float* stats) {
+  modln_fwd(ctx, X1, ch, sg, tg, alpha, beta, gamma, lnw, lnb, eps, B, N, C, X3, mu, rstd);
+  gproj_narrow(ctx, X3, (long)B * N, C, ds, g, W, wsg, wsj, wsc, y);
+  if (stats) bn_stats(ctx, y, (long)B * N, ds, stats);
+}
+
 void gproj_wide(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,
                 void* y, float* stats) {
   const int cg = C / g, dg = ds / g;
