@@ -53,15 +53,16 @@ static ColGeom col_geom(int UNR, int C, int VE, long rows, int B, long target_wg
   return g;
 }
 static inline int col_ve(const Ctx& ctx, int C) {
-  const int vmax = ctx.mode == DT_BF16 ? 8 : 4;
-  return C % vmax == 0 ? vmax : 1;
+  if (ctx.mode == DT_BF16) return C % 8 == 0 ? 8 : (C % 4 == 0 ? 4 : 1);      // ds = 12 (C = 96): 8-byte vectors, not 2-byte scalars
+  return C % 4 == 0 ? 4 : 1;
 }
 // resident capacity (occupancy x CUs) of the instantiation COL_DISPATCH would launch; reductions use one full round
 #define COL_CAPACITY(OUT, ctx, VE_, KERNEL, SHMEM)                                                         \
   do {                                                                                                      \
     const void* fn_;                                                                                        \
     if ((ctx).mode == DT_BF16) fn_ = (VE_) == 8 ? reinterpret_cast<const void*>(&KERNEL<DT_BF16, 8>)         \
-                                                : reinterpret_cast<const void*>(&KERNEL<DT_BF16, 1>);        \
+                                   : ((VE_) == 4 ? reinterpret_cast<const void*>(&KERNEL<DT_BF16, 4>)        \
+                                                 : reinterpret_cast<const void*>(&KERNEL<DT_BF16, 1>));      \
     else fn_ = (VE_) == 4 ? reinterpret_cast<const void*>(&KERNEL<DT_F32, 4>)                                \
                           : reinterpret_cast<const void*>(&KERNEL<DT_F32, 1>);                               \
     OUT = wg_capacity(fn_, SHMEM);                                                                          \
@@ -71,6 +72,7 @@ static inline int col_ve(const Ctx& ctx, int C) {
   do {                                                                                                      \
     if ((ctx).mode == DT_BF16) {                                                                            \
       if ((VE_) == 8) hipLaunchKernelGGL((KERNEL<DT_BF16, 8>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
+      else if ((VE_) == 4) hipLaunchKernelGGL((KERNEL<DT_BF16, 4>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
       else hipLaunchKernelGGL((KERNEL<DT_BF16, 1>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__);      \
     } else {                                                                                                \
       if ((VE_) == 4) hipLaunchKernelGGL((KERNEL<DT_F32, 4>), GRID, dim3(256), SHMEM, STREAM(ctx), __VA_ARGS__); \
