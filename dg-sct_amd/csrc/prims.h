@@ -140,6 +140,7 @@ bool gproj_supported(int mode, int C, int ds, int g);
 void gproj_narrow(const Ctx&, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc, void* y);
 // modln_fwd + gproj_narrow + bn_stats(y) in one pass over X1 (lnw may be null; stats null = no sums)
 bool modln_gproj_supported(int mode, int C, int ds, int g);
+int rowfuse_mode(int set);        // test / tuning switch of the fused row passes (dgsct_test_tune "rowfuse")
 void modln_gproj(const Ctx&, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta, float gamma,
                  const float* lnw, const float* lnb, float eps, int B, int N, int C, int ds, int g, const float* W, long wsg, long wsj,
                  long wsc, void* X3, float* mu, float* rstd, void* y, float* stats);

@@ -7,6 +7,7 @@
 //   wide:   y[r][gi*cg + cl] = sum_jl x[r][gi*dg + jl] * W(gi, jl, cl)     [rows][ds] -> [rows][C]  (+ BatchNorm sums)
 // W(gi, jl, cl) = W[gi*sg + jl*sj + cl*sc] addresses the fp32 master weight in either role (forward: down/up sampler,
 // backward: the same tensors transposed), so no transposed copy exists.   Reference: net_trans.py:629-643.
+#include <atomic>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "prims.h"
@@ -337,10 +338,16 @@ __global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void modln_gproj_k(const 
   }
 }
 
+int rowfuse_mode(int set) {                              // -1: query; 0 / 1: off / on (DGSCT_NO_ROWFUSE=1 starts it off); returns the old value
+  static std::atomic<int> mode{(getenv("DGSCT_NO_ROWFUSE") && atoi(getenv("DGSCT_NO_ROWFUSE"))) ? 0 : 1};
+  const int old = mode.load(std::memory_order_relaxed);
+  if (set >= 0) mode.store(set ? 1 : 0, std::memory_order_relaxed);
+  return old;
+}
+
 bool modln_gproj_supported(int mode, int C, int ds, int g) {
-  static const int off = getenv("DGSCT_NO_ROWFUSE") ? atoi(getenv("DGSCT_NO_ROWFUSE")) : 0;
   ProjGeom pg;
-  return !off && proj_geom(mode, C, ds, g, 1 << 20, 1024, pg) && (pg.gs == 16 || pg.gs == 32);
+  return rowfuse_mode(-1) && proj_geom(mode, C, ds, g, 1 << 20, 1024, pg) && (pg.gs == 16 || pg.gs == 32);
 }
 
 void modln_gproj(const Ctx& ctx, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta, float gamma,

@@ -247,7 +247,9 @@ int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, cons
 /* Test / tuning hook: set an internal switch, returns its previous value (-1: unknown key).
  *   "gemm8": 0 = 8-wave deep-product GEMM kernel off, 1 = on for shapes that fill the chip (default), 2 = on for every
  *   eligible shape (lets the unit tests reach it with small matrices); value < 0 only queries.
- *   "skinny": 0 / 1 = the K-split kernel of the [BT, C] gate-MLP products off / on (default on). */
+ *   "skinny": 0 / 1 = the K-split kernel of the [BT, C] gate-MLP products off / on (default on).
+ *   "rowfuse": 0 / 1 = the fused row passes of stages 0-1 (modulation + ln_before + down-projection + BN1 sums in one
+ *   kernel) off / on (default on; off = the three separate launches). */
 int dgsct_test_tune(const char* key, int value);
 
 int dgsct_prof_enable(int on);

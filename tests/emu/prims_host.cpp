@@ -338,7 +338,9 @@ void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g
         st(y, ctx.mode, r * ds + gi * dg + jl, (float)s);
       }
 }
-bool modln_gproj_supported(int mode, int C, int ds, int g) { return gproj_supported(mode, C, ds, g); }
+static int g_rowfuse = 1;
+int rowfuse_mode(int set) { const int old = g_rowfuse; if (set >= 0) g_rowfuse = set ? 1 : 0; return old; }
+bool modln_gproj_supported(int mode, int C, int ds, int g) { return g_rowfuse && gproj_supported(mode, C, ds, g); }
 
 void modln_gproj(const Ctx& ctx, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta, float gamma,
                  const float* lnw, const float* lnb, float eps, int B, int N, int C, int ds, int g, const float* W, long wsg, long wsj,

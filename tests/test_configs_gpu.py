@@ -181,3 +181,49 @@ def test_avvp_per_gpu_batch(dtype):
 def test_full_batch_against_oracle(shape, dtype):
     r = run_case(*shape, BT=160, dtype=dtype)
     (check_fp32 if dtype == torch.float32 else check_bf16)(r)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,flavour", [((4096, 96, 2304, 128), "ave"), ((576, 256, 1024, 192), "ave"), ((1024, 192, 576, 256), "avs_s4")])
+def test_fused_row_pass_equals_the_three_launches(shape, flavour, dtype):
+    """modln_gproj (modulation + ln_before + down-projection + BN1 sums, one kernel at stages 0-1) against the separate
+    modln_fwd / gproj_narrow / bn_stats launches it replaces (dgsct_test_tune "rowfuse"): same rounding points, so the
+    stored tensors agree to the last bit or two of fp32 summation order, and everything downstream with them."""
+    N, C, No, Co = shape
+    BT = 10
+    kw = {**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour]}
+    cfg = O.AdapterConfig(**kw)
+    p = O.random_params(cfg, flavour, seed=3, scale=0.577)
+    if cfg.remap == "bicubic":
+        p["_bicubic"] = O.bicubic_matrix(No, N)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    gen = torch.Generator().manual_seed(11)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    dMap = torch.randn(BT, N, generator=gen).to(DEV)
+    res = []
+    old = lib.test_tune("rowfuse", -1)
+    try:
+        for mode in (1, 0):
+            lib.test_tune("rowfuse", mode)
+            params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)       # (BN running stats are updated in place)
+            prep = ops.prepare(lib, spec, params, dtype, DEV)
+            out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+            dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, None)
+            torch.cuda.synchronize()
+            bn = [params[PARAM_NAMES.index(n)].clone() for n in ("bn1.running_mean", "bn1.running_var")]
+            res.append((out.float(), amap, dX.float(), dY.float(), [g.clone() if g is not None else None for g in grads], bn))
+    finally:
+        lib.test_tune("rowfuse", old)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2      # bf16: a 1-ulp difference of a stored BN statistic can flip roundings downstream
+    a, b = res
+    for i, name in enumerate(("out", "map", "dX", "dY")):
+        assert _l2(a[i], b[i]) < tol, (name, _l2(a[i], b[i]))
+    for n, (ra, rb) in zip(("bn1.running_mean", "bn1.running_var"), zip(a[5], b[5])):
+        assert _l2(ra, rb) < 1e-5, (n, _l2(ra, rb))
+    for name, ga, gb in zip(PARAM_NAMES, a[4], b[4]):
+        if ga is None or ga.float().norm() == 0 or name in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias"):
+            continue        # (those three are cancellation residues: a bias in front of a normalisation / softmax, helpers.FP32_RESIDUES)
+        assert _l2(ga, gb) < (1e-4 if dtype == torch.float32 else 2e-2), (name, _l2(ga, gb))
