@@ -336,8 +336,12 @@ class VisualAdapter(nn.Module):
             res = residual.squeeze(-1).permute(0, 2, 1).to(cd).contiguous()
         out, amap, tmap = ops.adapter_apply(lib, self.spec, training, prep, X, Y, params, flat, residual=res, skip=skip)
         if training and self.use_bn:
-            self.bn1.num_batches_tracked += 1
-            self.bn2.num_batches_tracked += 1
+            pend = self.__dict__.get("_count_later")
+            if pend is not None:                         # AdapterStack: one _foreach_add_ per step instead of 96 one-element kernels
+                pend.append(self.bn1.num_batches_tracked); pend.append(self.bn2.num_batches_tracked)
+            else:
+                self.bn1.num_batches_tracked += 1
+                self.bn2.num_batches_tracked += 1
         if out.dtype != in_dtype:
             out = out.to(in_dtype)
         output = out.permute(0, 2, 1).unsqueeze(-1)

@@ -139,6 +139,24 @@ class AdapterStack(nn.Module):
                 return a[0], v[0], a[1], v[1]
             return (r_a + a[0].squeeze(-1).permute(0, 2, 1), r_v + v[0].squeeze(-1).permute(0, 2, 1), a[1], v[1])
 
+        # BatchNorm's num_batches_tracked (2 per adapter call): collected and bumped by ONE _foreach_add_ after the loop -- as 96
+        # one-element kernels they sat on the adapter streams' dependency chains (~9 us per forward call)
+        counters: List[torch.Tensor] = []
+        mods = [m for ml in (self.audio_adapter_blocks_p1, self.vis_adapter_blocks_p1, self.audio_adapter_blocks_p2,
+                             self.vis_adapter_blocks_p2) for m in ml]
+        for m in mods:
+            m.__dict__["_count_later"] = counters
+        try:
+            outs, maps = self._layers(feats, step, outs, maps)
+        finally:
+            for m in mods:
+                m.__dict__.pop("_count_later", None)
+        if counters:
+            torch._foreach_add_(counters, 1)
+        return outs, maps
+
+    def _layers(self, feats, step, outs, maps):
+        idx = 0
         for s, (f_v, f_a) in zip(self.stages, feats):
             for _ in range(s["layers"]):
                 f_a, f_v, _, _ = step(self.audio_adapter_blocks_p1[idx], self.vis_adapter_blocks_p1[idx], f_a, f_v, idx, 0, True)
