@@ -456,6 +456,13 @@ def main():
                                                round(sum(b.elapsed_time(c) for _, b, c in phase_ev[-args.steps:]) / args.steps, 2)]}
                            if args.phases and len(phase_ev) >= args.steps else {})),
             roofline=roofline, cpu_baseline=cpu)
+        # RCCL writes its version banner through C stdio: on a pipe it would be flushed at exit, i.e. AFTER this line; drain it
+        # first so that the JSON line is the last thing rank 0 prints
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if dp:
         import torch.distributed as dist
