@@ -63,3 +63,25 @@ def test_rccl_single_rank_allreduce_keeps_the_gradients(overlap):
             assert n == len(fx["grads"])
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_contract_last_stdout_line_is_the_json_line():
+    """The driver reads ONE JSON line from rank 0.  RCCL prints a version banner through C stdio, which on a pipe used to come
+    out at exit, after the line; bench.py drains it first.  Runs the data-parallel path at one rank (--force-dp)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-roofline", "--force-dp", "--batch", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
