@@ -365,3 +365,199 @@ def test_cpu_tensors_raise():
                       linear_in=16, linear_out=32)
     with pytest.raises(RuntimeError):
         m(torch.randn(10, 32, 16, 1), torch.randn(10, 16, 36, 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Restored in round 4 (deleted without replacement by commit 3451bcf; VERDICT r3 weak #1 / ADVICE r3 medium), on the
+# no-floor fp32 metric (helpers.fp32_err / grad_close_fp32(name=)) and with the device's ReLU masks pinned where an oracle
+# backward is compared.
+
+# (N, C, No, Co) of AVE stages 0 / 1, visual and audio direction, Swin-V2-B widths (BASELINE config 2): the benchmark's
+# dominant shapes (remap GEMMs with K = 4096 / 2304, the C = 128 / 256 kernel instantiations)
+STAGE01 = [(2304, 128, 4096, 96), (4096, 96, 2304, 128), (576, 256, 1024, 192), (1024, 192, 576, 256)]
+
+
+@pytest.mark.parametrize("shape", STAGE01)
+def test_real_shapes_stage01_fp32(shape):
+    """the large-token stages against the oracle, one clip: out, map, dX, dY and every parameter gradient"""
+    r = _real_case(*shape, BT=10, dtype=torch.float32)
+    bad = [(k, fp32_err(*r[k])) for k in ("out", "map", "dX", "dY") if not fp32_err(*r[k]) < TOL_F32]
+    bad += [(k, fp32_err(g, go)) for k, (g, go) in r["grads"].items() if not grad_close_fp32(g, go, TOL_F32, name=k)]
+    assert not bad, bad
+    assert not r["extra"], r["extra"]
+
+
+@pytest.mark.parametrize("shape", STAGE01)
+def test_real_shapes_stage01_bf16_outputs(shape):
+    """bf16 production kernels at the benchmark's stage-0/1 shapes: out and map against the fp32 oracle on the same
+    (bf16-representable) inputs, BASELINE's 1e-2 in relative L2 and 2e-2 of max|ref| in the worst element"""
+    r = _real_case(*shape, BT=10, dtype=torch.bfloat16, seed=3)
+    for k in ("out", "map"):
+        assert _l2(*r[k]) < TOL_BF16, (k, _l2(*r[k]))
+        assert nrm_err(*r[k]) < 2 * TOL_BF16, (k, nrm_err(*r[k]))
+
+
+@pytest.mark.parametrize("shape", [STAGE01[0], STAGE01[1]])
+def test_full_size_frames_are_independent(shape):
+    """BASELINE size (B=16 x T=10 = 160 frames, stage 0): with BatchNorm in eval mode no operation couples frames, so
+    the first clip of the 160-frame call must equal a 10-frame call on the same data (size-independent property;
+    exercises the full grids, the large-offset addressing and the XCD tile remap at the benchmark's shapes)."""
+    N, C, No, Co = shape
+    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
+    p = O.random_params(cfg, "ave", seed=5, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        params = param_table(p, spec, DEV)
+        gen = torch.Generator().manual_seed(7)
+        X = torch.randn(160, N, C, generator=gen).to(DEV, dtype)
+        Y = torch.randn(160, No, Co, generator=gen).to(DEV, dtype)
+        prep = ops.prepare(lib, spec, params, dtype, DEV)
+        big = ops.raw_forward(lib, spec, params, prep, X, Y, False)
+        small = ops.raw_forward(lib, spec, params, prep, X[:10].contiguous(), Y[:10].contiguous(), False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(big[0].float()).all()
+        assert nrm_err(big[0][:10], small[0].float().cpu()) < tol
+        assert nrm_err(big[1][:10], small[1].float().cpu()) < tol
+        assert nrm_err(big[0][150:], ops.raw_forward(lib, spec, params, prep, X[150:].contiguous(), Y[150:].contiguous(),
+                                                     False)[0].float().cpu()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL_F32), (torch.bfloat16, 2e-2)])
+def test_fused_residual_and_skip(dtype, tol):
+    """SURVEY 8f row f2 on the GPU (net_trans.py:894-906): dgsct_adapter_forward_ex(residual) / backward_ex(skip_into_dx)
+    against the plain entry points + the caller's own adds."""
+    fx = load_golden("ave_orderB")
+    lib = default_lib()
+    base = run_library(lib, fx, DEV, dtype, training=True)
+    Rz = torch.randn(fx["X"].shape, generator=torch.Generator().manual_seed(5))
+    r = run_library(lib, fx, DEV, dtype, training=True, residual=Rz)
+    assert nrm_err(r["out"], base["out"].float().cpu() + Rz.to(dtype).float()) < tol
+    assert nrm_err(r["dX"], base["dX"].float().cpu()) < 1e-5 + (0 if dtype == torch.float32 else 1e-2)
+    r = run_library(lib, fx, DEV, dtype, training=True, skip=True)
+    X = fx["X"].to(dtype).float(); dO = fx["dOut"].to(dtype).float()
+    assert nrm_err(r["out"], base["out"].float().cpu() + X) < tol
+    assert nrm_err(r["dX"], base["dX"].float().cpu() + dO) < tol
+    assert nrm_err(r["dY"], base["dY"].float().cpu()) < 1e-5 + (0 if dtype == torch.float32 else 1e-2)
+    if dtype == torch.float32:      # and against the reference-generated vectors themselves
+        assert fp32_err(r["out"], fx["out"] + fx["X"]) < TOL_F32
+        assert fp32_err(r["dX"], fx["dX"] + fx["dOut"]) < TOL_F32
+        assert fp32_err(r["dY"], fx["dY"]) < TOL_F32
+
+
+@pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "avs_s4", "pretrain"])
+def test_results_do_not_depend_on_buffer_contents(name, monkeypatch):
+    """every output / scratch / saved-activation / gradient buffer is filled with NaN bit patterns before the call
+    (ops._POISON): a kernel that reads memory the call has not written yet would turn the results into NaN"""
+    monkeypatch.setattr(ops, "_POISON", True)
+    fx = load_golden(name)
+    r = run_library(default_lib(), fx, DEV, torch.float32, training=True)
+    bad = [(k, fp32_err(r[k], fx[k])) for k in ("out", "map", "dX", "dY") if not fp32_err(r[k], fx[k]) < TOL_F32]
+    bad += [(k, fp32_err(r["grads"][k], g)) for k, g in fx["grads"].items() if not grad_close_fp32(r["grads"][k], g, TOL_F32, name=k)]
+    assert not bad, bad
+    rb = run_library(default_lib(), fx, DEV, torch.bfloat16, training=True, skip=True)
+    assert all(torch.isfinite(rb[k].float()).all() for k in ("out", "map", "dX", "dY"))
+    assert all(torch.isfinite(g).all() for g in rb["grads"].values())
+
+
+@pytest.mark.parametrize("shape", [(2304, 128, 4096, 96), (4096, 96, 2304, 128), (576, 256, 1024, 192), (144, 512, 256, 384),
+                                   (36, 1024, 64, 768)])
+def test_poisoned_buffers_at_production_shapes_bf16(shape, monkeypatch):
+    """the same NaN-poison check through the kernels only the production shapes reach (gemm8 split-K atomics, the skinny
+    K-split products, rowdot_colsum's partial scratch, modln_gproj's BN sums): bf16, 20 frames, everything finite and the
+    outputs within BASELINE's bf16 bound of the oracle"""
+    monkeypatch.setattr(ops, "_POISON", True)
+    r = _real_case(*shape, BT=20, dtype=torch.bfloat16, seed=9)
+    for k in ("out", "map", "dX", "dY"):
+        assert torch.isfinite(r[k][0].float()).all(), k
+    for k, (g, _) in r["grads"].items():
+        assert torch.isfinite(g).all(), k
+    for k in ("out", "map"):
+        assert _l2(*r[k]) < TOL_BF16, (k, _l2(*r[k]))
+
+
+@pytest.mark.parametrize("flat", [False, True], ids=["unflat", "flat"])
+def test_stack_on_gpu_matches_reference_fixture(flat):
+    """SURVEY row a-10 on the device (net_trans.py:880-916): 12 adapters through AdapterStack with everything the benchmark
+    uses switched on (two adapter streams, aux streams in forward and backward, fused residual/skip, flat parameters)
+    against the reference-generated stack fixture: outputs, maps, input gradients and every parameter gradient; repeated
+    to give stream-ordering bugs a chance to show."""
+    from dgsct_amd import AdapterStack
+    from dgsct_amd.stack import default_opt
+    fx = load_golden("stack_2stage")
+    st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4), concurrent=True)
+    st.load_state_dict(fx["state0"])
+    st = st.to(DEV)
+    if flat:
+        st.flatten_parameters()
+    st.train()
+    for rep in range(3):
+        if rep:                                              # BN running stats moved in the previous repetition
+            st.load_state_dict(fx["state0"])
+        for p in st.parameters():
+            p.grad = None
+        feats = [(a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for a, b in fx["feats"]]
+        outs, maps = st(feats)
+        bad = []
+        for i, ((fv, fa), (rv, ra)) in enumerate(zip(outs, fx["outs"])):
+            bad += [(f"out{i}{m}", fp32_err(a, b)) for m, a, b in (("v", fv, rv), ("a", fa, ra)) if not fp32_err(a, b) < TOL_F32]
+        bad += [(f"map{i}", fp32_err(maps[i], fx["maps"][i])) for i in (0, 1) if not fp32_err(maps[i], fx["maps"][i]) < TOL_F32]
+        torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
+                                [g.to(DEV) for pr in fx["cots"] for g in pr] + [fx["mcots"][0].to(DEV), fx["mcots"][1].to(DEV)])
+        torch.cuda.synchronize()
+        for i, ((fv, fa), (gv, ga)) in enumerate(zip(feats, fx["dfeats"])):
+            bad += [(f"dfeat{i}{m}", fp32_err(a.grad, b)) for m, a, b in (("v", fv, gv), ("a", fa, ga)) if not fp32_err(a.grad, b) < TOL_F32]
+        if flat:
+            n = 0
+            for name, m in st.named_modules():
+                if hasattr(m, "flat_param"):
+                    for pn, (off, cnt, shape) in m._flat_layout.items():
+                        ref = fx["grads"].get(name + "." + pn)
+                        if ref is not None:
+                            if not grad_close_fp32(m.flat_param.grad[off:off + cnt].view(shape), ref, TOL_F32, name=pn):
+                                bad.append((name + "." + pn, fp32_err(m.flat_param.grad[off:off + cnt].view(shape), ref)))
+                            n += 1
+            assert n == len(fx["grads"])
+        else:
+            got = {k: p.grad for k, p in st.named_parameters() if p.grad is not None}
+            assert set(got) == set(fx["grads"])
+            for k, g in fx["grads"].items():
+                if not grad_close_fp32(got[k], g, TOL_F32, name=k.split(".", 2)[-1]):
+                    bad.append((k, fp32_err(got[k], g)))
+        assert not bad, (rep, bad)
+
+
+def test_module_dropin_matches_oracle():
+    """nn.Module boundary on the GPU: reference call convention ([BT,C,N,1] views), state_dict names, autograd -- against the
+    oracle (forward values, input gradients, every parameter gradient, BN buffers)."""
+    from types import SimpleNamespace
+    from dgsct_amd import VisualAdapter
+    opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=8)
+    torch.manual_seed(0)
+    m = VisualAdapter(64, 64, "bottleneck", reduction_factor=8, opt=opt, use_bn=True, use_gate=True, num_tk=8,
+                      conv_dim_in=49, conv_dim_out=25, linear_in=48, linear_out=64).to(DEV)
+    with torch.no_grad():
+        m.gate.fill_(0.7); m.gate_av.fill_(0.3)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    cfg = O.AdapterConfig(N=25, C=64, No=49, Co=48, tk=8, r=8, g=2)
+    BT = 10
+    f = torch.randn(BT, 25, 64, device=DEV, requires_grad=True)
+    fo = torch.randn(BT, 49, 48, device=DEV, requires_grad=True)
+    out, amap = m(f.permute(0, 2, 1).unsqueeze(-1), fo.permute(0, 2, 1).unsqueeze(-1))
+    assert out.shape == (BT, 64, 25, 1) and amap.shape == (BT, 1, 25)
+    g_out = torch.randn_like(out); g_map = torch.randn_like(amap)
+    (out * g_out).sum().add((amap * g_map).sum()).backward()
+    po = {k: v.clone() for k, v in sd.items()}
+    out_o, map_o, _, s = O.forward(po, f.detach().cpu(), fo.detach().cpu(), cfg, training=True)
+    dX_o, dY_o, g_o = O.backward(po, s, cfg, g_out.squeeze(-1).permute(0, 2, 1).cpu(), g_map.squeeze(1).cpu(), None)
+    assert fp32_err(out.squeeze(-1).permute(0, 2, 1), out_o) < TOL_F32
+    assert fp32_err(amap.squeeze(1), map_o) < TOL_F32
+    assert fp32_err(f.grad, dX_o) < TOL_F32 and fp32_err(fo.grad, dY_o) < TOL_F32
+    for k, p in m.named_parameters():
+        if k in g_o:
+            assert grad_close_fp32(p.grad, g_o[k].reshape(p.shape), TOL_F32, name=k), (k, fp32_err(p.grad, g_o[k].reshape(p.shape)))
+        else:
+            assert p.grad is None or k in ("gate_tk",), k
+    assert int(m.bn1.num_batches_tracked) == 1
+    assert fp32_err(m.bn2.running_mean, po["bn2.running_mean"]) < TOL_F32
+    assert fp32_err(m.bn2.running_var, po["bn2.running_var"]) < TOL_F32
