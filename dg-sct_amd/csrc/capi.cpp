@@ -249,6 +249,7 @@ int dgsct_test_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm8")) return gemm8_mode(value);
   if (key && !strcmp(key, "skinny")) return gemm_skinny_mode(value);
   if (key && !strcmp(key, "rowfuse")) return rowfuse_mode(value);
+  if (key && !strcmp(key, "gatefuse")) return gatefuse_mode(value);
   return -1;
 }
 

@@ -397,7 +397,22 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     gemm(ctx, g5);
   }
   // F7 ---- spatial gate and the returned map                            :601-608
-  {
+  // F8 ---- modulation + ln_before                                       :611-627
+  // Early stages (C <= 256, bf16): F7 + F8 + the down-projection of F9 + the BN1 sums are ONE pass over X1 (fused_gate.hip).
+  const bool gfuse = gate_fused_supported(ctx.mode, N, C, ds, g) && !fp8;
+  const bool fuse89 = !gfuse && modln_gproj_supported(ctx.mode, C, ds, g);
+  if (d.temporal) {                                              // tg depends on a only
+    temporal_fwd(ctx, b.S<float>(s.a), b.F(DGSCT_P_WT), b.F(DGSCT_P_BT), B, C, b.S<float>(s.tg));
+    if (tmap) ew(ctx, EW_COPY, tmap, DT_F32, F32(b.S(s.tg)), NOARG, NOARG, B, 0.f, 1);
+  }
+  if (gfuse) {
+    scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);        // Xc = X1 * (1 + ch): backward's dWv2 operand
+    gatemod_fwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S(s.aq2), b.F(DGSCT_P_WV2), b.F(DGSCT_P_BV2), b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
+                d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta, d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr,
+                d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C, ds, g, b.F(DGSCT_P_WD), b.S<float>(s.sl), b.S(s.X3),
+                b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S(s.Zp), d.use_bn && d.training ? b.S<float>(s.bnacc1) : nullptr, b.S(s.vq2));
+    spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map), map);   // saved copy + the returned map
+  } else {
     scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);        // Xc = X1 * (1 + ch)
     Gemm g1 = mk((int)R, dd, C);                                 // vq2 = relu(Xc Wv2^T + b)
     g1.A = km(b.S(s.Xc), C); g1.B = km(b.W(DGSCT_P_WV2), C); g1.bias_n = b.F(DGSCT_P_BV2); g1.act = ACT_RELU;
@@ -407,23 +422,17 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     rowdot_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.S(s.aq2), E, dd, b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
                    b.S<float>(s.sl));
     spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map), map);   // saved copy + the returned map
-    if (d.temporal) {
-      temporal_fwd(ctx, b.S<float>(s.a), b.F(DGSCT_P_WT), b.F(DGSCT_P_BT), B, C, b.S<float>(s.tg));
-      if (tmap) ew(ctx, EW_COPY, tmap, DT_F32, F32(b.S(s.tg)), NOARG, NOARG, B, 0.f, 1);
-    }
+    // (stages 0-1 without the gate fusion: modulation + ln_before + down-projection + BN1 sums in one pass, see modln_gproj)
+    if (fuse89)
+      modln_gproj(ctx, b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta, d.gamma,
+                  d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C, ds, g,
+                  b.F(DGSCT_P_WD), (long)(ds / g) * (C / g), C / g, 1, b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S(s.Zp),
+                  d.use_bn && d.training ? b.S<float>(s.bnacc1) : nullptr);
+    else
+      modln_fwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta,
+                d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C,
+                b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b));
   }
-  // F8 ---- modulation + ln_before                                       :611-627
-  // (stages 0-1: one pass with the down-projection and the BN1 sums, see modln_gproj)
-  const bool fuse89 = modln_gproj_supported(ctx.mode, C, ds, g);
-  if (fuse89)
-    modln_gproj(ctx, b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta, d.gamma,
-                d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C, ds, g,
-                b.F(DGSCT_P_WD), (long)(ds / g) * (C / g), C / g, 1, b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S(s.Zp),
-                d.use_bn && d.training ? b.S<float>(s.bnacc1) : nullptr);
-  else
-  modln_fwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta,
-            d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C,
-            b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b));
   // F9-F10 ---- grouped bottleneck + BatchNorm                           :629-643
   float* bn1 = b.S<float>(s.bn1);
   float* bn2 = b.S<float>(s.bn2);
@@ -432,7 +441,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     // dimensions -> vector-unit row kernels (prims_proj.hip) instead of 80 %-padded MFMA tiles
     const bool vproj = gproj_supported(ctx.mode, C, ds, g);
     const long cgl = C / g, dgl = ds / g;
-    if (fuse89) {
+    if (fuse89 || gfuse) {
     } else if (vproj) {
       gproj_narrow(ctx, b.S(s.X3), R, C, ds, g, b.F(DGSCT_P_WD), dgl * cgl, cgl, 1, b.S(s.Zp));     // Zp = X3 (x)_g Wd
     } else {
@@ -443,7 +452,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       gemm(ctx, g1);
     }
     if (d.use_bn) {
-      if (d.training && !fuse89) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
+      if (d.training && !fuse89 && !gfuse) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
       bn_finalize(ctx, b.S<float>(s.bnacc1), R, ds, b.F(DGSCT_P_BN1_W), b.F(DGSCT_P_BN1_B), b.Fm(DGSCT_P_BN1_RM),
                   b.Fm(DGSCT_P_BN1_RV), d.bn_momentum, d.eps, d.training, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds);
     }

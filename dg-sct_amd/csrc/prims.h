@@ -147,6 +147,19 @@ void modln_gproj(const Ctx&, const void* X1, const float* ch, const float* sg, c
 void gproj_wide(const Ctx&, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc, void* y,
                 float* stats);
 
+// ---- fused row passes of the gate / bottleneck chain (fused_gate.hip; bf16, C in {96, 128, 192, 256}, N % 32 == 0) --------------
+// One pass over X1 (E [B][N][C]) instead of scale_cols -> GEMM -> rowdot -> modln_fwd -> gproj_narrow -> bn_stats:
+//   sl[b][n] = relu(X1 (1 + ch_b) Wv2^T + bv2) . (aq2_b * ws) + bs;   X2 = X1 (alpha ch_b + beta sigmoid(sl) + gamma tg_b + 1 - alpha);
+//   X3 = lnw ? LN(X2) : X2 (+ mu, rstd);   Zp = X3 (x)_g Wd;   stats (3*ds floats, pre-zeroed, may be null): bn_stats(Zp as stored)
+// Wv2 [C/2][C], Wd [ds][C/g]: the fp32 MASTER weights.  aq2: E [B][C/2].  vq2 (optional, E [B][N][C/2]): relu(...) for callers that
+// still want it materialised.
+bool gate_fused_supported(int mode, int N, int C, int ds, int g);
+int gatefuse_mode(int set);       // test / tuning switch (dgsct_test_tune "gatefuse"); set < 0: query
+void gatemod_fwd(const Ctx&, const void* X1, const float* ch, const void* aq2, const float* Wv2, const float* bv2, const float* ws,
+                 const float* bs, const float* tg, float alpha, float beta, float gamma, const float* lnw, const float* lnb, float eps,
+                 int B, int N, int C, int ds, int g, const float* Wd, float* sl, void* X3, float* mu, float* rstd, void* Zp,
+                 float* stats, void* vq2);
+
 // acc = [shift | sum(x-shift) | sum((x-shift)^2)] per column, 3*C floats, pre-zeroed.  x is E [rows][C].
 void bn_stats(const Ctx&, const void* x, long rows, int C, float* acc);
 // training: mean/var from acc, running stats updated (momentum, unbiased var); eval: mean/var = running.

@@ -350,6 +350,54 @@ void modln_gproj(const Ctx& ctx, const void* X1, const float* ch, const float* s
   if (stats) bn_stats(ctx, y, (long)B * N, ds, stats);
 }
 
+// ---- fused gate / bottleneck passes (csrc/fused_gate.hip): host loops with the same rounding points (stored tensors rounded to E)
+static int g_gatefuse = 1;
+int gatefuse_mode(int set) { const int old = g_gatefuse; if (set >= 0) g_gatefuse = set ? 1 : 0; return old; }
+bool gate_fused_supported(int, int, int, int ds, int g) { return g_gatefuse && ds % g == 0; }      // the emulation takes every shape
+void gatemod_fwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq2, const float* Wv2, const float* bv2, const float* ws,
+                 const float* bs, const float* tg, float alpha, float beta, float gamma, const float* lnw, const float* lnb, float eps,
+                 int B, int N, int C, int ds, int g, const float* Wd, float* sl, void* X3, float* mu, float* rstd, void* Zp,
+                 float* stats, void* vq2) {
+  const int dd = C / 2, cg = C / g, dg = ds / g;
+  std::vector<double> x2(C);
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      const long row = (long)b * N + n;
+      double s = 0;
+      for (int j = 0; j < dd; ++j) {
+        double a = bv2[j];
+        for (int c = 0; c < C; ++c) a += (double)ld(X1, ctx.mode, row * C + c) * (1.0 + ch[(long)b * C + c]) * Wv2[(long)j * C + c];
+        const double v = a > 0 ? a : 0;
+        if (vq2) st(vq2, ctx.mode, row * dd + j, (float)v);
+        s += v * ld(aq2, ctx.mode, (long)b * dd + j) * ws[j];
+      }
+      s += *bs;
+      sl[row] = (float)s;
+      const double sgv = 1.0 / (1.0 + std::exp(-s));
+      double m1 = 0;
+      for (int c = 0; c < C; ++c) {
+        x2[c] = (double)ld(X1, ctx.mode, row * C + c) * (alpha * ch[(long)b * C + c] + beta * sgv + (tg ? gamma * tg[b] : 0.0) + 1.0 - alpha);
+        m1 += x2[c];
+      }
+      if (lnw) {
+        m1 /= C;
+        double v = 0;
+        for (int c = 0; c < C; ++c) v += (x2[c] - m1) * (x2[c] - m1);
+        const double rs = 1.0 / std::sqrt(v / C + eps);
+        mu[row] = (float)m1; rstd[row] = (float)rs;
+        for (int c = 0; c < C; ++c) x2[c] = (x2[c] - m1) * rs * lnw[c] + lnb[c];
+      }
+      for (int c = 0; c < C; ++c) st(X3, ctx.mode, row * C + c, (float)x2[c]);
+      for (int jz = 0; jz < ds; ++jz) {
+        const int gi = jz / dg;
+        double a = 0;
+        for (int cl = 0; cl < cg; ++cl) a += (double)ld(X3, ctx.mode, row * C + gi * cg + cl) * Wd[(long)jz * cg + cl];
+        st(Zp, ctx.mode, row * ds + jz, (float)a);
+      }
+    }
+  if (stats) bn_stats(ctx, Zp, (long)B * N, ds, stats);
+}
+
 void gproj_wide(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,
                 void* y, float* stats) {
   const int cg = C / g, dg = ds / g;

@@ -43,6 +43,23 @@ def test_schedule_matches_reference_fp32(emu, name):
             assert rel_err(r["params"][P_INDEX[k]], v) < tol, k
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_schedule_without_the_gate_fusion_fp32(emu, name):
+    """the emulation takes the fused gate / bottleneck passes (fused_gate.hip's schedule branch) for every shape by default;
+    with dgsct_test_tune("gatefuse", 0) the same goldens go through the unfused launches the device uses for C > 256 and fp32"""
+    fx = load_golden(name)
+    old = emu.test_tune("gatefuse", 0)
+    try:
+        r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
+    finally:
+        emu.test_tune("gatefuse", old)
+    tol = 1e-4
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(r[k], fx[k]) < tol, k
+    for k, g in fx["grads"].items():
+        assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
+
+
 @pytest.mark.parametrize("name", ["ave_orderA", "avs_s4", "avqa"])
 def test_schedule_eval_mode(emu, name):
     fx = load_golden(name)
