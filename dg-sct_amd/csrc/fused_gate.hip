@@ -52,7 +52,8 @@ __device__ __forceinline__ bfx8 fg_pack8(const float (&x)[8]) {
   return __builtin_bit_cast(bfx8, u);
 }
 
-typedef unsigned fg_u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: arrays of it are copied with memcpy and stay in scratch)
+typedef unsigned fg_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned fg_u32x2 __attribute__((ext_vector_type(2)));   // (HIP's uint4 is a struct: arrays of it are copied with memcpy and stay in scratch)
 template <int NV>
 __device__ __forceinline__ void fg_gload(fg_u32x4 (&nx)[NV], const unsigned short* base, int lane) {
   const fg_u32x4* src = reinterpret_cast<const fg_u32x4*>(base);
@@ -306,13 +307,489 @@ __global__ __launch_bounds__(256) void gatemod_fwd_k(const GF p) {
   }
 }
 
+
+// =====================================================================================================================
+// Backward of the same chain (net_trans.py:598-638 through autograd), C in {96, 128}: ONE pass over X1 instead of
+//   bn_bwd_apply -> gproj_wide (dX3) -> modln_bwd -> spatial_bwd -> colsum (u) -> relu_bwd_scale (dvq2) -> GEMM (dXc) -> xc_bwd.
+// Here the products are issued the OTHER way round -- token rows are the M operand, so an accumulator tile is [token][channel]
+// with the CHANNEL in the lane: the many per-channel sums over tokens of a backward pass (d ln_before.weight / bias, dch, d bv2,
+// u = sum_n dsl * vq2) are in-lane sums over the 16 accumulator registers, and the three per-token sums over channels (the
+// LayerNorm backward pair and dsg) are one cross-lane reduction of 16 values each.  vq2 is RECOMPUTED from X1 (same
+// per-frame-scaled weight image as the forward: same bits, same ReLU decisions) instead of being stored by the forward; Xc, which
+// only the dWv2 GEMM on the aux stream still wants materialised, is written from here.
+//   dZp  = BN1 backward of dZ (in place)                                  -> consumed by the dWd GEMM
+//   dX3  = dZp (x)_g Wd;  LN / modulation backward -> dX1a, dsg, d lnw, d lnb, dch (first part), dtg
+//   dsl  = dsg sg (1 - sg) + map (dMap - sum_n map dMap) (1 - tanh(sl)^2)                      (spatial_bwd)
+//   dvq2 = dsl * (aq2_b * ws) * (vq2 > 0);  u += dsl * vq2;  d bv2 += dvq2                     -> dvq2 stored for the dWv2 GEMM
+//   dX1  = dX1a + dvq2 W2_b   (= dXc (1 + ch_b));   dch += dXc * X1
+// 8 wavefronts per workgroup (one frame per workgroup, like the forward), wave-private LDS images, no __syncthreads in the loop.
+template <int C_>
+struct BG {
+  static constexpr int C = C_, DD = C / 2, DDP = (DD + 31) / 32 * 32, DS = C / 8, KS = C / 16, JT = DDP / 32, NT = C / 32;
+  static constexpr int PW = C * 2 + 16, PV = DDP * 2 + 16, PZ = 16 * 2 + 16;     // pitches: [.][C], [.][DDP], [.][16] bf16 images
+  static constexpr int NV = C / 16, CPR = C / 8;
+  static constexpr int NZ = (8 * DS + 63) / 64;          // 8-byte chunks (4 channels of one token) of a 32 x DS block per lane
+  static constexpr int WAVES = 4;
+  static constexpr int NTHR = WAVES * 64;
+  static constexpr int W2_BYTES = DDP * PW, WDT_BYTES = C * PZ;
+  static constexpr int XIMG = 32 * PW, DVIMG = 32 * PV, DZIMG = 32 * PZ, TOKV = 10 * 32 * 4;
+  static constexpr int WAVE_BYTES = XIMG + DVIMG + DZIMG + TOKV;
+  static constexpr int VEC_FLOATS = 2 * DDP + 3 * C + 5 * 16;     // bv2 | aq2*ws | modulation | ln weight | 1 + ch | BN1: a, sh, k1(=a), k2, k3
+  static constexpr int NQ = 4 * C + 2 * DDP;              // per-channel sums of a wave: dlnw | dlnb | dchA | dchB | u | dbv2
+  static constexpr int NK = (NQ + 255) / 256;             // reduction slots per thread
+  static constexpr int SMEM = W2_BYTES + WDT_BYTES + WAVES * WAVE_BYTES + VEC_FLOATS * 4 + 64;
+  static_assert(DS <= 16 && DS % 4 == 0, "bottleneck width");
+  static_assert(WAVES * WAVE_BYTES >= WAVES * NQ * 4, "the wave images double as the reduction scratch");
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
+};
+
+struct GB {
+  const unsigned short* X1; const float* ch; const unsigned short* aq2; const float* Wv2; const float* bv2; const float* ws;
+  const float* tg; float alpha, beta, gamma; const float* lnw; const float* mu; const float* rstd;
+  const float* sl; const float* sg; const float* map; const float* dMap; const float* mapdot;
+  int B, N, g, wpf; const float* Wd;
+  unsigned short* dZ; const unsigned short* Zp; const float* bn_mean; const float* bn_rstd; const float* bn_sc; const float* bn_sh;
+  const float* bn_sums; int has_bn, training; float inv_rows;
+  unsigned short* dX1; unsigned short* dvq2; unsigned short* Xc;
+  float* dch; float* u; float* dtg; float* part;      // part: [workgroup][2 C + DD + 1] = d lnw | d lnb | d bv2 | d bs
+};
+
+__device__ __forceinline__ unsigned short fg_ldsu16(const char* p) { return *reinterpret_cast<const unsigned short*>(p); }
+
+// HAS_LN (ln_before present) is a compile-time flag: as a run-time condition inside the unrolled element loops it compiled to a
+// branch per element, each behind its own ds_read + s_waitcnt lgkmcnt(0) -- 48 serialised LDS round trips per pass
+template <int C, bool HAS_LN>
+__global__ __launch_bounds__(256) void gatemod_bwd_k(const GB p) {
+  using G = BG<C>;
+  __shared__ __attribute__((aligned(16))) char smem[G::SMEM];
+  char* w2img = smem;
+  char* wdT = w2img + G::W2_BYTES;
+  char* wave0 = wdT + G::WDT_BYTES;
+  float* bv2s = reinterpret_cast<float*>(wave0 + G::WAVES * G::WAVE_BYTES);
+  float* w2s = bv2s + G::DDP;
+  float* mcs = w2s + G::DDP;
+  float* lnws = mcs + C;
+  float* opcs = lnws + C;
+  float* bnv = opcs + C;                                  // [5][16]
+  float* misc = bnv + 80;
+  const int tid = threadIdx.x, lane_ = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = lane_, h = lane_ >> 5, tl = lane_ & 31;
+  // (measured: with has_ln a compile-time constant the straight-line block body needs > 512 registers and spills: 335 / 543 us
+  //  against 237 / 257 us with the per-element branches of the run-time flag, which keep the scheduling regions small)
+  const bool has_ln = p.lnw != nullptr;
+  // Work items = (frame, part of the frame); a workgroup walks items blockIdx.x, + gridDim.x, ...: the grid is ONE workgroup per CU
+  // (LDS) and the host picks the parts per frame so that the items fill whole rounds of it (160 frames x 8 parts = 5 x 256).
+  const int nitems = p.B * p.wpf;
+  float keep[G::NK];
+#pragma unroll
+  for (int k = 0; k < G::NK; ++k) keep[k] = 0.f;
+  //                              // this thread's slots of [d lnw | d lnb | d bv2], summed over its items
+  float keep_bs = 0.f;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const int b = item / p.wpf, part = item - b * p.wpf;
+  const float* chb = p.ch + (long)b * C;
+  __syncthreads();                                         // the previous item's reduction has read the images / vectors
+
+  // ---- per-frame operand images and vectors
+  for (int i = tid; i < G::DDP * G::CPR; i += G::NTHR) {
+    const int j = i / G::CPR, c = (i - j * G::CPR) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (j < G::DD) {
+      float w[8], s[8];
+      ldf<8>(p.Wv2, (long)j * C + c, w);
+      ldf<8>(chb, c, s);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] *= 1.f + s[e];
+      v = make_uint4(f2bf2(w[0], w[1]), f2bf2(w[2], w[3]), f2bf2(w[4], w[5]), f2bf2(w[6], w[7]));
+    }
+    *reinterpret_cast<uint4*>(w2img + j * G::PW + c * 2) = v;
+  }
+  {
+    const int cg = C / p.g, dg = G::DS / p.g;
+    for (int i = tid; i < C * 2; i += G::NTHR) {               // WdT[c][jz] (block diagonal), 16 k-columns = 2 chunks per row
+      const int c = i >> 1, j0 = (i & 1) * 8;
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int jz = j0 + e;
+        const int jc = jz < G::DS ? jz : 0;
+        const int gi = jc / dg, cl = c - gi * cg;
+        const bool in = jz < G::DS && cl >= 0 && cl < cg;
+        const float t = p.Wd[(long)jc * cg + (in ? cl : 0)];
+        w[e] = in ? t : 0.f;
+      }
+      *reinterpret_cast<uint4*>(wdT + c * G::PZ + j0 * 2) = make_uint4(f2bf2(w[0], w[1]), f2bf2(w[2], w[3]), f2bf2(w[4], w[5]), f2bf2(w[6], w[7]));
+    }
+  }
+  for (int i = tid; i < G::DDP; i += G::NTHR) {
+    const int ic = i < G::DD ? i : 0;
+    const float bb = p.bv2[ic], w = bf2f(p.aq2[(long)b * G::DD + ic]) * p.ws[ic];
+    bv2s[i] = i < G::DD ? bb : 0.f;
+    w2s[i] = i < G::DD ? w : 0.f;
+  }
+  {
+    const float tgv = p.tg ? p.gamma * p.tg[b] : 0.f;
+    for (int i = tid; i < C; i += G::NTHR) {
+      mcs[i] = p.alpha * chb[i] + 1.f - p.alpha + tgv;
+      lnws[i] = has_ln ? p.lnw[i] : 1.f;
+      opcs[i] = 1.f + chb[i];
+    }
+  }
+  if (tid < 16) {                                          // BatchNorm-1 backward: dx = k1 * dyb - k2 - x * k3, mask = (x * a + sh > 0)
+    const int c = tid < G::DS ? tid : 0;
+    float a = 1.f, sh = 0.f, k2 = 0.f, k3 = 0.f;
+    if (p.has_bn) {
+      a = p.bn_sc[c]; sh = p.bn_sh[c];
+      if (p.training) { k3 = a * p.bn_rstd[c] * p.bn_sums[G::DS + c] * p.inv_rows; k2 = a * p.bn_sums[c] * p.inv_rows - p.bn_mean[c] * k3; }
+    }
+    bnv[tid] = a; bnv[16 + tid] = sh; bnv[32 + tid] = a; bnv[48 + tid] = k2; bnv[64 + tid] = k3;
+  }
+  char* ximg = wave0 + wave * G::WAVE_BYTES;
+  char* dvimg = ximg + G::XIMG;
+  char* dzimg = dvimg + G::DVIMG;
+  float* tokv = reinterpret_cast<float*>(dzimg + G::DZIMG);          // [10][32]: sg | mu | rstd | sl | map | dMap | dsl | S1 | S2
+  for (int i = lane; i < G::DZIMG / 16; i += 64) *reinterpret_cast<uint4*>(dzimg + i * 16) = make_uint4(0, 0, 0, 0);   // columns >= DS stay zero
+  __syncthreads();
+
+  const int nblk = p.N / 32, stride = p.wpf * G::WAVES;
+  const long frame0 = (long)b * p.N;
+  const float mapdot = p.dMap ? p.mapdot[b] : 0.f;
+  int blk = part * G::WAVES + wave;
+  fg_u32x4 nx[G::NV];
+  fg_u32x2 ndz[G::NZ], nzp[G::NZ];
+  float ntok[6];
+  auto prefetch = [&](int bk) {                            // everything of block bk that comes from HBM (unconditional, clamped index)
+    const long r0 = frame0 + (long)bk * 32;
+    fg_gload<G::NV>(nx, p.X1 + r0 * C, lane);
+#pragma unroll
+    for (int i = 0; i < G::NZ; ++i) {
+      int q = i * 64 + lane; q = q < 8 * G::DS ? q : 8 * G::DS - 1;
+      ndz[i] = *reinterpret_cast<const fg_u32x2*>(p.dZ + r0 * G::DS + q * 4);
+      nzp[i] = *reinterpret_cast<const fg_u32x2*>(p.Zp + r0 * G::DS + q * 4);
+    }
+    const long row = r0 + tl;
+    ntok[0] = p.sg[row]; ntok[1] = has_ln ? p.mu[row] : 0.f; ntok[2] = has_ln ? p.rstd[row] : 1.f;
+    ntok[3] = p.sl[row]; ntok[4] = p.map[row]; ntok[5] = p.dMap ? p.dMap[row] : 0.f;
+  };
+  prefetch(blk < nblk ? blk : nblk - 1);
+
+  float a_lnw[G::NT], a_lnb[G::NT], a_chA[G::NT], a_chB[G::NT], a_u[G::JT], a_bv[G::JT];
+#pragma unroll
+  for (int i = 0; i < G::NT; ++i) { a_lnw[i] = 0.f; a_lnb[i] = 0.f; a_chA[i] = 0.f; a_chB[i] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < G::JT; ++i) { a_u[i] = 0.f; a_bv[i] = 0.f; }
+  float tsum = 0.f, bsum = 0.f;
+  const float invC = 1.f / (float)C;
+
+  for (; blk < nblk; blk += stride) {
+    // The lane id is made OPAQUE once per block: every per-lane address below (a few dozen LDS / global offsets) is loop-invariant,
+    // and hipcc hoists them all out of the block loop -- 100+ VGPRs of addresses, i.e. spills.  Recomputing them costs ~150 VALU
+    // instructions per block.
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    const int h = lane >> 5, tl = lane & 31;
+    // element (token = mt_row(r, lane), channel = 32 tile + tl) of an image = ONE per-lane base + a compile-time offset
+    char* const xcol = ximg + 4 * h * G::PW + tl * 2;
+    char* const dvcol = dvimg + 4 * h * G::PV + tl * 2;
+    const long r0 = frame0 + (long)blk * 32;
+    // ---- block -> images; Xc = X1 (1 + ch) and dZp leave from the load layout (coalesced)
+#pragma unroll
+    for (int i = 0; i < G::NV; ++i) {
+      const int idx = i * 64 + lane, r = idx / G::CPR, c8 = idx - r * G::CPR;
+      *reinterpret_cast<fg_u32x4*>(ximg + r * G::PW + c8 * 16) = nx[i];
+      float x[8];
+      fg_unpack8(__builtin_bit_cast(bfx8, nx[i]), x);
+      const float4 o0 = *reinterpret_cast<const float4*>(opcs + c8 * 8), o1 = *reinterpret_cast<const float4*>(opcs + c8 * 8 + 4);
+      x[0] *= o0.x; x[1] *= o0.y; x[2] *= o0.z; x[3] *= o0.w; x[4] *= o1.x; x[5] *= o1.y; x[6] *= o1.z; x[7] *= o1.w;
+      reinterpret_cast<bfx8*>(p.Xc + r0 * C)[idx] = fg_pack8(x);
+    }
+#pragma unroll
+    for (int i = 0; i < G::NZ; ++i) {
+      const int q = i * 64 + lane;
+      if (q < 8 * G::DS) {
+        const int e0 = q * 4, tok = e0 / G::DS, jz0 = e0 - tok * G::DS;
+        const float4 va = *reinterpret_cast<const float4*>(bnv + jz0), vs = *reinterpret_cast<const float4*>(bnv + 16 + jz0);
+        const float4 v2 = *reinterpret_cast<const float4*>(bnv + 48 + jz0), v3 = *reinterpret_cast<const float4*>(bnv + 64 + jz0);
+        const float a[4] = {va.x, va.y, va.z, va.w}, sh[4] = {vs.x, vs.y, vs.z, vs.w};
+        const float k2[4] = {v2.x, v2.y, v2.z, v2.w}, k3[4] = {v3.x, v3.y, v3.z, v3.w};
+        const float dy[4] = {__uint_as_float(ndz[i].x << 16), __uint_as_float(ndz[i].x & 0xffff0000u), __uint_as_float(ndz[i].y << 16),
+                             __uint_as_float(ndz[i].y & 0xffff0000u)};
+        const float zx[4] = {__uint_as_float(nzp[i].x << 16), __uint_as_float(nzp[i].x & 0xffff0000u), __uint_as_float(nzp[i].y << 16),
+                             __uint_as_float(nzp[i].y & 0xffff0000u)};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gg = (zx[e] * a[e] + sh[e] > 0.f) ? dy[e] : 0.f;
+          o[e] = a[e] * gg - k2[e] - zx[e] * k3[e];
+        }
+        const uint2 w = make_uint2(f2bf2(o[0], o[1]), f2bf2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(p.dZ + r0 * G::DS + e0) = w;
+        *reinterpret_cast<uint2*>(dzimg + tok * G::PZ + jz0 * 2) = w;
+      }
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tokv[i * 32 + lane] = ntok[i];
+    }
+    fg_wave_sync();
+
+    // per-token scalars of the 16 tokens whose accumulator rows this lane holds (token = mt_row(r, lane)) are re-read from the
+    // wave's LDS vectors tile by tile (float4 broadcasts): held in registers they are 48 VGPRs this kernel does not have
+    auto tokvec = [&](int which, f32x16& v) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(tokv + which * 32 + 8 * q + 4 * h);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      }
+    };
+    const bfx8 zf = fg_lds8(dzimg + tl * G::PZ + h * 16);            // dZp as the A operand (row = token, k = bottleneck channel)
+
+    // ---- pass 1, channel tiles as the M operand: acc[channel][token], the lane's OWN token (tl) -- the per-token sums over
+    // channels of the LayerNorm backward (S1 = mean gw, S2 = mean gw xh) and of dsg (T = sum_c dX2 X1, expanded into three more
+    // sums) are in-lane sums + one exchange with lane ^ 32; the spatial-gate backward is then ONE evaluation per lane.
+    {
+      const float sg_t = tokv[tl], mu_t = tokv[32 + tl], rs_t = tokv[64 + tl];
+      const float bsg = p.beta * sg_t;
+      float S1 = 0.f, S2 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f;
+      const char* xr = ximg + tl * G::PW + 8 * h;
+#pragma unroll
+      for (int nt = 0; nt < G::NT; ++nt) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg_lds8(wdT + (32 * nt + tl) * G::PZ + h * 16), zf, acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = 32 * nt + 8 * q + 4 * h;
+          const uint2 raw = *reinterpret_cast<const uint2*>(xr + (32 * nt + 8 * q) * 2);
+          const float4 m4 = *reinterpret_cast<const float4*>(mcs + c0), w4 = *reinterpret_cast<const float4*>(lnws + c0);
+          const float x1[4] = {__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                               __uint_as_float(raw.y & 0xffff0000u)};
+          const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (x1[e] * (mm[e] + bsg) - mu_t) * rs_t;
+            const float gw = acc[4 * q + e] * ww[e];
+            S1 += gw; S2 += gw * xh; A1 += gw * x1[e]; A2 += x1[e]; A3 += xh * x1[e];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      S1 += fg_xor32(S1); S2 += fg_xor32(S2); A1 += fg_xor32(A1); A2 += fg_xor32(A2); A3 += fg_xor32(A3);
+      float T = A1;                                        // no ln_before: dX2 = dX3
+      if (has_ln) { S1 *= invC; S2 *= invC; T = rs_t * (A1 - S1 * A2 - S2 * A3); }
+      float d = p.beta * T * sg_t * (1.f - sg_t);
+      if (p.dMap) { const float t = tanhf(tokv[96 + tl]); d += tokv[128 + tl] * (tokv[160 + tl] - mapdot) * (1.f - t * t); }
+      if (lane < 32) { tokv[192 + tl] = d; tokv[224 + tl] = S1; tokv[256 + tl] = S2; bsum += d; tsum += T; }
+    }
+    fg_wave_sync();
+    // ---- pass 2, token rows as the M operand: acc[token][channel], the lane's channel = 32 nt + tl -- the per-channel sums over
+    // tokens (d lnw, d lnb, first part of dch) are in-lane sums over the 16 registers; dX1a = dX2 * modulation is kept packed
+    unsigned pk[G::NT][8];
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf, fg_lds8(wdT + (32 * nt + tl) * G::PZ + h * 16), acc, 0, 0, 0);
+      const int c = 32 * nt + tl;
+      const float mc = mcs[c], lw = lnws[c];
+      float sw = 0.f, sb = 0.f, sc = 0.f;
+      float o[16];
+      f32x16 sgv, muv, rsv, s1v, s2v;
+      asm volatile("" ::: "memory");
+      tokvec(0, sgv); tokvec(1, muv); tokvec(2, rsv); tokvec(7, s1v); tokvec(8, s2v);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x1 = bf2f(fg_ldsu16(xcol + ((r & 3) + 8 * (r >> 2)) * G::PW + 64 * nt));
+        const float m = mc + p.beta * sgv[r];
+        float dx2 = acc[r];
+        if (has_ln) {
+          const float xh = (x1 * m - muv[r]) * rsv[r];
+          dx2 = rsv[r] * (acc[r] * lw - s1v[r] - xh * s2v[r]);
+          sw += acc[r] * xh;
+        }
+        sb += acc[r];
+        const float dm = dx2 * x1;
+        sc += dm;
+        o[r] = dx2 * m;
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // small scheduling regions: left free, hipcc interleaves the whole
+      }                                                         // unrolled pass and runs out of its 512 registers (98-216 spills)
+      a_lnw[nt] += sw; a_lnb[nt] += sb; a_chA[nt] += sc;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) pk[nt][r] = f2bf2(o[2 * r], o[2 * r + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // (the next block's loads are issued here, not at the top: the row-sum registers of the two passes above are dead now)
+    prefetch(blk + stride < nblk ? blk + stride : nblk - 1);
+    // ---- vq2 recomputed (token rows x per-frame-scaled Wv2), dvq2, u, d bv2
+#pragma unroll
+    for (int jt = 0; jt < G::JT; ++jt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* arow = ximg + tl * G::PW + h * 16;
+      const char* brow = w2img + (32 * jt + tl) * G::PW + h * 16;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg_lds8(arow + kk * 32), fg_lds8(brow + kk * 32), acc, 0, 0, 0);
+      const int j = 32 * jt + tl;
+      const float bb = bv2s[j], wj = w2s[j];
+      float su = 0.f, sv = 0.f;
+      f32x16 dsl;
+      tokvec(6, dsl);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaxf(acc[r] + bb, 0.f);
+        const float dv = v > 0.f ? dsl[r] * wj : 0.f;
+        su += dsl[r] * v; sv += dv;
+        *reinterpret_cast<unsigned short*>(dvcol + ((r & 3) + 8 * (r >> 2)) * G::PV + 64 * jt) = f2bf(dv);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      a_u[jt] += su; a_bv[jt] += sv;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fg_wave_sync();
+    {   // dvq2 rows leave as 16-byte stores
+      constexpr int CPRV = G::DD / 8, NCH = 32 * CPRV;
+      fg_u32x4* dst = reinterpret_cast<fg_u32x4*>(p.dvq2 + r0 * G::DD);
+#pragma unroll
+      for (int i = 0; i < (NCH + 63) / 64; ++i) {
+        const int idx = i * 64 + lane;
+        if (NCH % 64 == 0 || idx < NCH) {
+          const int r = idx / CPRV, c8 = idx - r * CPRV;
+          dst[idx] = *reinterpret_cast<const fg_u32x4*>(dvimg + r * G::PV + c8 * 16);
+        }
+      }
+    }
+    // ---- dX1 = dX1a + dvq2 W2_b  (= dXc (1 + ch)),  dch += dXc * X1; result replaces the X1 image tile by tile
+    const char* drow = dvimg + tl * G::PV + h * 16;
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < G::DDP / 16; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg_lds8(drow + kk * 32), mt_frag_mn(w2img, G::PW, 32 * nt, kk, lane), acc, 0, 0, 0);
+      const int c = 32 * nt + tl;
+      float sc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        char* px = xcol + ((r & 3) + 8 * (r >> 2)) * G::PW + 64 * nt;
+        const float x1 = bf2f(fg_ldsu16(px));
+        sc += acc[r] * x1;
+        const unsigned w = pk[nt][r >> 1];
+        const float a1 = (r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+        *reinterpret_cast<unsigned short*>(px) = f2bf(a1 + acc[r]);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      a_chB[nt] += sc;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fg_wave_sync();
+    {
+      fg_u32x4* dst = reinterpret_cast<fg_u32x4*>(p.dX1 + r0 * C);
+#pragma unroll
+      for (int i = 0; i < G::NV; ++i) {
+        const int idx = i * 64 + lane, r = idx / G::CPR, c8 = idx - r * G::CPR;
+        dst[idx] = *reinterpret_cast<const fg_u32x4*>(ximg + r * G::PW + c8 * 16);
+      }
+    }
+    fg_wave_sync();
+  }
+
+  // ---- per-channel sums: the two token halves of a wave, then the 8 waves through LDS, then out
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(wave0);             // [WAVES][NQ]
+  {
+    float* rw = red + wave * G::NQ;
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) {
+      const float v0 = a_lnw[nt] + fg_xor32(a_lnw[nt]), v1 = a_lnb[nt] + fg_xor32(a_lnb[nt]);
+      const float v2 = a_chA[nt] + fg_xor32(a_chA[nt]), v3 = a_chB[nt] + fg_xor32(a_chB[nt]);
+      if (lane < 32) { rw[32 * nt + tl] = v0; rw[C + 32 * nt + tl] = v1; rw[2 * C + 32 * nt + tl] = v2; rw[3 * C + 32 * nt + tl] = v3; }
+    }
+#pragma unroll
+    for (int jt = 0; jt < G::JT; ++jt) {
+      const float v0 = a_u[jt] + fg_xor32(a_u[jt]), v1 = a_bv[jt] + fg_xor32(a_bv[jt]);
+      if (lane < 32) { rw[4 * C + 32 * jt + tl] = v0; rw[4 * C + G::DDP + 32 * jt + tl] = v1; }
+    }
+    tsum = group_sum(tsum, 64); bsum = group_sum(bsum, 64);
+    if (lane == 0) { misc[wave] = tsum; misc[8 + wave] = bsum; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < G::NK; ++k) {
+    const int i = tid + k * G::NTHR;
+    if (i < G::NQ) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < G::WAVES; ++w) s += red[w * G::NQ + i];
+      if (i < 2 * C) keep[k] += s;                                                   // d lnw | d lnb
+      else if (i < 3 * C) unsafeAtomicAdd(p.dch + (long)b * C + (i - 2 * C), p.alpha * s);
+      else if (i < 4 * C) unsafeAtomicAdd(p.dch + (long)b * C + (i - 3 * C), s / opcs[i - 3 * C]);
+      else if (i < 4 * C + G::DDP) { const int j = i - 4 * C; if (j < G::DD) unsafeAtomicAdd(p.u + (long)b * G::DD + j, s); }
+      else keep[k] += s;                                                             // d bv2
+    }
+  }
+  if (tid == 0) {
+    float t = 0.f, bs = 0.f;
+#pragma unroll
+    for (int w = 0; w < G::WAVES; ++w) { t += misc[w]; bs += misc[8 + w]; }
+    keep_bs += bs;
+    if (p.dtg) unsafeAtomicAdd(p.dtg + b, p.gamma * t);
+  }
+  }   // items
+  constexpr int L = 2 * C + G::DD + 1;
+  float* prow = p.part + (long)blockIdx.x * L;
+#pragma unroll
+  for (int k = 0; k < G::NK; ++k) {
+    const int i = tid + k * G::NTHR;
+    if (i < 2 * C) prow[i] = keep[k];
+    else if (i >= 4 * C + G::DDP && i < G::NQ) { const int j = i - 4 * C - G::DDP; if (j < G::DD) prow[2 * C + j] = keep[k]; }
+  }
+  if (tid == 0) prow[2 * C + G::DD] = keep_bs;
+}
+
+// mapdot[b] = sum_n map[b][n] * dMap[b][n]   (softmax-backward inner product of the returned map; last layer only)
+__global__ __launch_bounds__(256) void mapdot_k(const float* map, const float* dMap, int N, float* out) {
+  __shared__ float red[4];
+  const long o = (long)blockIdx.x * N;
+  float pd = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) pd += map[o + n] * dMap[o + n];
+  pd = block_sum(pd, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = pd;
+}
+// grads += sum over workgroups of part rows [d lnw | d lnb | d bv2 | d bs]
+struct GFin { const float* part; int nwg, L, C, DD; float* dlnw; float* dlnb; float* dbv2; float* dbs; };
+__global__ __launch_bounds__(256) void gate_bwd_finish_k(const GFin p) {
+  // 64 columns x 4 row slices per workgroup
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < p.L) {
+    int k = sl;
+    for (; k + 4 < p.nwg; k += 8) { s0 += p.part[(long)k * p.L + i]; s1 += p.part[(long)(k + 4) * p.L + i]; }
+    for (; k < p.nwg; k += 4) s0 += p.part[(long)k * p.L + i];
+  }
+  red[sl][col] = s0 + s1;
+  __syncthreads();
+  if (sl != 0 || i >= p.L) return;
+  const float s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  float* dst = i < p.C ? (p.dlnw ? p.dlnw + i : nullptr) : i < 2 * p.C ? (p.dlnb ? p.dlnb + (i - p.C) : nullptr)
+             : i < 2 * p.C + p.DD ? p.dbv2 + (i - 2 * p.C) : p.dbs;
+  if (dst) *dst += s;
+}
+
 std::atomic<int> g_gatefuse{-1};
 }  // namespace
 
 int gatefuse_mode(int set) {
   if (g_gatefuse.load(std::memory_order_relaxed) < 0) g_gatefuse.store(getenv("DGSCT_NO_GATEFUSE") ? 0 : 1, std::memory_order_relaxed);
   const int old = g_gatefuse.load(std::memory_order_relaxed);
-  if (set >= 0) g_gatefuse.store(set ? 1 : 0, std::memory_order_relaxed);
+  if (set >= 0) g_gatefuse.store(set > 2 ? 1 : set, std::memory_order_relaxed);
   return old;
 }
 
@@ -346,6 +823,53 @@ void gatemod_fwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq
     case 256: launch(gatemod_fwd_k<256>); break;
     default: set_error("gatemod_fwd: unsupported width %d", C);
   }
+}
+
+
+bool gate_bwd_fused_supported(int mode, int N, int C, int ds, int g) {
+  return gate_fused_supported(mode, N, C, ds, g) && (C == 96 || C == 128) && ds == C / 8;
+}
+
+long gate_bwd_part_floats(int B, int C) { return (long)(1024 + B) * (2 * C + C / 2 + 1); }
+
+void gatemod_bwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq2, const float* Wv2, const float* bv2, const float* ws,
+                 const float* tg, float alpha, float beta, float gamma, const float* lnw, const float* mu, const float* rstd,
+                 const float* sl, const float* sg, const float* map, const float* dMap, int B, int N, int C, int ds, int g, const float* Wd,
+                 void* dZ, const void* Zp, const float* bn_mean, const float* bn_rstd, const float* bn_sc, const float* bn_sh,
+                 const float* bn_sums, int has_bn, int training, void* dX1, void* dvq2, void* Xc, float* dch, float* u, float* dtg,
+                 float* dlnw, float* dlnb, float* dbv2, float* dbs, float* mapdot_scratch, float* part, long part_floats) {
+  hipStream_t st = (hipStream_t)ctx.stream;
+  if (dMap) hipLaunchKernelGGL(mapdot_k, dim3(B), dim3(256), 0, st, map, dMap, N, mapdot_scratch);
+  GB a{(const unsigned short*)X1, ch, (const unsigned short*)aq2, Wv2, bv2, ws, tg, alpha, beta, gamma, lnw, mu, rstd, sl, sg, map, dMap,
+       mapdot_scratch, B, N, g, 1, Wd, (unsigned short*)dZ, (const unsigned short*)Zp, bn_mean, bn_rstd, bn_sc, bn_sh, bn_sums, has_bn,
+       training, 1.f / ((float)B * (float)N), (unsigned short*)dX1, (unsigned short*)dvq2, (unsigned short*)Xc, dch, u, tg ? dtg : nullptr, part};
+  const int nblk = N / 32;
+  const int L = 2 * C + C / 2 + 1;
+  int nwg = 0;
+  auto launch = [&](auto kern) {
+    // parts per frame: every wave of an item should get >= 2 blocks, and the items should fill whole rounds of the grid
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int maxw = nblk / 8; if (maxw < 1) maxw = 1;
+    int best = 1; double be = -1;
+    for (int w = 1; w <= maxw; ++w) {
+      const long items = (long)B * w;
+      const double e = (double)items / (double)(((items + cus - 1) / cus) * cus);
+      if (e > be + 1e-9) { be = e; best = w; }
+    }
+    a.wpf = best;
+    const long items = (long)B * best;
+    nwg = (int)(items < cus ? items : cus);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, st, a);
+  };
+  if ((long)1024 * L > part_floats) { set_error("gatemod_bwd: partial-sum scratch too small"); return; }
+  switch (C) {
+    case 96: if (lnw) launch(gatemod_bwd_k<96, true>); else launch(gatemod_bwd_k<96, false>); break;
+    case 128: if (lnw) launch(gatemod_bwd_k<128, true>); else launch(gatemod_bwd_k<128, false>); break;
+    default: set_error("gatemod_bwd: unsupported width %d", C); return;
+  }
+  GFin f{part, nwg, L, C, C / 2, dlnw, dlnb, dbv2, dbs};
+  hipLaunchKernelGGL(gate_bwd_finish_k, dim3((L + 63) / 64), dim3(256), 0, st, f);
 }
 
 }  // namespace dgsct

@@ -406,11 +406,14 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     if (tmap) ew(ctx, EW_COPY, tmap, DT_F32, F32(b.S(s.tg)), NOARG, NOARG, B, 0.f, 1);
   }
   if (gfuse) {
-    scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);        // Xc = X1 * (1 + ch): backward's dWv2 operand
+    // (with the fused backward nothing downstream reads Xc or vq2: it recomputes both from X1)
+    const bool bfuse = gate_bwd_fused_supported(ctx.mode, N, C, ds, g);
+    if (!bfuse) scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);     // Xc = X1 * (1 + ch): backward's dWv2 operand
     gatemod_fwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S(s.aq2), b.F(DGSCT_P_WV2), b.F(DGSCT_P_BV2), b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
                 d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta, d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr,
                 d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C, ds, g, b.F(DGSCT_P_WD), b.S<float>(s.sl), b.S(s.X3),
-                b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S(s.Zp), d.use_bn && d.training ? b.S<float>(s.bnacc1) : nullptr, b.S(s.vq2));
+                b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S(s.Zp), d.use_bn && d.training ? b.S<float>(s.bnacc1) : nullptr,
+                (!bfuse || gatefuse_mode(-1) == 2) ? b.S(s.vq2) : nullptr);
     spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map), map);   // saved copy + the returned map
   } else {
     scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);        // Xc = X1 * (1 + ch)
@@ -544,20 +547,43 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   }
   // B9 ---- relu, BN1 backward, down projection
   void* dZ = b.Wk(wb.dZ);
-  if (d.use_bn) {
+  void* dX1 = b.Wk(wb.dX1);
+  const bool bfuse = gate_bwd_fused_supported(ctx.mode, N, C, ds, g) && !fp8;
+  if (d.use_bn)
     bn_bwd_stats(ctx, dZ, b.S(s.Zp), R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, 1, G(DGSCT_P_BN1_B), b.Wk<float>(wb.rowpart),
                  row_part_floats(B, C));
+  Gemm gwd = mk(dg, cg, (int)R, g);                              // dWd = dZp^T (x)_g X3
+  gwd.A = mn(dZ, ds, dg);
+  gwd.B = mn(b.S(s.X3), C, cg);
+  outF(gwd, G(DGSCT_P_WD), cg, (long)dg * cg);
+  atomic_out(gwd);
+  Gemm gwv2 = mk(dd, C, (int)R);                                 // dWv2 = dvq2^T . Xc
+  gwv2.A = mn(b.S(s.vq2), dd);
+  gwv2.B = mn(b.S(s.Xc), C);
+  outF(gwv2, G(DGSCT_P_WV2), C);
+  atomic_out(gwv2);
+  if (bfuse) {
+    // B9 (BN1 apply, dX3) + B8 + B7 in ONE pass over X1 (fused_gate.hip): dZp in place, dX1, dvq2 (over the vq2 region), Xc
+    gatemod_bwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S(s.aq2), b.F(DGSCT_P_WV2), b.F(DGSCT_P_BV2), b.F(DGSCT_P_WS), tg, d.alpha, d.beta,
+                d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S<float>(s.sl),
+                b.S<float>(s.sg), b.S<float>(s.map), dMap, B, N, C, ds, g, b.F(DGSCT_P_WD), dZ, b.S(s.Zp), bn1, bn1 + ds, bn1 + 2 * ds,
+                bn1 + 3 * ds, d.use_bn ? G(DGSCT_P_BN1_B) : nullptr, d.use_bn, d.training, dX1, b.S(s.vq2), b.S(s.Xc),
+                b.Wk<float>(wb.dch), b.Wk<float>(wb.u), b.Wk<float>(wb.dtg), G(DGSCT_P_LNB_W), G(DGSCT_P_LNB_B), G(DGSCT_P_BV2),
+                G(DGSCT_P_BS), b.Wk<float>(wb.rowtmp), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+    defer([=, &side] { gemm(side, gwd); });
+    defer([=, &side] { gemm(side, gwv2); });
+    side_flush();
+    // tmpBd = u * aq2 (d ws = sum_b tmpBd: with the bias gradients below, colsum_multi);  dpa2 = u * ws * (aq2 > 0)
+    ew2(ctx, EwCall{EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1},
+        EwCall{EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd});
+  } else {
+  if (d.use_bn) {
     bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, G(DGSCT_P_BN1_B), 1, 1, d.training);
   } else {
     bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0);
   }
   {
-    Gemm g1 = mk(dg, cg, (int)R, g);                             // dWd = dZp^T (x)_g X3
-    g1.A = mn(dZ, ds, dg);
-    g1.B = mn(b.S(s.X3), C, cg);
-    outF(g1, G(DGSCT_P_WD), cg, (long)dg * cg);
-    atomic_out(g1);
-    defer([=, &side] { gemm(side, g1); });
+    defer([=, &side] { gemm(side, gwd); });
     side_flush();
     if (vproj) {                                                 // dX3 = dZp (x)_g Wd
       gproj_wide(ctx, dZ, R, C, ds, g, b.F(DGSCT_P_WD), (long)dg * cg, cg, 1, b.Wk(wb.dX3), nullptr);
@@ -570,7 +596,6 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     }
   }
   // B8 ---- ln_before, modulation
-  void* dX1 = b.Wk(wb.dX1);
   modln_bwd(ctx, b.Wk(wb.dX3), b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), tg, d.alpha, d.beta, d.gamma,
             d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, b.S<float>(s.mu_b), b.S<float>(s.rstd_b), B, N, C, dX1,
             G(DGSCT_P_LNB_W), G(DGSCT_P_LNB_B), b.Wk<float>(wb.dch), b.Wk<float>(wb.dsg), b.Wk<float>(wb.dtg),
@@ -591,14 +616,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g1.B = b.WB(DGSCT_P_WV2, C, dd);
     outE(g1, b.Wk(wb.dXc), E, C);
     gemm(ctx, g1);
-    Gemm g2 = mk(dd, C, (int)R);                                 // dWv2 = dvq2^T . Xc
-    g2.A = mn(b.S(s.vq2), dd);
-    g2.B = mn(b.S(s.Xc), C);
-    outF(g2, G(DGSCT_P_WV2), C);
-    atomic_out(g2);
-    defer([=, &side] { gemm(side, g2); });
+    defer([=, &side] { gemm(side, gwv2); });
     side_flush();
     xc_bwd(ctx, b.Wk(wb.dXc), b.S(s.X1), dX1, B, N, C, b.S<float>(s.ch), b.Wk<float>(wb.dch));
+  }
   }
   // B6 ---- channel-gate head
   {

@@ -154,11 +154,28 @@ void gproj_wide(const Ctx&, const void* x, long rows, int C, int ds, int g, cons
 // Wv2 [C/2][C], Wd [ds][C/g]: the fp32 MASTER weights.  aq2: E [B][C/2].  vq2 (optional, E [B][N][C/2]): relu(...) for callers that
 // still want it materialised.
 bool gate_fused_supported(int mode, int N, int C, int ds, int g);
-int gatefuse_mode(int set);       // test / tuning switch (dgsct_test_tune "gatefuse"); set < 0: query
+// 0: off, 1: on (default), 2: on, and the forward still materialises vq2 for inspection (tests pin the device's ReLU decisions).
+// dgsct_test_tune "gatefuse"; set < 0: query
+int gatefuse_mode(int set);
 void gatemod_fwd(const Ctx&, const void* X1, const float* ch, const void* aq2, const float* Wv2, const float* bv2, const float* ws,
                  const float* bs, const float* tg, float alpha, float beta, float gamma, const float* lnw, const float* lnb, float eps,
                  int B, int N, int C, int ds, int g, const float* Wd, float* sl, void* X3, float* mu, float* rstd, void* Zp,
                  float* stats, void* vq2);
+// Backward of the same chain in one pass over X1 (C in {96, 128}, ds = C / 8): replaces bn_bwd_apply (BN1) -> dX3 projection ->
+// modln_bwd -> spatial_bwd -> colsum (u) -> relu_bwd_scale (dvq2) -> dXc GEMM -> xc_bwd.  vq2 is recomputed from X1.
+//   in : dZ (E [R][ds], cotangent of relu(bn1(Zp))), Zp, BN1 vectors (mean | rstd | sc | sh) and its backward sums (2*ds, from
+//        bn_bwd_stats), saved sl / sg / map / mu / rstd, dMap (may be null)
+//   out: dZ <- dZp (in place), dX1 (E, written), dvq2 (E [R][C/2]), Xc = X1 (1 + ch) (E; operand of the dWv2 GEMM),
+//        dch [B][C] +=, u [B][C/2] += sum_n dsl vq2, dtg [B] += (tg != null), dlnw / dlnb [C] += (lnw != null), dbv2 [C/2] +=, *dbs +=
+//   mapdot_scratch: B floats; part: gate_bwd_part_floats(B, C) floats of scratch.
+bool gate_bwd_fused_supported(int mode, int N, int C, int ds, int g);
+long gate_bwd_part_floats(int B, int C);
+void gatemod_bwd(const Ctx&, const void* X1, const float* ch, const void* aq2, const float* Wv2, const float* bv2, const float* ws,
+                 const float* tg, float alpha, float beta, float gamma, const float* lnw, const float* mu, const float* rstd,
+                 const float* sl, const float* sg, const float* map, const float* dMap, int B, int N, int C, int ds, int g, const float* Wd,
+                 void* dZ, const void* Zp, const float* bn_mean, const float* bn_rstd, const float* bn_sc, const float* bn_sh,
+                 const float* bn_sums, int has_bn, int training, void* dX1, void* dvq2, void* Xc, float* dch, float* u, float* dtg,
+                 float* dlnw, float* dlnb, float* dbv2, float* dbs, float* mapdot_scratch, float* part, long part_floats);
 
 // acc = [shift | sum(x-shift) | sum((x-shift)^2)] per column, 3*C floats, pre-zeroed.  x is E [rows][C].
 void bn_stats(const Ctx&, const void* x, long rows, int C, float* acc);

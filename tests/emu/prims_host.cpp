@@ -398,6 +398,42 @@ void gatemod_fwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq
   if (stats) bn_stats(ctx, Zp, (long)B * N, ds, stats);
 }
 
+bool gate_bwd_fused_supported(int mode, int N, int C, int ds, int g) { return gate_fused_supported(mode, N, C, ds, g); }
+long gate_bwd_part_floats(int, int) { return 0; }
+// composition of the host primitives the device kernel replaces (same order as the unfused schedule)
+void gatemod_bwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq2, const float* Wv2, const float* bv2, const float* ws,
+                 const float* tg, float alpha, float beta, float gamma, const float* lnw, const float* mu, const float* rstd,
+                 const float* sl, const float* sg, const float* map, const float* dMap, int B, int N, int C, int ds, int g, const float* Wd,
+                 void* dZ, const void* Zp, const float* bn_mean, const float* bn_rstd, const float* bn_sc, const float* bn_sh,
+                 const float* bn_sums, int has_bn, int training, void* dX1, void* dvq2, void* Xc, float* dch, float* u, float* dtg,
+                 float* dlnw, float* dlnb, float* dbv2, float* dbs, float*, float*, long) {
+  const long R = (long)B * N;
+  const int dd = C / 2, cg = C / g, dg = ds / g;
+  const size_t es = dt_size(ctx.mode);
+  bn_bwd_apply(ctx, dZ, Zp, dZ, R, ds, bn_mean, bn_rstd, bn_sc, bn_sh, bn_sums, 1, has_bn, training);
+  std::vector<char> dX3((size_t)R * C * es), dXc((size_t)R * C * es);
+  std::vector<float> dsg(R), dsl(R);
+  gproj_wide(ctx, dZ, R, C, ds, g, Wd, (long)dg * cg, cg, 1, dX3.data(), nullptr);
+  modln_bwd(ctx, dX3.data(), X1, ch, sg, tg, alpha, beta, gamma, lnw, mu, rstd, B, N, C, dX1, dlnw, dlnb, dch, dsg.data(), dtg);
+  spatial_bwd(ctx, sl, sg, map, dsg.data(), dMap, B, N, dsl.data(), dbs);
+  scale_cols(ctx, X1, Xc, B, N, C, ch, 1.f);
+  for (long r = 0; r < R; ++r)                               // vq2 recomputed: relu(Xc Wv2^T + bv2)
+    for (int j = 0; j < dd; ++j) {
+      double a = bv2[j];
+      for (int c = 0; c < C; ++c) a += (double)ld(Xc, ctx.mode, r * C + c) * Wv2[(long)j * C + c];
+      st(dvq2, ctx.mode, r * dd + j, a > 0 ? (float)a : 0.f);
+    }
+  colsum_batched(ctx, dvq2, dd, (long)N * dd, B, N, dd, dsl.data(), N, 1.f, u, dd);
+  relu_bwd_scale(ctx, dvq2, dvq2, B, N, dd, dsl.data(), aq2, ctx.mode, ws, 1.f, dbv2);
+  for (long r = 0; r < R; ++r)                               // dXc = dvq2 . Wv2
+    for (int c = 0; c < C; ++c) {
+      double a = 0;
+      for (int j = 0; j < dd; ++j) a += (double)ld(dvq2, ctx.mode, r * dd + j) * Wv2[(long)j * C + c];
+      st(dXc.data(), ctx.mode, r * C + c, (float)a);
+    }
+  xc_bwd(ctx, dXc.data(), X1, dX1, B, N, C, ch, dch);
+}
+
 void gproj_wide(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,
                 void* y, float* stats) {
   const int cg = C / g, dg = ds / g;

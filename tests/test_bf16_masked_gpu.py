@@ -72,8 +72,14 @@ def test_bf16_backward_with_device_relu_masks(case):
     dt = torch.bfloat16
     Xd, Yd = X.to(DEV, dt).contiguous(), Y.to(DEV, dt).contiguous()
     prep = ops.prepare(lib, spec, params, dt, DEV)
-    out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
-    torch.cuda.synchronize()
+    # (the fused gate passes of stages 0-1 recompute vq2 in backward instead of storing it: "gatefuse" = 2 makes the forward
+    #  materialise it as well, so that the device's ReLU decisions can be read back)
+    old = lib.test_tune("gatefuse", 2)
+    try:
+        out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
+        torch.cuda.synchronize()
+    finally:
+        lib.test_tune("gatefuse", old)
     masks = device_relu_masks(lib, d, saved, spec, BT, dt)
     dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(DEV, dt).contiguous(), dMap.to(DEV), None)
     torch.cuda.synchronize()
