@@ -152,29 +152,49 @@ def cpu_baseline(backbone, max_seconds=30.0):
             break
         X = torch.randn(160, cfg.N, cfg.C, requires_grad=True)
         Y = torch.randn(160, cfg.No, cfg.Co, requires_grad=True)
-        t0 = time.perf_counter()
-        out, amap, _ = O.forward_autograd(p, X, Y, cfg, training=True)
-        torch.autograd.backward([out, amap], [torch.randn_like(out), torch.randn_like(amap)])
-        dt = time.perf_counter() - t0
-        for v in p.values():
-            if v.requires_grad:
-                v.grad = None
-        del out, amap, X, Y
-        t16 += cnt * dt
+        dts = []
+        for rep in range(3):              # one warm-up pass (first touch of the multi-GB saved activations), then <= 2 timed ones
+            go, gm = torch.randn(160, cfg.N, cfg.C), torch.randn(160, 1, cfg.N)
+            t0 = time.perf_counter()
+            out, amap, _ = O.forward_autograd(p, X, Y, cfg, training=True)
+            torch.autograd.backward([out, amap], [go.reshape(out.shape), gm.reshape(amap.shape)])
+            dt = time.perf_counter() - t0
+            for v in p.values():
+                if v.requires_grad:
+                    v.grad = None
+            X.grad = Y.grad = None
+            del out, amap
+            if rep:
+                dts.append(dt)
+            if time.perf_counter() + dt > t_budget and dts:
+                break
+        del X, Y
+        t16 += cnt * min(dts) if dts else cnt * dt
         n16 += 1
     model = "unknown"
+    physical = None
     try:
+        cores = set()
+        phys_id = core_id = None
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
+            if line.startswith("model name") and model == "unknown":
                 model = line.split(":", 1)[1].strip()
-                break
+            elif line.startswith("physical id"):
+                phys_id = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core_id = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys_id is not None and core_id is not None:
+                    cores.add((phys_id, core_id))
+                phys_id = core_id = None
+        physical = len(cores) or None
     except OSError:
         pass
     b1 = round(1.0 / t, 4)
     b16 = round(16.0 / t16, 4) if t16 else None
     return dict(value=b16 if b16 is not None else b1, unit="clips/s", cores=torch.get_num_threads(), kind="port", cpu_model=model,
-                logical_cpus=ncpu, value_b1=b1, value_b16=b16,
-                sample=(f"B=16: one fwd+bwd of each of the {n16} distinct adapter shapes at BT=160, weighted by the stack's call "
+                logical_cpus=ncpu, physical_cores=physical, value_b1=b1, value_b16=b16,
+                sample=(f"B=16: fwd+bwd of each of the {n16} distinct adapter shapes at BT=160 (one warm-up pass, best of <= 2 timed), weighted by the stack's call "
                         f"counts (= {t16:.1f} s for the 48-adapter step; `value`); " if b16 is not None else "B=16 sample skipped (time budget); ") +
                        f"B=1: 1 clip (BT=10) x 48 adapters, median of {len(times)} passes after 1 warm-up ({t:.2f} s/pass; `value_b1`).  "
                        f"fp32, oracle.forward_autograd (ATen op-for-op port of the reference adapter on token-major maps: at least as fast "
@@ -343,6 +363,7 @@ def main():
         host_s += time.perf_counter() - h0
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if dp:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -426,7 +447,17 @@ def main():
                                   hbm_side_gbps=round(tb / 1e9 / (ms_per_step * 1e-3)), frac_of_hbm_peak=round(tb / (ms_per_step * 1e-3) / 8e12, 3))
                 # which roof is closer: the step as a whole is limited by memory-side traffic of its multi-pass schedule
                 step_block["bound_by_data"] = "hbm" if step_block["frac_of_hbm_peak"] > step_block["frac_of_mfma_peak"] else "mfma"
+        # the same family INSIDE the timed schedule (two adapter streams + aux streams, kernels overlapping each other): its
+        # summed duration from a rocprofv3 --kernel-trace of this command, committed under profiles/ by tools/profile_round.sh
+        in_step = None
+        gfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_in_step.json")))
+        if gfiles and args.backbone == "swinv2_base" and per_gpu_batch == 16 and args.dtype == "bf16":
+            gj = json.load(open(gfiles[-1]))
+            if gj.get("gemm_ms_per_step"):
+                in_step = dict(frac=round(gemm_flops / nprof / (gj["gemm_ms_per_step"] * 1e-3) / 1e12 / peak, 4), gemm_ms_per_step=gj["gemm_ms_per_step"],
+                               launches_per_step=gj.get("launches_per_step"), source=os.path.relpath(gfiles[-1], ROOT))
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                        frac_serial=round(achieved / peak, 4), frac_in_step=in_step["frac"] if in_step else None, in_step=in_step,
                         traffic=traffic, traffic_unit=f"bytes/launch (PMC, {tsrc})" if tsrc else None,
                         traffic_source=("committed: separate rocprofv3 --pmc passes over this workload's 8 adapter shapes "
                                         "(tools/pmc_stack.sh), not measured in this run") if tsrc else None,
@@ -435,7 +466,35 @@ def main():
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
                         gemm_ms_per_step=round(gemm_ms / nprof, 3), heaviest_launch=heaviest,
                         step_frac_of_mfma_peak=step_block["frac_of_mfma_peak"], step=step_block)
+    dp_info = None
     if dp:
+        # what a driver log needs to diagnose a multi-GPU run without a second one: ranks RCCL really has, buckets launched from
+        # the hooks, the spread of the per-rank step time, and the EXPOSED cost of the gradient exchange = this step against the
+        # same steps with the exchange switched off (A/B inside this run, after the timed region; weights diverge, nothing reads them)
+        import torch.distributed as dist
+        barrier()
+        mine = torch.tensor([host_s / args.steps * 1e3, elapsed_local / args.steps * 1e3], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        reducer.paused = reducer.skip_exchange = True
+        nab = max(3, min(args.steps, 10))
+        step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(nab):
+            step()
+        barrier()
+        no_comm_ms = (time.perf_counter() - t1) / nab * 1e3
+        reducer.paused = reducer.skip_exchange = False
+        tt = torch.tensor([no_comm_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dp_info = dict(world=world, backend=dist.get_backend(), rccl_ranks=dist.get_world_size(), overlap=bool(reducer.overlap),
+                       buckets=len(reducer.buckets), hook_launches_last_step=int(getattr(reducer, "last_hook_launches", 0)),
+                       relaunches=int(getattr(reducer, "relaunches", 0)), grad_mbytes=round(sum(p.numel() for p in params) * 4 / 1e6, 1),
+                       rank_ms_per_step_min_max=[round(min(float(a[1]) for a in allr), 3), round(max(float(a[1]) for a in allr), 3)],
+                       rank_host_ms_min_max=[round(min(float(a[0]) for a in allr), 2), round(max(float(a[0]) for a in allr), 2)],
+                       ms_per_step_without_exchange=round(tt.item(), 3), allreduce_exposed_ms=round(ms_per_step - tt.item(), 3),
+                       hw_queues_env=os.environ.get("GPU_MAX_HW_QUEUES"))
         barrier()
 
     if rank == 0:
@@ -455,7 +514,7 @@ def main():
                         **({"gpu_ms_fwd_bwd": [round(sum(a.elapsed_time(b) for a, b, _ in phase_ev[-args.steps:]) / args.steps, 2),
                                                round(sum(b.elapsed_time(c) for _, b, c in phase_ev[-args.steps:]) / args.steps, 2)]}
                            if args.phases and len(phase_ev) >= args.steps else {})),
-            roofline=roofline, cpu_baseline=cpu)
+            roofline=roofline, cpu_baseline=cpu, **({"dp": dp_info} if dp_info else {}))
         # RCCL writes its version banner through C stdio: on a pipe it would be flushed at exit, i.e. AFTER this line; drain it
         # first so that the JSON line is the last thing rank 0 prints
         try:

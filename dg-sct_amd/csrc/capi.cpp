@@ -15,6 +15,8 @@ using namespace dgsct;
 // Entry of every call: forget this thread's previous dgsct error AND any stale sticky HIP error another library (PyTorch)
 // left on the thread, so that check_async() at the end reports only what THIS call raised.
 static inline void begin_call() { clear_error(); clear_async(); }
+// pure host entry points (queries, layout introspection): no HIP runtime call at all
+static inline void begin_host_call() { clear_error(); }
 
 extern "C" {
 
@@ -23,7 +25,7 @@ const char* dgsct_arch(void) { return "gfx950"; }
 const char* dgsct_last_error(void) { return last_error(); }
 
 int dgsct_query(const dgsct_adapter_desc* desc, dgsct_sizes* out) {
-  begin_call();
+  begin_host_call();
   if (!desc || !out) { set_error("dgsct_query: NULL argument"); return 2; }
   Plan p(*desc);
   if (!p.ok) return 2;
@@ -94,7 +96,7 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
 }
 
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes) {
-  begin_call();
+  begin_host_call();
   if (!desc) return 2;
   Plan p(*desc, true);
   if (!p.ok) return 2;

@@ -600,22 +600,30 @@ __global__ __launch_bounds__(256) void gatemod_bwd_k(const GB p) {
       f32x16 sgv, muv, rsv, s1v, s2v;
       asm volatile("" ::: "memory");
       tokvec(0, sgv); tokvec(1, muv); tokvec(2, rsv); tokvec(7, s1v); tokvec(8, s2v);
+      // (the ln_before flag is tested once per TILE, with two straight-line element loops behind it: tested per element it is
+      //  16 branches per tile, each serialising its ds_read_u16 behind an s_waitcnt)
+      float x1v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x1 = bf2f(fg_ldsu16(xcol + ((r & 3) + 8 * (r >> 2)) * G::PW + 64 * nt));
-        const float m = mc + p.beta * sgv[r];
-        float dx2 = acc[r];
-        if (has_ln) {
-          const float xh = (x1 * m - muv[r]) * rsv[r];
-          dx2 = rsv[r] * (acc[r] * lw - s1v[r] - xh * s2v[r]);
-          sw += acc[r] * xh;
+      for (int r = 0; r < 16; ++r) x1v[r] = bf2f(fg_ldsu16(xcol + ((r & 3) + 8 * (r >> 2)) * G::PW + 64 * nt));
+      if (has_ln) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m = mc + p.beta * sgv[r];
+          const float xh = (x1v[r] * m - muv[r]) * rsv[r];
+          const float dx2 = rsv[r] * (acc[r] * lw - s1v[r] - xh * s2v[r]);
+          sw += acc[r] * xh; sb += acc[r];
+          sc += dx2 * x1v[r];
+          o[r] = dx2 * m;
         }
-        sb += acc[r];
-        const float dm = dx2 * x1;
-        sc += dm;
-        o[r] = dx2 * m;
-        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // small scheduling regions: left free, hipcc interleaves the whole
-      }                                                         // unrolled pass and runs out of its 512 registers (98-216 spills)
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m = mc + p.beta * sgv[r];
+          sb += acc[r];
+          sc += acc[r] * x1v[r];
+          o[r] = acc[r] * m;
+        }
+      }
       a_lnw[nt] += sw; a_lnb[nt] += sb; a_chA[nt] += sc;
 #pragma unroll
       for (int r = 0; r < 8; ++r) pk[nt][r] = f2bf2(o[2 * r], o[2 * r + 1]);

@@ -14,6 +14,7 @@
 // can pull are spread over M/32 x N/32 = 40-160 CUs instead of 24.  Epilogue: bias, ReLU / sigmoid, ReLU mask of
 // another tensor, residual; fp32 or bf16 out as 16- / 8-byte row pieces.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdlib>
 #include "prims.h"
 #include "device_util.h"
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_k(const SkArgs p) {
 
 static inline bool sk_al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-int gemm_skinny_mode(int set) {
-  static int mode = getenv("DGSCT_GEMM_SKINNY") ? atoi(getenv("DGSCT_GEMM_SKINNY")) : 1;
-  const int old = mode;
-  if (set >= 0) mode = set;
+int gemm_skinny_mode(int set) {     // process-wide, test-only switch (like gemm8_mode / rowfuse_mode): atomic, DataParallel replicas run on threads
+  static std::atomic<int> mode{getenv("DGSCT_GEMM_SKINNY") ? atoi(getenv("DGSCT_GEMM_SKINNY")) : 1};
+  const int old = mode.load(std::memory_order_relaxed);
+  if (set >= 0) mode.store(set, std::memory_order_relaxed);
   return old;
 }
 

@@ -55,11 +55,17 @@ static void order_after(hipStream_t waiter, hipStream_t producer, int dir) {
 }
 // Launch errors are sticky per thread: one check at the end of an entry point reports the first failed launch of the call
 // (a wrong current device, an invalid configuration) instead of returning 0 with uninitialised outputs.
+// A pending (non-sticky) HIP error may belong to ANOTHER user of the runtime on this thread (a PyTorch launch whose status has not
+// been read yet): it is remembered at entry, NOT consumed, and an error found at exit counts as this call's only when it differs
+// from it -- the other library still sees its own error.
+static thread_local hipError_t g_pre_err = hipSuccess;
 void check_async(const char* where) {
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) set_error("%s: HIP error '%s' (is the current device the one that owns the buffers and streams?)", where, hipGetErrorString(e));
+  const hipError_t e = hipPeekAtLastError();
+  if (e == hipSuccess || e == g_pre_err) return;
+  (void)hipGetLastError();
+  set_error("%s: HIP error '%s' (is the current device the one that owns the buffers and streams?)", where, hipGetErrorString(e));
 }
-void clear_async() { (void)hipGetLastError(); }
+void clear_async() { g_pre_err = hipPeekAtLastError(); }
 void* stream_create(int priority_class) {
   int least = 0, greatest = 0;                       // numerically: the greatest priority is the SMALLER number
   hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);

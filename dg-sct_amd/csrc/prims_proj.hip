@@ -374,7 +374,7 @@ int rowfuse_mode(int set) {                              // -1: query; 0 / 1: of
 
 bool modln_gproj_supported(int mode, int C, int ds, int g) {
   ProjGeom pg;
-  return rowfuse_mode(-1) && proj_geom(mode, C, ds, g, 1 << 20, 1024, pg) && (pg.gs == 16 || pg.gs == 32);
+  return rowfuse_mode(-1) && gproj_supported(mode, C, ds, g) && proj_geom(mode, C, ds, g, 1 << 20, 1024, pg) && (pg.gs == 16 || pg.gs == 32);   // (DGSCT_NO_GPROJ switches this pass off too)
 }
 
 void modln_gproj(const Ctx& ctx, const void* X1, const float* ch, const float* sg, const float* tg, float alpha, float beta, float gamma,

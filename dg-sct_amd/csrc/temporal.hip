@@ -6,6 +6,7 @@
 // float4 loads, DPP/shuffle row reductions; the backward's per-channel sums (d wa, d wv) are reduced over the rows of a
 // workgroup in registers/LDS and leave as one atomic per channel per workgroup.
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include "prims.h"
 #include "device_util.h"
 #include "err.h"
@@ -182,8 +183,10 @@ static int fs_chunks(int rows, long inner, int V) {
   if (c > maxc) c = maxc;
   return (int)(c < 1 ? 1 : c);
 }
+static inline bool fs_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 void frame_scale_fwd(const Ctx& ctx, int rows, long inner, float gamma, const void* x, const float* g, void* y) {
   if (rows <= 0 || inner <= 0) return;
+  if (!fs_al16(x) || !fs_al16(y)) { set_error("frame_scale: x / y must be 16-byte aligned"); return; }
   const bool al = (inner % (ctx.mode == DT_BF16 ? 8 : 4)) == 0;
   if (!al) { set_error("frame_scale: the per-frame block (%ld elements) must be a multiple of 16 bytes", inner); return; }
   const int ch = fs_chunks(rows, inner, ctx.mode == DT_BF16 ? 8 : 4);
@@ -192,6 +195,7 @@ void frame_scale_fwd(const Ctx& ctx, int rows, long inner, float gamma, const vo
 }
 void frame_scale_bwd(const Ctx& ctx, int rows, long inner, float gamma, const void* x, const float* g, const void* dy, void* dx, float* dg) {
   if (rows <= 0 || inner <= 0) return;
+  if (!fs_al16(x) || !fs_al16(dy) || (dx && !fs_al16(dx))) { set_error("frame_scale: x / dy / dx must be 16-byte aligned"); return; }
   const bool al = (inner % (ctx.mode == DT_BF16 ? 8 : 4)) == 0;
   if (!al) { set_error("frame_scale: the per-frame block (%ld elements) must be a multiple of 16 bytes", inner); return; }
   hipStream_t s = (hipStream_t)ctx.stream;

@@ -71,6 +71,7 @@ class GradAllReducer:
         self._producers: List[set] = [set() for _ in self.buckets]
         self.hook_launches = 0                          # buckets launched from hooks (before finish()) in the last step
         self.paused = False                             # True: hooks do nothing (rank-local passes, e.g. bench.py's profiling leg)
+        self.skip_exchange = False                      # True: finish() sends nothing either (bench.py's "step without the exchange" A/B leg)
         self._work: List[object] = []
         self._reduced: List[torch.Tensor] = []          # tensors to scale by 1/world after the wait
         self._copy_back: List[tuple] = []               # (flat, params) of the fallback path
@@ -99,6 +100,11 @@ class GradAllReducer:
                 # gets a gradient is simply reduced later by finish(); one whose gradient is ALREADY in flight has just been
                 # accumulated into under the collective -- that cannot be repaired, finish() raises
                 if id(param) in self._sent[bi]:
+                    self._dirty[bi] = True
+                elif any(q is param for q in self._late[bi]):
+                    # a late parameter accumulated into a SECOND time (three or more backward() calls in the step): listed once --
+                    # twice in the message it would be averaged twice -- and the bucket is dirty like any other accumulation that
+                    # happens while the step's collectives are under way
                     self._dirty[bi] = True
                 else:
                     self._late[bi].append(param)
@@ -201,6 +207,9 @@ class GradAllReducer:
     def finish(self):
         """Call after loss.backward(): launches what the hooks did not, waits, averages."""
         if not self.active:
+            return
+        if self.skip_exchange:
+            self._reset()
             return
         for bi in range(len(self.buckets)):
             if self._dirty[bi]:

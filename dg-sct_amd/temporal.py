@@ -238,7 +238,7 @@ class _FrameScaleFn(torch.autograd.Function):
         xc = x.contiguous()
         gc = g.reshape(-1).contiguous().float()
         rows = gc.numel()
-        inner = xc.numel() // rows
+        inner = xc.numel() // rows if rows else 0            # (an empty gate: nothing to scale, the library returns at once)
         y = torch.empty_like(xc)
         dt = _lib.BF16 if xc.dtype == torch.bfloat16 else _lib.F32
         with _dev_guard(xc):
@@ -253,7 +253,7 @@ class _FrameScaleFn(torch.autograd.Function):
         xc, gc = ctx.saved_tensors
         dyc = dy.contiguous()
         rows = gc.numel()
-        inner = xc.numel() // rows
+        inner = xc.numel() // rows if rows else 0
         dx = torch.empty_like(xc) if ctx.needs_input_grad[2] else None
         dg = torch.empty(rows, dtype=torch.float32, device=xc.device) if ctx.needs_input_grad[3] else None
         dt = _lib.BF16 if xc.dtype == torch.bfloat16 else _lib.F32

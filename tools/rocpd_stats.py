@@ -7,11 +7,11 @@ import sys
 
 def short(name: str) -> str:
     name = re.sub(r"^void ", "", name)
-    name = name.replace("dgsct::", "")
+    name = name.replace("dgsct::", "").replace("(anonymous namespace)::", "")
     return name if len(name) <= 110 else name[:107] + "..."
 
 
-def main(path, top=40):
+def main(path, top=40, gemm_json=None, steps=None):
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     rows = c.execute("select name, count(*), sum(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
@@ -26,10 +26,21 @@ def main(path, top=40):
         k = "gemm_kernel<*>" if ("gemm_kernel" in name or "gemm8_kernel" in name) else ("torch/other" if "dgsct" not in name else re.sub(r"<.*", "", short(name)))
         a = fam.setdefault(k, [0, 0])
         a[0] += n; a[1] += tot
+    if gemm_json and steps:
+        import json
+        g = fam.get("gemm_kernel<*>", [0, 0])
+        sk = fam.get("gemm_skinny_k", [0, 0])
+        json.dump({"gemm_ms_per_step": round(g[1] / 1e6 / steps, 3), "launches_per_step": round(g[0] / steps, 1),
+                   "skinny_ms_per_step": round(sk[1] / 1e6 / steps, 3), "skinny_launches_per_step": round(sk[0] / steps, 1),
+                   "kernel_ms_per_step_all": round(total / 1e6 / steps, 2), "dispatches_per_step": round(sum(r[1] for r in rows) / steps, 1),
+                   "steps_traced": steps,
+                   "source": "rocprofv3 --kernel-trace of `python bench.py --steps 5 --warmup 2 --no-roofline --no-cpu-baseline` "
+                             "(7 steps under the timed two-stream schedule); gemm = gemm_kernel<*> + gemm8_kernel<*>"}, open(gemm_json, "w"))
     print("# by family")
     for k, (n, tot) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         print(f"{n:7d} {tot/1e6:10.3f} {tot/n/1e3:9.2f} {'':8} {'':9} {100*tot/total:6.2f}  {k}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40, sys.argv[3] if len(sys.argv) > 3 else None,
+         int(sys.argv[4]) if len(sys.argv) > 4 else None)

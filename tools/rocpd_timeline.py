@@ -16,6 +16,6 @@ for s,e in iv[1:]:
 busy+=cur_e-cur_s
 print(f"# wall {(half[-1][2]-t0)/1e3:.1f} us, union busy {busy/1e3:.1f} us, sum {sum(r[2]-r[1] for r in half)/1e3:.1f}")
 for name, s, e, gx, gy, gz, q in half:
-    nm = re.sub(r"^void ", "", name).replace("dgsct::", ""); nm = re.sub(r"\(.*", "", nm)
+    nm = re.sub(r"^void ", "", name).replace("dgsct::", "").replace("(anonymous namespace)::", ""); nm = re.sub(r"\(.*", "", nm)
     gap = (s-prev_end.get(q,s))/1e3; prev_end[q]=e
     print(f"{(s-t0)/1e3:9.1f} +{(e-s)/1e3:7.1f} us gap{gap:7.1f} q={q} grid=({gx//256 if gx>=256 else gx},{gy},{gz}) {nm[:50]}")
