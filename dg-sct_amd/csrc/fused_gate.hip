@@ -801,11 +801,15 @@ int gatefuse_mode(int set) {
   return old;
 }
 
-bool gate_fused_supported(int mode, int N, int C, int ds, int g) {
-  if (!gatefuse_mode(-1) || mode != DT_BF16) return false;
+static bool gate_shape_ok(int mode, int N, int C, int ds, int g) {
+  if (mode != DT_BF16) return false;
   if (!(C == 96 || C == 128 || C == 192 || C == 256)) return false;
   if (N % 32 || N < 32 || g < 1 || ds < 4 || ds > 32 || ds % 4 || ds % g || C % g) return false;
   return true;
+}
+bool gate_fused_supported(int mode, int N, int C, int ds, int g) { return gatefuse_mode(-1) && gate_shape_ok(mode, N, C, ds, g); }
+bool gate_bwd_fused_shape(int mode, int N, int C, int ds, int g) {
+  return gate_shape_ok(mode, N, C, ds, g) && (C == 96 || C == 128) && ds == C / 8;
 }
 
 void gatemod_fwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq2, const float* Wv2, const float* bv2, const float* ws,
@@ -835,7 +839,7 @@ void gatemod_fwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq
 
 
 bool gate_bwd_fused_supported(int mode, int N, int C, int ds, int g) {
-  return gate_fused_supported(mode, N, C, ds, g) && (C == 96 || C == 128) && ds == C / 8;
+  return gatefuse_mode(-1) && gate_bwd_fused_shape(mode, N, C, ds, g);
 }
 
 long gate_bwd_part_floats(int B, int C) { return (long)(1024 + B) * (2 * C + C / 2 + 1); }

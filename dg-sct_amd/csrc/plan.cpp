@@ -49,6 +49,7 @@ Plan::Plan(const dgsct_adapter_desc& d_, bool record_regions) : record_regions_(
     orderA = a <= b;
   }
   ok = validate();
+  if (ok) xc_scratch = !fp8 && gate_bwd_fused_shape(E, N, C, ds, g);
   if (ok) layout();
 }
 
@@ -136,7 +137,7 @@ void Plan::layout() {
     s.m1 = a.take("m1", (int64_t)B * C * es);
     s.q = a.take("q", (int64_t)B * dd * es);
     s.ch = a.take("ch", (int64_t)B * C * 4);
-    s.Xc = a.take("Xc", R * C * es);
+    s.Xc = xc_scratch ? -1 : a.take("Xc", R * C * es);
     s.vq2 = a.take("vq2", R * dd * es);
     s.sl = a.take("sl", R * 4);
     s.sg = a.take("sg", R * 4);
@@ -158,6 +159,7 @@ void Plan::layout() {
   {
     Arena a;
     wf.tokscr = a.take("tokscr", tokattn_scratch_floats(B, N, C) * 4);
+    wf.Xc = xc_scratch ? a.take("Xc", R * C * es) : -1;       // (only the unfused test path of these shapes writes it)
     ws_fwd_bytes = a.off;
   }
   // ---- backward scratch
@@ -177,6 +179,7 @@ void Plan::layout() {
     wb.dX3 = a.take("dX3", R * C * es);
     wb.dX1 = a.take("dX1", R * C * es);
     wb.dXc = a.take("dXc", R * C * es);
+    wb.Xc = xc_scratch ? a.take("Xc", R * C * es) : -1;
     wb.dsg = a.take("dsg", R * 4);
     wb.dsl = a.take("dsl", R * 4);
     wb.tmpBd = a.take("tmpBd", (int64_t)B * dd * 4);
@@ -408,7 +411,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   if (gfuse) {
     // (with the fused backward nothing downstream reads Xc or vq2: it recomputes both from X1)
     const bool bfuse = gate_bwd_fused_supported(ctx.mode, N, C, ds, g);
-    if (!bfuse) scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);     // Xc = X1 * (1 + ch): backward's dWv2 operand
+    if (!bfuse && !xc_scratch) scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);   // Xc = X1 * (1 + ch): backward's dWv2 operand
     gatemod_fwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S(s.aq2), b.F(DGSCT_P_WV2), b.F(DGSCT_P_BV2), b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
                 d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta, d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr,
                 d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C, ds, g, b.F(DGSCT_P_WD), b.S<float>(s.sl), b.S(s.X3),
@@ -416,11 +419,12 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
                 (!bfuse || gatefuse_mode(-1) == 2) ? b.S(s.vq2) : nullptr);
     spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map), map);   // saved copy + the returned map
   } else {
-    scale_cols(ctx, b.S(s.X1), b.S(s.Xc), B, N, C, b.S<float>(s.ch), 1.f);        // Xc = X1 * (1 + ch)
+    void* Xcf = xc_scratch ? b.Wk(wf.Xc) : b.S(s.Xc);
+    scale_cols(ctx, b.S(s.X1), Xcf, B, N, C, b.S<float>(s.ch), 1.f);              // Xc = X1 * (1 + ch)
     Gemm g1 = mk((int)R, dd, C);                                 // vq2 = relu(Xc Wv2^T + b)
-    g1.A = km(b.S(s.Xc), C); g1.B = km(b.W(DGSCT_P_WV2), C); g1.bias_n = b.F(DGSCT_P_BV2); g1.act = ACT_RELU;
+    g1.A = km(Xcf, C); g1.B = km(b.W(DGSCT_P_WV2), C); g1.bias_n = b.F(DGSCT_P_BV2); g1.act = ACT_RELU;
     outE(g1, b.S(s.vq2), E, dd);
-    if (fp8) gemm_fp8(ctx, (int)R, dd, C, b.S(s.Xc), C, b.prep + prep_w8[2], (const float*)(b.prep + prep_w8scale) + 2, b.F(DGSCT_P_BV2), 1, b.S(s.vq2), dd);
+    if (fp8) gemm_fp8(ctx, (int)R, dd, C, Xcf, C, b.prep + prep_w8[2], (const float*)(b.prep + prep_w8scale) + 2, b.F(DGSCT_P_BV2), 1, b.S(s.vq2), dd);
     else gemm(ctx, g1);
     rowdot_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.S(s.aq2), E, dd, b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
                    b.S<float>(s.sl));
@@ -559,7 +563,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   atomic_out(gwd);
   Gemm gwv2 = mk(dd, C, (int)R);                                 // dWv2 = dvq2^T . Xc
   gwv2.A = mn(b.S(s.vq2), dd);
-  gwv2.B = mn(b.S(s.Xc), C);
+  void* Xcb = xc_scratch ? b.Wk(wb.Xc) : b.S(s.Xc);
+  gwv2.B = mn(Xcb, C);
   outF(gwv2, G(DGSCT_P_WV2), C);
   atomic_out(gwv2);
   if (bfuse) {
@@ -567,7 +572,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     gatemod_bwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S(s.aq2), b.F(DGSCT_P_WV2), b.F(DGSCT_P_BV2), b.F(DGSCT_P_WS), tg, d.alpha, d.beta,
                 d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S<float>(s.sl),
                 b.S<float>(s.sg), b.S<float>(s.map), dMap, B, N, C, ds, g, b.F(DGSCT_P_WD), dZ, b.S(s.Zp), bn1, bn1 + ds, bn1 + 2 * ds,
-                bn1 + 3 * ds, d.use_bn ? G(DGSCT_P_BN1_B) : nullptr, d.use_bn, d.training, dX1, b.S(s.vq2), b.S(s.Xc),
+                bn1 + 3 * ds, d.use_bn ? G(DGSCT_P_BN1_B) : nullptr, d.use_bn, d.training, dX1, b.S(s.vq2), Xcb,
                 b.Wk<float>(wb.dch), b.Wk<float>(wb.u), b.Wk<float>(wb.dtg), G(DGSCT_P_LNB_W), G(DGSCT_P_LNB_B), G(DGSCT_P_BV2),
                 G(DGSCT_P_BS), b.Wk<float>(wb.rowtmp), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
     defer([=, &side] { gemm(side, gwd); });
@@ -577,6 +582,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     ew2(ctx, EwCall{EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1},
         EwCall{EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd});
   } else {
+  if (xc_scratch) scale_cols(ctx, b.S(s.X1), Xcb, B, N, C, b.S<float>(s.ch), 1.f);   // (unfused test path of a fused shape: Xc is not saved)
   if (d.use_bn) {
     bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, G(DGSCT_P_BN1_B), 1, 1, d.training);
   } else {
@@ -782,12 +788,14 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       gemm(ctx, g3);
     }
     // both bias-side reductions of dYp in one pass (they were rowdot -> sum_batch and colsum: two more reads of the cotangent)
+    // (round 4: frame by frame -- contiguous rows -- with the per-frame row dots summed by a second small launch: 150 -> ~45 us
+    //  at 655 360 x 96)
     if (conv)                                                    // dbn[n] = sum dYp . colb;  d rowsum(Wc)[c] = sum rowb[n] dYp
-      rowdot_colsum(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), b.rowb(), G(DGSCT_P_BN), b.Wk<float>(wb.dwcsum),
-                    b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+      rowdot_colsum_frames(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), b.rowb(), G(DGSCT_P_BN), b.Wk<float>(wb.dwcsum),
+                           b.Wk<float>(wb.rowtmp), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
     else
-      rowdot_colsum(ctx, dYp, C, (long)N * C, B, N, C, nullptr, b.rowb(), nullptr, G(DGSCT_P_BC), b.Wk<float>(wb.rowpart),
-                    row_part_floats(B, C));
+      rowdot_colsum_frames(ctx, dYp, C, (long)N * C, B, N, C, nullptr, b.rowb(), nullptr, G(DGSCT_P_BC), b.Wk<float>(wb.rowtmp),
+                           b.Wk<float>(wb.rowpart), row_part_floats(B, C));
   }
   side_flush();
   stream_join(ctx);

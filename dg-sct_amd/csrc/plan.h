@@ -19,6 +19,7 @@ struct Plan {
   int64_t es, R;
   bool fp8 = false;   // DGSCT_BF16_FP8: fp8 operands for fc / fc_affine_video_1 / fc_affine_video_2 (forward)
   int64_t prep_w8[3] = {-1, -1, -1}, prep_w8scale = -1;   // fp8 copies of Wc, Wv1, Wv2 + their 3 inverse scales (+ 1 scratch word)
+  bool xc_scratch = false;   // Xc = X1 (1 + ch) is scratch (the fused gate backward writes it), not a saved activation
   bool orderA;   // remap association: (Wn.Y).Wc^T (A) or Wn.(Y.Wc^T) (B), whichever is cheaper
 
   // prep
@@ -32,10 +33,10 @@ struct Plan {
   std::vector<Region> saved_regions;
   int64_t saved_bytes;
   // forward / backward scratch
-  struct { int64_t tokscr; } wf;
+  struct { int64_t tokscr, Xc; } wf;
   struct {
     int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, dtokF, dT0b, zero_end;
-    int64_t dO, dZ, dX3, dX1, dXc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart;
+    int64_t dO, dZ, dX3, dX1, dXc, Xc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart;
   } wb;
   int64_t ws_fwd_bytes, ws_bwd_bytes;
   // gradients

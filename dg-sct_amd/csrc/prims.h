@@ -98,6 +98,9 @@ void rowdot_batched(const Ctx&, const void* x, long ld, long bs, int B, int N, i
 // part / part_floats: optional scratch (>= row_part_floats(B, C)) for the per-workgroup partial column sums.
 void rowdot_colsum(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const float* w, const float* roww,
                    float* out_row, float* out_col, float* part = nullptr, long part_floats = 0);
+// Same reductions, frames walked one at a time (contiguous rows); row_part: B*N floats of scratch for the per-frame row dots.
+void rowdot_colsum_frames(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const float* w, const float* roww,
+                          float* out_row, float* out_col, float* row_part, float* part = nullptr, long part_floats = 0);
 // out[i] = (accumulate ? out[i] : 0) + scale * sum_b in[b*bs + i]
 void sum_batch(const Ctx&, const float* in, long bs, int B, long n, float* out, float scale, int accumulate);
 // y[b][n][c] = x[b][n][c] * (add + colw[b][c])         x,y are E (may alias)
@@ -169,6 +172,8 @@ void gatemod_fwd(const Ctx&, const void* X1, const float* ch, const void* aq2, c
 //        dch [B][C] +=, u [B][C/2] += sum_n dsl vq2, dtg [B] += (tg != null), dlnw / dlnb [C] += (lnw != null), dbv2 [C/2] +=, *dbs +=
 //   mapdot_scratch: B floats; part: gate_bwd_part_floats(B, C) floats of scratch.
 bool gate_bwd_fused_supported(int mode, int N, int C, int ds, int g);
+// the same test without the tuning switch: what the buffer LAYOUT keys on (Xc is scratch, not a saved activation, for these shapes)
+bool gate_bwd_fused_shape(int mode, int N, int C, int ds, int g);
 long gate_bwd_part_floats(int B, int C);
 void gatemod_bwd(const Ctx&, const void* X1, const float* ch, const void* aq2, const float* Wv2, const float* bv2, const float* ws,
                  const float* tg, float alpha, float beta, float gamma, const float* lnw, const float* mu, const float* rstd,

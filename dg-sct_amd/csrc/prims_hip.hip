@@ -848,6 +848,90 @@ __global__ __launch_bounds__(256) void rowdot_colsum_k(const void* x, long ld, l
   if (out_col) flush_cols<1, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst, part);
 }
 
+// Frame-contiguous variant (round 4): a workgroup walks consecutive rows of ONE frame (the rows of a frame are contiguous in memory;
+// the kernel above strides FPG frames 0.8 MB apart per row and ran at 0.84 TB/s), FU rows of a lane group in flight.  The row dots
+// leave as plain stores into row_part[b][n] and are summed over the frames by sum_batch; the column sums as above.
+template <int DT, int VE, int MAXNV>
+__global__ __launch_bounds__(256) void rowdot_colsum_fr_k(const void* x, long ld, long bs, int N, int C, const float* w,
+                                                          const float* roww, int gs, int nv, int rpc, float* row_part,
+                                                          float* out_col, float* part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
+  const int b = blockIdx.y;
+  const int n_end = imin_d(N, (blockIdx.x + 1) * rpc);
+  float ww[MAXNV][VE], acc[1][MAXNV][VE];
+#pragma unroll
+  for (int v = 0; v < MAXNV; ++v) {
+    const int col = (v * gs + gl) * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { ww[v][e] = 0.f; acc[0][v][e] = 0.f; }
+    if (w && v < nv && col < C) ldv<DT_F32, VE>(w, col, ww[v]);
+  }
+  constexpr int FU = 4;
+  const char* xb = reinterpret_cast<const char*>(x) + (long)b * bs * El<DT>::ES;
+  for (int n = blockIdx.x * rpc + sub; n < n_end; n += rpp * FU) {
+    uint4 raw[FU][MAXNV];
+    float rw[FU];
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+      const int nc = n + u * rpp < n_end ? n + u * rpp : n_end - 1;      // unconditional, clamped loads; masked below
+      rw[u] = roww ? roww[nc] : 1.f;
+#pragma unroll
+      for (int v = 0; v < MAXNV; ++v) {
+        const int col = (v * gs + gl) * VE;
+        raw[u][v] = ldraw<DT, VE>(xb, (long)nc * ld + ((v < nv && col < C) ? col : 0));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+      const bool ok = n + u * rpp < n_end;
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < MAXNV; ++v) {
+        const int col = (v * gs + gl) * VE;
+        const float mv = (ok && v < nv && col < C) ? 1.f : 0.f;
+        float t[VE];
+        unpack<DT, VE>(raw[u][v], t);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          s += mv * t[e] * ww[v][e];
+          acc[0][v][e] += mv * rw[u] * t[e];
+        }
+      }
+      if (row_part) {
+        s = group_sum(s, gs);
+        if (gl == 0 && ok) row_part[(long)b * N + n + u * rpp] = s;
+      }
+    }
+  }
+  float* const dst[1] = {out_col};
+  if (out_col) flush_cols<1, VE, MAXNV>(acc, lds, C, gs, nv, gl, dst, part);
+}
+
+void rowdot_colsum_frames(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const float* w, const float* roww,
+                          float* out_row, float* out_col, float* row_part, float* part, long part_floats) {
+  int ve = row_ve(ctx, C);
+  if (ld % ve != 0 || bs % ve != 0) { set_error("rowdot_colsum: unaligned ld/bs"); return; }
+  if (!out_row && !out_col) return;
+  RowGeom g = row_geom(C, ve, N, B);
+  const size_t sh = (size_t)(256 / g.gs) * C * sizeof(float);
+  {
+    int cap = 2048;
+    ROW_CAPACITY(cap, ctx, C, g.nv, rowdot_colsum_fr_k, sh);
+    g = row_geom(C, ve, N, B, cap, 4, true);
+  }
+  static const int use_part = env_int("DGSCT_ROW_PART", 1);
+  if (!use_part || !out_col || (long)g.chunks * B * C > part_floats) part = nullptr;
+  ROW_DISPATCH_SH(ctx, C, g.nv, rowdot_colsum_fr_k, dim3(g.chunks, B), sh, x, ld, bs, N, C, w, roww, g.gs, g.nv, g.rpc,
+                  out_row ? row_part : nullptr, out_col, part);
+  if (out_row) sum_batch(ctx, row_part, N, B, N, out_row, 1.f, 1);
+  if (part) {
+    PartTable t; t.NQ = 1; t.C = C;
+    t.d[0] = PartDesc{0, 1, g.chunks * B, 1, out_col, 0, 1.f};
+    part_reduce(ctx.stream, part, t, 1);
+  }
+}
+
 void rowdot_colsum(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const float* w, const float* roww,
                    float* out_row, float* out_col, float* part, long part_floats) {
   int ve = row_ve(ctx, C);

@@ -175,6 +175,10 @@ void rowdot_colsum(const Ctx& ctx, const void* x, long ldx, long bs, int B, int 
       out_col[c] += (float)s;
     }
 }
+void rowdot_colsum_frames(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const float* w, const float* roww,
+                          float* out_row, float* out_col, float*, float*, long) {
+  rowdot_colsum(ctx, x, ld, bs, B, N, C, w, roww, out_row, out_col);
+}
 
 void sum_batch(const Ctx&, const float* in, long bs, int B, long n, float* out, float scale, int accumulate) {
   for (long i = 0; i < n; ++i) {
@@ -398,6 +402,7 @@ void gatemod_fwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq
   if (stats) bn_stats(ctx, Zp, (long)B * N, ds, stats);
 }
 
+bool gate_bwd_fused_shape(int, int, int, int ds, int g) { return ds % g == 0; }
 bool gate_bwd_fused_supported(int mode, int N, int C, int ds, int g) { return gate_fused_supported(mode, N, C, ds, g); }
 long gate_bwd_part_floats(int, int) { return 0; }
 // composition of the host primitives the device kernel replaces (same order as the unfused schedule)

@@ -32,8 +32,14 @@ class Q:
     def __call__(self, name, x):
         if name in self.names or '*' in self.names and ('-'+name) not in self.names: return x.bfloat16().float()
         return x
-def run(cfg,p,X,Y,dOut,dMap,q):
+def run(cfg,p,X,Y,dOut,dMap,q,masks=None):
     B,N,C = X.shape; R=B*N
+    used = {}
+    def M(name, x):            # the ReLU decision of `name`: this run's own, or a pinned one (masks=...)
+        m = masks[name] if masks is not None else (x > 0)
+        used[name] = m
+        return m
+    relu = lambda name, x: x * M(name, x)
     W = lambda n: q('W:'+n.replace('fc_affine_','').replace('.weight',''), p[n])    # bf16 weight copies
     Wc,bc = p['fc.weight'],p['fc.bias']; Wn = p['conv_adapter.weight'].reshape(N,cfg.No); bn = p['conv_adapter.bias']
     rowb,colb,colb2 = bn, Wc.sum(1), bc
@@ -53,14 +59,14 @@ def run(cfg,p,X,Y,dOut,dMap,q):
     gav = p['gate_av']
     X1full = X + gav*(q('P2m',torch.softmax(S2,-1)) @ q('tokV',tok)); X1 = q('X1', X + gav*(P2 @ q('tokV',tok))); X1m = q('X1m', X1full)
     aE = q('aE',a)
-    aq1 = q('aq', F.relu(F.linear(aE, W('fc_affine_audio_1.weight'), p['fc_affine_audio_1.bias'])))
-    aq2 = q('aq', F.relu(F.linear(aE, W('fc_affine_audio_2.weight'), p['fc_affine_audio_2.bias'])))
-    vq1 = q('vq1', F.relu(F.linear(X1, W('fc_affine_video_1.weight'), p['fc_affine_video_1.bias'])))
+    aq1 = q('aq', relu('aq1', F.linear(aE, W('fc_affine_audio_1.weight'), p['fc_affine_audio_1.bias'])))
+    aq2 = q('aq', relu('aq2', F.linear(aE, W('fc_affine_audio_2.weight'), p['fc_affine_audio_2.bias'])))
+    vq1 = q('vq1', relu('vq1', F.linear(X1, W('fc_affine_video_1.weight'), p['fc_affine_video_1.bias'])))
     mvq1 = vq1.mean(1); m1 = q('m1', aq1*mvq1)
-    qq = q('q', F.relu(F.linear(m1, W('fc_affine_bottleneck.weight'), p['fc_affine_bottleneck.bias'])))
+    qq = q('q', relu('q', F.linear(m1, W('fc_affine_bottleneck.weight'), p['fc_affine_bottleneck.bias'])))
     ch = torch.sigmoid(F.linear(qq, W('fc_affine_v_c_att.weight'), p['fc_affine_v_c_att.bias']))
     Xc = q('Xc', X1*(1+ch[:,None,:]))
-    vq2 = q('vq2', F.relu(F.linear(Xc, W('fc_affine_video_2.weight'), p['fc_affine_video_2.bias'])))
+    vq2 = q('vq2', relu('vq2', F.linear(Xc, W('fc_affine_video_2.weight'), p['fc_affine_video_2.bias'])))
     ws,bs = p['fc_affine_v_s_att.weight'].reshape(-1), p['fc_affine_v_s_att.bias']
     sl = (vq2*(aq2*ws)[:,None,:]).sum(-1)+bs; sg = torch.sigmoid(sl); amap = torch.softmax(torch.tanh(sl),-1)
     mod = cfg.alpha*ch[:,None,:] + cfg.beta*sg[:,:,None] + (1-cfg.alpha)
@@ -71,7 +77,7 @@ def run(cfg,p,X,Y,dOut,dMap,q):
     def bn_(x,name):
         w,b = p[name+'.weight'],p[name+'.bias']; xf=x.reshape(R,-1); mu=xf.mean(0); var=((xf-mu)**2).mean(0); rstd=torch.rsqrt(var+cfg.eps); xh=(x-mu)*rstd
         return xh*w+b, xh, rstd
-    Zb,zh,rstd1 = bn_(Zp,'bn1'); Z = q('Z',F.relu(Zb))
+    Zb,zh,rstd1 = bn_(Zp,'bn1'); Z = q('Z',relu('Z', Zb))
     Op = q('Op', O._groupmm(Z, q('W:Wu',Wu), cfg.g))
     Oo,oh,rstd2 = bn_(Op,'bn2')
     L,xh_p,rstd_p = O._ln(Oo, p['ln_post.weight'], p['ln_post.bias'], cfg.eps)
@@ -86,7 +92,7 @@ def run(cfg,p,X,Y,dOut,dMap,q):
         return w*rstd*(dy-db/R-xh*(dw/R))
     dOp = q('dO', bn_bwd(dO,oh,rstd2,'bn2'))
     dZ,dWu = O._groupmm_bwd(dOp,Z,q('W:Wu',Wu),cfg.g); g['up_sampler.weight']=dWu.reshape(p['up_sampler.weight'].shape); dZ=q('dZ',dZ)
-    dZb = dZ*(Z>0); dZp = q('dZ', bn_bwd(dZb,zh,rstd1,'bn1'))
+    dZb = dZ*used['Z']; dZp = q('dZ', bn_bwd(dZb,zh,rstd1,'bn1'))
     dX3,dWd = O._groupmm_bwd(dZp,X3,q('W:Wd',Wd),cfg.g); g['down_sampler.weight']=dWd.reshape(p['down_sampler.weight'].shape); dX3=q('dX3',dX3)
     dX2,g['ln_before.weight'],g['ln_before.bias'] = O._ln_bwd(dX3,xh_b,rstd_b,p['ln_before.weight'])
     dX1 = q('dX1', dX2*mod); dmod = dX2*X1m
@@ -94,19 +100,19 @@ def run(cfg,p,X,Y,dOut,dMap,q):
     dsl = dsg*sg*(1-sg); dt = amap*(dMap-(amap*dMap).sum(-1,keepdim=True)); dsl = dsl + dt*(1-torch.tanh(sl)**2)
     u = (dsl[:,:,None]*vq2).sum(1); g['fc_affine_v_s_att.bias']=dsl.sum().reshape(1); g['fc_affine_v_s_att.weight']=(u*aq2).sum(0)
     daq2 = u*ws
-    dvq2 = q('dvq2', dsl[:,:,None]*(aq2*ws)[:,None,:]*(vq2>0))
+    dvq2 = q('dvq2', dsl[:,:,None]*(aq2*ws)[:,None,:]*used['vq2'])
     dXc = q('dXc', dvq2 @ W('fc_affine_video_2.weight'))
     g['fc_affine_video_2.weight'] = dvq2.reshape(R,-1).t() @ Xc.reshape(R,C); g['fc_affine_video_2.bias']=dvq2.reshape(R,-1).sum(0)
     dX1 = q('dX1', dX1 + dXc*(1+ch[:,None,:])); dch = dch + (dXc*X1).sum(1)
     dpre_c = q('dpre', dch*ch*(1-ch))
     g['fc_affine_v_c_att.weight']=dpre_c.t()@qq; g['fc_affine_v_c_att.bias']=dpre_c.sum(0)
-    dq = q('dpre', (dpre_c @ W('fc_affine_v_c_att.weight'))*(qq>0))
+    dq = q('dpre', (dpre_c @ W('fc_affine_v_c_att.weight'))*used['q'])
     g['fc_affine_bottleneck.weight']=dq.t()@m1; g['fc_affine_bottleneck.bias']=dq.sum(0)
     dm1 = dq @ W('fc_affine_bottleneck.weight'); daq1 = dm1*mvq1; dmvq1 = dm1*aq1
-    dvq1 = q('dvq1', (dmvq1/N)[:,None,:]*(vq1>0))
+    dvq1 = q('dvq1', (dmvq1/N)[:,None,:]*used['vq1'])
     dX1 = q('dX1', dX1 + dvq1 @ W('fc_affine_video_1.weight'))
     g['fc_affine_video_1.weight']=dvq1.reshape(R,C).t()@X1.reshape(R,C); g['fc_affine_video_1.bias']=dvq1.reshape(R,C).sum(0)
-    dpa1 = q('dpre', daq1*(aq1>0)); dpa2 = q('dpre', daq2*(aq2>0))
+    dpa1 = q('dpre', daq1*used['aq1']); dpa2 = q('dpre', daq2*used['aq2'])
     g['fc_affine_audio_1.weight']=dpa1.t()@aE; g['fc_affine_audio_1.bias']=dpa1.sum(0); g['fc_affine_audio_2.weight']=dpa2.t()@aE; g['fc_affine_audio_2.bias']=dpa2.sum(0)
     da = dpa1 @ W('fc_affine_audio_1.weight') + dpa2 @ W('fc_affine_audio_2.weight')
     U = dX1 @ q('tokS',tok).transpose(1,2)
@@ -126,7 +132,7 @@ def run(cfg,p,X,Y,dOut,dMap,q):
     else:
         dT2t = q('dT', torch.einsum('bmc,mn->bcn',dYp,q('W:Wn',Wn))); dWn = torch.einsum('bmc,bcn->mn',dYp,T2t); dY = torch.einsum('bcn,ck->bnk',dT2t,q('W:Wc',Wc)); dWc = torch.einsum('bcn,bnk->ck',dT2t,Y)
     g['fc.weight']=dWc+dwcsum[:,None]; g['conv_adapter.weight']=dWn
-    return dict(out=out,map=amap,dX=dX,dY=q('dY',dY),g=g)
+    return dict(out=out,map=amap,dX=dX,dY=q('dY',dY),g=g,masks=used)
 def l2(a,b): return ((a-b).norm()/b.norm().clamp_min(1e-30)).item()
 def report(tag, r, ref):
     gs = sorted(((l2(r['g'][k].reshape(-1), ref['g'][k].reshape(-1)),k) for k in ref['g'] if k not in('ln_before.bias',)), reverse=True)
@@ -134,7 +140,32 @@ def report(tag, r, ref):
 
 
 
+def pinned_table(shape):
+    """would computing the two un-scaled softmax logits from an UN-ROUNDED Yp take the C-linear term out of the
+    bf16 backward?  Each scenario rounds a subset of tensors; the reference is the fp32 evaluation differentiated on the
+    scenario's own ReLU decisions (masks pinned, as tests/test_bf16_masked_gpu.py does), so what is left is rounding, not flips."""
+    args = mk(*shape)
+    WS = ['W:Wn','W:Wc','W:Wd','W:Wu','W:audio_1','W:audio_2','W:video_1','W:video_2','W:bottleneck','W:v_c_att']
+    remap = ['W:Wn','W:Wc','T']
+    scen = [("only Yp rounded", Q(['Yp'])), ("only the remap operands (Wn, Wc, T) rounded", Q(remap)),
+            ("Yp + remap operands", Q(['Yp'] + remap)),
+            ("everything the bf16 schedule rounds", Q(['*','-tok','-tokS','-tokV','-T0','-X1m','-P2m'])),
+            ("  ... but Yp kept in fp32", Q(['*','-tok','-tokS','-tokV','-T0','-X1m','-P2m','-Yp'])),
+            ("  ... but Yp AND the remap operands in fp32", Q(['*','-tok','-tokS','-tokV','-T0','-X1m','-P2m','-Yp','-W:Wn','-W:Wc','-T'])),
+            ("  ... but only the remap operands in fp32 (Yp rounded)", Q(['*','-tok','-tokS','-tokV','-T0','-X1m','-P2m','-W:Wn','-W:Wc','-T']))]
+    print(f"shape (N,C,No,Co) = {shape}; rel-L2 against the fp32 evaluation on the scenario's own ReLU masks")
+    for tag, q in scen:
+        r = run(*args, q)
+        ref = run(*args, Q([]), masks=r['masks'])
+        gk = ['conv_adapter.weight','fc.weight','my_tokens']
+        print(f"{tag:58s} dX {l2(r['dX'],ref['dX']):.4f}  dY {l2(r['dY'],ref['dY']):.4f}  " + ' '.join(f"{k}:{l2(r['g'][k].reshape(-1),ref['g'][k].reshape(-1)):.4f}" for k in gk))
+
+
 if __name__=='__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'pinned':
+        for shp in ([tuple(int(x) for x in a.split(',')) for a in sys.argv[2:]] or [(144,512,256,384),(36,1024,64,768)]):
+            pinned_table(shp)
+        sys.exit(0)
     shape = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv)>1 else (144,512,256,384)
     args = mk(*shape)
     WS = ['W:Wn','W:Wc','W:Wd','W:Wu','W:audio_1','W:audio_2','W:video_1','W:video_2','W:bottleneck','W:v_c_att']
