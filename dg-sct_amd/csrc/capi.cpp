@@ -202,7 +202,8 @@ int dgsct_test_gemm(const dgsct_gemm_args* a, void* stream) {
   if (!a) return 2;
   Ctx ctx{stream, a->mode};
   Gemm g;
-  g.M = a->M; g.N = a->N; g.K = a->K; g.KB = a->KB; g.batch = a->batch; g.splitk = a->splitk; g.atomic = a->atomic;
+  g.M = a->M; g.N = a->N; g.K = a->K; g.KB = a->KB; g.batch = a->batch; g.splitk = a->splitk; g.atomic = a->atomic != 0;
+  g.sole_writer = a->atomic == 2;                      // atomic = 2: D is pre-zeroed and this product is its only writer
   g.A.p = a->A; g.A.ld = a->lda; g.A.kmajor = a->a_kmajor; g.A.bs = a->a_bs; g.A.kbs = a->a_kbs;
   g.B.p = a->B; g.B.ld = a->ldb; g.B.kmajor = a->b_kmajor; g.B.bs = a->b_bs; g.B.kbs = a->b_kbs;
   g.D = a->D; g.ddt = a->ddt; g.ldd = a->ldd; g.dbs = a->dbs;

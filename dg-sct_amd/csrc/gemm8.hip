@@ -38,6 +38,32 @@ typedef __attribute__((ext_vector_type(4))) short g8_s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short g8_s16x8_t;
 typedef __attribute__((ext_vector_type(16))) float g8_f32x16_t;
 
+// Structure experiments of round 4 (compile-time, default = the round-3 kernel: 8 waves, 256-row tiles).  Timings of the remap
+// forward 2304 x (96 x 160) x 4096, K-major x MN-major, alone on the chip (tools/gemm_bench.py BIG=1, DGSCT_GEMM8_DBG switches):
+//                                             whole kernel   no DMA in the loop   DMA + barriers only   MFMAs + barriers only
+//   8 waves, 256 x 192 (64 x 96 per wave)        331 us           268 us               154 us                 196 us
+//   4 waves, 256 x 192 (128 x 96 per wave,
+//     accumulators in AGPRs, 0.58 KB of
+//     fragment reads per MFMA instead of 0.83)   347              274                  174
+//   4 waves, 128 x 192, TWO workgroups per CU
+//     (80 KB of LDS each, independent barriers)  356              267                  184
+// i.e. neither fewer fragment reads nor de-synchronised workgroups move it, and the operand DMA alone is half the kernel: the
+// round-3 "per-CU delivery ceiling" reading was wrong (DMA only = 154 us), and so is "barrier lock-step".  What the three share
+// is the MFMA stream itself; with operands that never change (the no-read runs) it finishes in 196 us, with real data the
+// clock drops (MI355X_MICROARCH.md: 2.29 -> 1.87 GHz under bf16 MFMA load on random operands), so part of the 268 is DVFS.
+#ifndef G8_WAVES
+#define G8_WAVES 8
+#endif
+constexpr int G8_NW = G8_WAVES;
+constexpr int G8_NT = G8_NW * 64;
+// rows of the workgroup tile.  128 (with 4 waves of 64 x BN/2): 2 x (128 + 192) x 128 B = 80 KB of LDS per workgroup, so TWO
+// independent workgroups share a CU and fill each other's barrier / LDS-latency bubbles (one 8-wave workgroup runs its two waves
+// per SIMD in lock-step through the same barriers); the price is 1.43 x the operand DMA per FLOP.
+#ifndef G8_BM
+#define G8_BM 256
+#endif
+constexpr int G8_ROWS = G8_BM;
+
 struct G8 {
   int M, Ntot, Nsub; unsigned ninv;       // column n -> (frame n / Nsub, n % Nsub); ninv = ceil(2^32 / Nsub)
   int K, kflat; unsigned kinv;            // flat contraction index kf -> (kf / K, kf % K); kinv = ceil(2^32 / K), 0: one level
@@ -47,22 +73,23 @@ struct G8 {
   char* D; int ddt; long ldd, dbs; int atomic;
   const float* r1_m; const float* r1_n; const float* bias_n;
   int gm;                                 // m-tiles per group of the work list (tile order, see the kernel)
+  int dbg;                                // DGSCT_GEMM8_DBG (timing experiments only, results are garbage): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMA
 };
 
 template <bool KM, int ROWS>
 struct G8Geom {
   static constexpr int CPR = KM ? 8 : ROWS / 8;          // 16-byte chunks per LDS row
   static constexpr int NSLOT = ROWS * 8;
-  static constexpr int NI = NSLOT / 512;                 // DMA instructions per thread and k-tile
+  static constexpr int NI = NSLOT / G8_NT;               // DMA instructions per thread and k-tile
   static constexpr int BYTES = NSLOT * 16;
-  static_assert(NSLOT % 512 == 0, "tile must be a whole number of 8-wave DMA rounds");
-  static_assert(KM || ROWS == 192 || ROWS == 256, "MN-major swizzle is worked out for 192- and 256-row tiles");
+  static_assert(NSLOT % G8_NT == 0, "tile must be a whole number of workgroup-wide DMA rounds");
+  static_assert(KM || ROWS == 128 || ROWS == 192 || ROWS == 256, "MN-major swizzle is worked out for 128-, 192- and 256-row tiles");
   // MN-major image: a 32-lane group of ds_read_b64_tr_b16 reads 4 consecutive k-rows x 64 contiguous bytes (2 x 16 rows); the four
   // 64-byte pieces must fall on different quarters of the 256-byte bank line.  k-rows are ROWS * 2 bytes apart:
   //   512 B (256 rows): all four on the same quarter -> chunk index ^ 4 (k & 3)          (quarters 0, 1, 2, 3)
   //   384 B (192 rows): quarters 0, 2, 0, 2          -> chunk index ^ 4 ((k >> 1) & 1)   (quarters 0, 2, 1, 3)
   // (the first version XOR-ed 2 (k & 3): that only swaps the two 32-byte halves of a piece -- 28-40 % SQ_LDS_BANK_CONFLICT)
-  static __host__ __device__ constexpr int swz_mn(int k) { return ROWS == 256 ? 4 * (k & 3) : 4 * ((k >> 1) & 1); }
+  static __host__ __device__ constexpr int swz_mn(int k) { return (ROWS == 256 || ROWS == 128) ? 4 * (k & 3) : 4 * ((k >> 1) & 1); }
 };
 
 // one operand tile of one k-tile: global -> LDS.  `BATCHED`: rows are (frame, row-in-frame) pairs, frames bs apart.
@@ -72,7 +99,7 @@ __device__ __forceinline__ void g8_glds(char* lds, const char* base, long ld, lo
   using G = G8Geom<KM, ROWS>;
 #pragma unroll
   for (int j = 0; j < G::NI; ++j) {
-    const int sbase = (j * 8 + wave) * 64;               // wave-uniform slot base: 64 lanes x 16 B = 1 KiB of LDS
+    const int sbase = (j * G8_NW + wave) * 64;               // wave-uniform slot base: 64 lanes x 16 B = 1 KiB of LDS
     const int s = sbase + lane;
     const int q = s / G::CPR, cpos = s % G::CPR;
     int rg, kf;
@@ -161,14 +188,14 @@ __device__ __forceinline__ g8_bf16x8_t g8_frag_km(const char* lds, int row0, int
 template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool AK, bool BK, int BN, bool BATCHED, bool TWO>
-__global__ __launch_bounds__(512, 2)
+__global__ __launch_bounds__(G8_NT, (G8_NW == 8 || G8_ROWS == 128) ? 2 : 1)
 void gemm8_kernel(const G8 p) {
-  constexpr int BM = 256, WGN = 2, TM = 2, TN = BN / 64;
+  constexpr int BM = G8_ROWS, WGN = 2, WGM = G8_NW / WGN, TM = BM / (WGM * 32), TN = BN / 64;
   using GA = G8Geom<AK, BM>;
   using GB = G8Geom<BK, BN>;
   constexpr int STAGE = GA::BYTES + GB::BYTES;
   constexpr int SP = TN * 32 + 4;                           // epilogue staging pitch (floats)
-  constexpr int STG_BYTES = 8 * 32 * SP * 4;
+  constexpr int STG_BYTES = G8_NW * 32 * SP * 4;
   constexpr int SMEM = 2 * STAGE > STG_BYTES ? 2 * STAGE : STG_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];   // ONE LDS object (a second one de-pipelines the DMA waits)
 
@@ -225,6 +252,7 @@ void gemm8_kernel(const G8 p) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) kx[kk] = (unsigned)((((kk * 2 + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) * 16));
 
+  const bool dbg_nodma = p.dbg & 1, dbg_nord = p.dbg & 2, dbg_nomma = p.dbg & 4;
   if (nk > 0) issue(kt_begin, 0);
   if (nk > 1) issue(kt_begin + 1, 1);
   for (int it = 0; it < nk; ++it) {
@@ -251,13 +279,14 @@ void gemm8_kernel(const G8 p) {
       // every fragment read of this buffer has returned (the MFMAs consumed them); once all waves are here it may be refilled
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (it + 2 < nk) issue(kt_begin + it + 2, it & 1);
+      if (it + 2 < nk && !dbg_nodma) issue(kt_begin + it + 2, it & 1);
     } else {
       const unsigned boff = (unsigned)((it & 1) * STAGE);
       G8F<AK> fa[2][TM];
       G8F<BK> fb[2][TN];
       // k-step KK of this tile -> register set KK & 1
       auto rd = [&](auto kkc) {
+        if (dbg_nord) return;
         constexpr int KK = decltype(kkc)::value;
         constexpr int S = KK & 1;
         constexpr int PA = BM * 2, PB = BN * 2;
@@ -280,6 +309,7 @@ void gemm8_kernel(const G8 p) {
         for (int j = 0; j < TN; ++j) g8_tie(fb[S][j]);
       };
       auto mma = [&](int S) {
+        if (dbg_nomma) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -306,7 +336,7 @@ void gemm8_kernel(const G8 p) {
       __builtin_amdgcn_sched_barrier(0);
       landed(1);                                             // last read of this buffer has returned: it may be refilled
       __builtin_amdgcn_s_barrier();
-      if (it + 2 < nk) issue(kt_begin + it + 2, it & 1);     // (address arithmetic + DMA issue interleave with the last MFMAs)
+      if (it + 2 < nk && !dbg_nodma) issue(kt_begin + it + 2, it & 1);     // (address arithmetic + DMA issue interleave with the last MFMAs)
       mma(1);
     }
   }
@@ -386,11 +416,11 @@ template <bool AK, bool BK, int BN> constexpr bool G8_TWO_OK = !(!AK && BK && BN
 
 template <bool AK, bool BK, int BN>
 static void g8_launch_lay(const G8& k, bool batched, bool two, dim3 grid, hipStream_t s) {
-  if (batched)  hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, true, false>), grid, dim3(512), 0, s, k);
+  if (batched)  hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, true, false>), grid, dim3(G8_NT), 0, s, k);
   else if (two) {
-    if constexpr (G8_TWO_OK<AK, BK, BN>) hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, false, true>), grid, dim3(512), 0, s, k);
+    if constexpr (G8_TWO_OK<AK, BK, BN>) hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, false, true>), grid, dim3(G8_NT), 0, s, k);
   }
-  else          hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, false, false>), grid, dim3(512), 0, s, k);
+  else          hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, false, false>), grid, dim3(G8_NT), 0, s, k);
 }
 template <int BN>
 static void g8_launch(const G8& k, int ak, int bk, bool batched, bool two, dim3 grid, hipStream_t s) {
@@ -419,7 +449,7 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
   if ((g.r1_m == nullptr) != (g.r1_n == nullptr)) return false;
   const long kflat = (long)g.K * g.KB;
   if (kflat % 64 || kflat < 1024 || g.K % 8) return false;
-  if (g.M % 256 || g.M < 256) return false;
+  if (g.M % G8_ROWS || g.M < G8_ROWS) return false;
   if (!g8_al16(g.A.p) || !g8_al16(g.B.p) || !g8_al16(g.D) || g.A.ld % 8 || g.B.ld % 8 || g.A.kbs % 8 || g.B.kbs % 8 || g.B.bs % 8) return false;
   if (!g.A.kmajor && g.M % 8) return false;
   if (g.KB > 1 && (unsigned long long)g.K * g.KB * g.K >= 0x100000000ULL) return false;
@@ -436,7 +466,7 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
   if ((g.r1_m || g.bias_n) && g.atomic) return false;
   if (!g.B.kmajor && Ntot % 8) return false;
   // column tile: the one that fills whole rounds of 256 workgroups better (ties: the wider tile)
-  const int tiles_m = g.M / 256;
+  const int tiles_m = g.M / G8_ROWS;
   int BN = 0;
   double best = -1;
   for (int bn : {256, 192}) {
@@ -444,6 +474,8 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
     const long tiles = (long)tiles_m * (Ntot / bn);
     double e = g.atomic ? 1.0 : g8_eff(tiles);                  // split-K fills the rounds itself
     if (bn == 192) e *= 0.97;
+    if (g.atomic && g.sole_writer && !batched)                  // unsplit weight gradient (below): the most tiles that fit one round
+      e = (tiles >= 96 && tiles <= 256) ? 2.0 + (double)tiles / 256.0 : e;
     if (e > best) { best = e; BN = bn; }
   }
   if (!BN) return false;
@@ -452,13 +484,21 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
   const long tiles = (long)tiles_m * tiles_n;
   const int kt_total = (int)(kflat / 64);
   int splitk = 1;
-  if (g.atomic) {
+  bool plain = false;                                           // atomic request served as ONE unsplit pass with plain stores
+  if (g.atomic && g.sole_writer && !batched && tiles >= 96 && tiles <= 256 && kt_total >= 64 && g.ldd % 8 == 0) {
+    // The remap weight gradient dWn (144 / 192 tiles of a 15 360-deep contraction): one workgroup per tile on as many CUs, the whole
+    // contraction in one k-loop, plain fp32 rows out.  Split 7 ways to fill 256 CUs it paid seven 256 x 256 slabs of fp32 atomics
+    // per tile (66 M per launch) and four prologue / epilogue rounds: 420-465 us on every CU; unsplit it holds 144-192 CUs for
+    // 240 k-tiles and leaves the rest to the kernels of the other streams (stage 0 is throughput-bound: CU-time is what counts).
+    plain = true;
+  } else if (g.atomic) {
+
     // Few output tiles = many splits of a handful of k-tiles each: prologue / epilogue bound and 60-way atomics per address.
     // Measured (tools/gemm8_ab_all.sh): 512 x 512 x 23 040 36.7 -> 61 us, 1024 x 1024 x 5 760 35.9 -> 59 us -- the tiled engine keeps them.
     if (mode < 2 && tiles < 96) return false;
     // dWn with both operands K-major (2304 x 4096 x (160 x 96)): 434 vs 443 us alone, 455 vs 515 us inside the step (seven 256 x 256
     // fp32 atomic slabs per tile against the tiled engine's two) -- stays on the tiled engine; the K-major x MN-major one gains 12 %
-    if (mode < 2 && two && g.A.kmajor && g.B.kmajor) return false;
+    if (mode < 2 && two && g.A.kmajor && g.B.kmajor) return false;      // (split: seven atomic slabs against the tiled engine's two)
     // enough splits for >= ~2 full rounds, each walking >= 6 k-tiles; among those the best-filled last round
     int smax = kt_total / 6; if (smax < 1) smax = 1; if (smax > 64) smax = 64;
     double be = -1;
@@ -472,7 +512,7 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
   } else if (mode < 2 && tiles < 160) {
     return false;                                               // too few tiles to fill the chip without split-K
   }
-  if (mode < 2 && tiles * splitk < 128) return false;
+  if (mode < 2 && !plain && tiles * splitk < 128) return false;
   const int kt_per_split = (kt_total + splitk - 1) / splitk;
   splitk = (kt_total + kt_per_split - 1) / kt_per_split;
 
@@ -484,10 +524,12 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
   k.tiles_m = tiles_m; k.tiles_n = tiles_n; k.kt_total = kt_total; k.kt_per_split = kt_per_split;
   k.A = (const char*)g.A.p; k.lda = g.A.ld; k.a_kbs = g.A.kbs;
   k.B = (const char*)g.B.p; k.ldb = g.B.ld; k.b_bs = g.B.bs; k.b_kbs = g.B.kbs;
-  k.D = (char*)g.D; k.ddt = g.ddt; k.ldd = g.ldd; k.dbs = g.dbs; k.atomic = g.atomic;
+  k.D = (char*)g.D; k.ddt = g.ddt; k.ldd = g.ldd; k.dbs = g.dbs; k.atomic = plain ? 0 : g.atomic;
   k.r1_m = g.r1_m; k.r1_n = g.r1_n; k.bias_n = g.bias_n;
   static const int gm_env = getenv("DGSCT_GEMM8_GM") ? atoi(getenv("DGSCT_GEMM8_GM")) : 4;
   k.gm = gm_env < 1 ? 1 : (gm_env > tiles_m ? tiles_m : gm_env);
+  static const int dbg_env = getenv("DGSCT_GEMM8_DBG") ? atoi(getenv("DGSCT_GEMM8_DBG")) : 0;
+  k.dbg = dbg_env;
   dim3 grid((unsigned)tiles, splitk, 1);
   hipStream_t s = (hipStream_t)ctx.stream;
   GemmProfShape shp{g.M, g.N, g.K, g.KB, g.batch, splitk, BN == 256 ? 8 : 9, g.A.kmajor, g.B.kmajor, g.atomic, !g.atomic, 0.0};

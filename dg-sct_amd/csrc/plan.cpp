@@ -752,7 +752,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         g4.A = km(b.Wk(wb.dT), Co, 0, (long)N * Co);
         g4.B = km(Y, Co, 0, (long)No * Co);
         outF(g4, G(DGSCT_P_WN), No);
-        atomic_out(g4);
+        atomic_out(g4); g4.sole_writer = 1;
         defer([=, &side] { gemm(side, g4); });
         side_flush();
       }
@@ -764,7 +764,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         g2.A = km(dYp, C, 0, (long)N * C);
         g2.B = mn(b.S(s.T), Nop, 0, (long)C * Nop);
         outF(g2, G(DGSCT_P_WN), No);
-        atomic_out(g2);
+        atomic_out(g2); g2.sole_writer = 1;
         defer([=, &side] { gemm(side, g2); });
       }
       side_flush();

@@ -61,6 +61,7 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_SOFTMAX = 3, A
 //   atomic ? atomicAdd(D, v) (D fp32, pre-zeroed, used with splitk > 1) : D = v
 struct Gemm {
   int M = 0, N = 0, K = 0, KB = 1, batch = 1, splitk = 1, atomic = 0;
+  int sole_writer = 0;       // with atomic: D is pre-zeroed and nothing else accumulates into it, so an UNSPLIT product may store it plainly
   MatOp A, B;
   void* D = nullptr; int ddt = DT_F32; long ldd = 0, dbs = 0;
   float alpha = 1.f; const float* alpha_ptr = nullptr;

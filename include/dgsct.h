@@ -201,7 +201,9 @@ int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int na
 /* One GEMM of the engine (see csrc/prims.h: struct Gemm).  Plain-C mirror for unit tests. */
 typedef struct dgsct_gemm_args {
   int32_t mode;           /* DGSCT_F32 | DGSCT_BF16 */
-  int32_t M, N, K, KB, batch, splitk, atomic;
+  int32_t M, N, K, KB, batch, splitk, atomic;      /* atomic: 1 = accumulate into D with fp32 atomics (split-K); 2 = the same
+                                                        contract AND D is pre-zeroed with this product as its only writer (an unsplit
+                                                        pass may then store rows plainly) */
   const void* A; int64_t lda; int32_t a_kmajor; int64_t a_bs, a_kbs;
   const void* B; int64_t ldb; int32_t b_kmajor; int64_t b_bs, b_kbs;
   void* D; int32_t ddt; int64_t ldd, dbs;

@@ -48,7 +48,7 @@ def run_case(mode, M, N, K, ak, bk, batch=1, KB=1, shared_a=False, pad=0, epi=No
     if atomic:
         D.zero_()
     a = GemmArgs()
-    a.mode, a.M, a.N, a.K, a.KB, a.batch, a.splitk, a.atomic = mode, M, N, K, KB, batch, splitk, int(atomic)
+    a.mode, a.M, a.N, a.K, a.KB, a.batch, a.splitk, a.atomic = mode, M, N, K, KB, batch, splitk, int(atomic)      # (atomic = 2: sole writer)
     a.A, a.lda, a.a_kmajor, a.a_bs, a.a_kbs = Am.data_ptr(), lda, int(ak), a_bs, a_kbs
     a.B, a.ldb, a.b_kmajor, a.b_bs, a.b_kbs = Bm.data_ptr(), ldb, int(bk), b_bs, b_kbs
     a.D, a.ddt, a.ldd, a.dbs = D.data_ptr(), ddt, ldd, M * ldd
@@ -257,6 +257,26 @@ def test_gemm8_split_k_atomic(gemm8_all, ak, bk):
     run_case(1, 256, 256, 96, ak, bk, batch=1, KB=24, atomic=True, splitk=0)              # dWn: contraction over (frame, channel)
     run_case(1, 512, 192, 2304, ak, bk, batch=1, atomic=True, splitk=0)
     run_case(1, 256, 512, 6400, ak, bk, batch=1, atomic=True, splitk=0)                   # C x C over token rows
+
+
+@pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0)])
+def test_gemm8_unsplit_weight_gradient(ak, bk):
+    """the remap weight gradient dWn at a reduced size but in its production mode (default size gates): >= 96 output tiles of a
+    two-level contraction >= 64 k-tiles deep, D pre-zeroed with the product as its only writer (atomic = 2) -> ONE workgroup per
+    tile, no split, plain fp32 rows instead of seven slabs of atomics"""
+    import csv, os, tempfile
+    lib = default_lib()
+    lib.prof_enable(True)
+    try:
+        path = os.path.join(tempfile.mkdtemp(), "g.csv")
+        os.environ["DGSCT_PROF_DUMP"] = path
+        run_case(1, 2560, 2304, 96, ak, bk, batch=1, KB=48, atomic=2, splitk=0)          # 10 x 12 (192-wide) tiles, 72 k-tiles
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] in ("8", "9") and rows[-1]["splitk"] == "1", rows[-1]
+    finally:
+        os.environ.pop("DGSCT_PROF_DUMP", None)
+        lib.prof_enable(False)
 
 
 def test_gemm8_is_actually_used(gemm8_all):
