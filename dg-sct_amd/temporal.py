@@ -207,26 +207,37 @@ class TemporalAttention(nn.Module):
         self.alpha = 0.1
         self.gamma = 0.1
 
+    def _project(self, vis: torch.Tensor, aud: torch.Tensor):
+        """per-modality input projections (net_trans.py:216-221): audio is a plain Linear, video Linear -> ReLU -> Dropout"""
+        return self.dropout(self.relu(self.v_fc(vis))), self.a_fc(aud)
+
+    def _time_major(self, vis: torch.Tensor, aud: torch.Tensor):
+        """the joint bi-LSTM over the T frames, then [B, T, d] -> [T, B, d] for the attention blocks (:222-226)"""
+        aud_seq, vis_seq = self.audio_visual_rnn_layer(aud, vis)
+        return vis_seq.transpose(0, 1).contiguous(), aud_seq.transpose(0, 1).contiguous()
+
     def forward(self, visual_feature, audio_feature):
         """visual_feature [B, T, video_dim], audio_feature [B, T, audio_dim] ->
-        (video_query_output [T, B, 256], audio_query_output [T, B, 256], audio_visual_gate [T, B, 1])"""
-        audio_feature = self.a_fc(audio_feature)
-        audio_rnn_input = audio_feature
-        visual_feature = self.dropout(self.relu(self.v_fc(visual_feature)))
-        audio_rnn_output1, visual_rnn_output1 = self.audio_visual_rnn_layer(audio_rnn_input, visual_feature)
-        audio_encoder_input1 = audio_rnn_output1.transpose(1, 0).contiguous()
-        visual_encoder_input1 = visual_rnn_output1.transpose(1, 0).contiguous()
-        video_key_value_feature = self.video_encoder(visual_encoder_input1)
-        audio_query_output = self.audio_decoder(audio_encoder_input1, video_key_value_feature)
-        audio_key_value_feature = self.audio_encoder(audio_encoder_input1)
-        video_query_output = self.video_decoder(visual_encoder_input1, audio_key_value_feature)
-        if not video_query_output.is_cuda and self._lib is None:
+        (video_query_output [T, B, 256], audio_query_output [T, B, 256], audio_visual_gate [T, B, 1]).
+
+        Each modality is self-encoded over time (memory) and cross-decoded against the OTHER modality's memory (queries):
+        net_trans.py:228-238; the gates on the two memories and their application (:240-249) are one HIP kernel each way."""
+        vis, aud = self._project(visual_feature, audio_feature)
+        vis_t, aud_t = self._time_major(vis, aud)
+        # call order video-enc, audio-dec, audio-enc, video-dec: in training mode the dropouts inside draw from the RNG
+        # stream in this order, and a seeded run has to match the reference's draw for draw
+        memory, queries = {}, {}
+        memory["video"] = self.video_encoder(vis_t)
+        queries["audio"] = self.audio_decoder(aud_t, memory["video"])
+        memory["audio"] = self.audio_encoder(aud_t)
+        queries["video"] = self.video_decoder(vis_t, memory["audio"])
+        if not queries["video"].is_cuda and self._lib is None:
             raise RuntimeError("dg-sct_amd.TemporalAttention applies its gates with a HIP kernel; there is no CPU path "
                                "(move the module and its inputs to a ROCm device)")
         lib = self._lib or _lib.default_lib()
-        al, vl = self.audio_gated[0], self.video_gated[0]
-        return _TemporalGateFn.apply(lib, self.gamma, audio_key_value_feature, video_key_value_feature, video_query_output,
-                                     audio_query_output, al.weight, al.bias, vl.weight, vl.bias)
+        gate_a, gate_v = self.audio_gated[0], self.video_gated[0]
+        return _TemporalGateFn.apply(lib, self.gamma, memory["audio"], memory["video"], queries["video"], queries["audio"],
+                                     gate_a.weight, gate_a.bias, gate_v.weight, gate_v.bias)
 
 
 # ---- the other two copies of the class (SURVEY.md 8(f) row f1) -----------------------------------------------------------
