@@ -1,6 +1,7 @@
 // extern "C" surface of libdgsct.so (include/dgsct.h).  No exceptions, no torch types, no device
 // allocations: descriptors in, raw device pointers in, status code out.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -72,7 +73,10 @@ int dgsct_adapter_forward_ex(const dgsct_adapter_desc* desc, float* const* param
   }
   Plan p(*desc);
   if (!p.ok) return 2;
-  return p.forward(params, prep, X, Y, out, map, tmap, saved, ws, stream, residual, aux_stream);
+  void* rec = call_prof_begin(stream, 0, desc->N, desc->C);
+  const int rc = p.forward(params, prep, X, Y, out, map, tmap, saved, ws, stream, residual, aux_stream);
+  call_prof_end(rec);
+  return rc;
 }
 
 int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
@@ -92,7 +96,10 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
   }
   Plan p(*desc);
   if (!p.ok) return 2;
-  return p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream, skip_into_dx != 0);
+  void* rec = call_prof_begin(stream, 1, desc->N, desc->C);
+  const int rc = p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream, skip_into_dx != 0);
+  call_prof_end(rec);
+  return rc;
 }
 
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes) {
@@ -253,6 +260,12 @@ int dgsct_test_tune(const char* key, int value) {
   if (key && !strcmp(key, "skinny")) return gemm_skinny_mode(value);
   if (key && !strcmp(key, "rowfuse")) return rowfuse_mode(value);
   if (key && !strcmp(key, "gatefuse")) return gatefuse_mode(value);
+  if (key && !strcmp(key, "bnfold")) return bnfold_mode(value);
+  if (key && !strcmp(key, "skfuse")) return skfuse_mode(value);
+  if (key && !strcmp(key, "callprof")) {
+    if (value == 2) { call_prof_dump(getenv("DGSCT_CALL_PROF") ? getenv("DGSCT_CALL_PROF") : "/tmp/dgsct_callprof.txt"); return 0; }
+    return call_prof_mode(value);
+  }
   return -1;
 }
 

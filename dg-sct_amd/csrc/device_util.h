@@ -222,9 +222,56 @@ __device__ __forceinline__ int imin_d(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ long lmin_d(long a, long b) { return a < b ? a : b; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// scale / shift of the VE BatchNorm channels c0 .. c0 + VE - 1 from the batch sums (bn_finalize_k's arithmetic, see BnFin in prims.h);
+// `owner`: exactly one thread of the launch per channel also stores the four vectors and updates the running statistics.
+// All inputs are fetched as vectors BEFORE anything is stored: channel by channel, the owner's stores (which may alias the inputs as
+// far as the compiler knows) turned the loads of every thread of the launch into VE serial round trips (+20 us per kernel).
+template <int VE>
+__device__ __forceinline__ void bn_fin_vec(const BnFin& f, int C, int c0, bool owner, float (&s)[VE], float (&t)[VE]) {
+  float m[VE], v[VE], w[VE], b[VE];
+  ldf<VE>(f.w, c0, w);
+  ldf<VE>(f.b, c0, b);
+  if (f.training) {
+    float sft[VE], s1[VE], s2[VE];
+    ldf<VE>(f.acc, c0, sft);
+    ldf<VE>(f.acc, (long)C + c0, s1);
+    ldf<VE>(f.acc, 2L * C + c0, s2);
+    const float rows = (float)f.rows;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const float a1 = s1[e] / rows, a2 = s2[e] / rows;       // (divisions, as bn_finalize_k: the variance below cancels, a last-bit difference shows)
+      m[e] = sft[e] + a1;
+      v[e] = fmaxf(a2 - a1 * a1, 0.f);
+    }
+  } else {
+    ldf<VE>(f.run_mean, c0, m);
+    ldf<VE>(f.run_var, c0, v);
+  }
+  float rs[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    rs[e] = rsqrtf(v[e] + f.eps);
+    s[e] = w[e] * rs[e];
+    t[e] = b[e] - m[e] * s[e];
+  }
+  if (owner) {
+    if (f.training) {
+      float rm[VE], rv[VE];
+      ldf<VE>(f.run_mean, c0, rm);
+      ldf<VE>(f.run_var, c0, rv);
+      const float k = f.rows > 1 ? (float)f.rows / (float)(f.rows - 1) : 1.f;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        f.run_mean[c0 + e] = (1.f - f.momentum) * rm[e] + f.momentum * m[e];
+        f.run_var[c0 + e] = (1.f - f.momentum) * rv[e] + f.momentum * (v[e] * k);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { f.mean[c0 + e] = m[e]; f.rstd[c0 + e] = rs[e]; f.sc[c0 + e] = s[e]; f.sh[c0 + e] = t[e]; }
+  }
+}
+
 // ---- second stage of the per-channel sums: dst[j][c] += scale * sum_{k<K} part[(j*K + k)][q][c] ---------------------
-struct PartDesc { int q, J, K, S; float* dst; long dst_stride; float scale; };
-struct PartTable { PartDesc d[4]; int NQ, C; };
 static __global__ __launch_bounds__(256) void part_reduce_k(const float* part, PartTable t) {
   const PartDesc d = t.d[blockIdx.z];
   const int c = blockIdx.x * 256 + threadIdx.x;

@@ -803,6 +803,49 @@ void gemm_prof_collect(long* launches, double* total_ms, double* total_flops) {
   if (total_flops) *total_flops = fl;
 }
 
+// ---- per-call time line (diagnostics): one event pair per adapter forward / backward call on ITS stream, so the overlap of the
+// two adapter streams can be read without a tracer in the way (rocprofv3 --kernel-trace makes the late stages host-bound).
+struct CallRec { hipEvent_t e0, e1; int kind, N, C; void* stream; };
+static std::atomic<int> g_call_on{0};
+static std::deque<CallRec>* g_calls = nullptr;
+int call_prof_mode(int set) {
+  const int old = g_call_on.load();
+  if (set == 0 || set == 1) g_call_on.store(set);
+  return old;
+}
+void* call_prof_begin(void* stream, int kind, int N, int C) {
+  if (!g_call_on.load(std::memory_order_relaxed)) return nullptr;
+  CallRec r{nullptr, nullptr, kind, N, C, stream};
+  (void)hipEventCreate(&r.e0);
+  (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, (hipStream_t)stream);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_calls) g_calls = new std::deque<CallRec>();
+  g_calls->push_back(r);
+  return &g_calls->back();
+}
+void call_prof_end(void* rec) {
+  if (rec) (void)hipEventRecord(((CallRec*)rec)->e1, (hipStream_t)((CallRec*)rec)->stream);
+}
+// "kind N C stream t0_us t1_us" per call, times relative to the first call's start; clears the log
+void call_prof_dump(const char* path) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  FILE* f = fopen(path, "w");
+  if (g_calls && !g_calls->empty()) {
+    hipEvent_t base = g_calls->front().e0;
+    for (auto& r : *g_calls) {
+      (void)hipEventSynchronize(r.e1);
+      float a = 0.f, b = 0.f;
+      (void)hipEventElapsedTime(&a, base, r.e0);
+      (void)hipEventElapsedTime(&b, base, r.e1);
+      if (f) fprintf(f, "%s %d %d %p %.1f %.1f\n", r.kind ? "bwd" : "fwd", r.N, r.C, r.stream, a * 1e3, b * 1e3);
+    }
+    for (auto& r : *g_calls) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_calls->clear();
+  }
+  if (f) fclose(f);
+}
+
 template <int MODE, int WGM, int WGN, int TM, int TN, int STAGE>
 static void launch_lay(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s) {
   if (ak && bk)       hipLaunchKernelGGL((gemm_kernel<MODE, true, true, WGM, WGN, TM, TN, STAGE>), grid, dim3(256), 0, s, k);

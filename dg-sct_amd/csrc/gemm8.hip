@@ -252,7 +252,7 @@ void gemm8_kernel(const G8 p) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) kx[kk] = (unsigned)((((kk * 2 + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) * 16));
 
-  const bool dbg_nodma = p.dbg & 1, dbg_nord = p.dbg & 2, dbg_nomma = p.dbg & 4;
+  const bool dbg_nodma = p.dbg & 1, dbg_nord = p.dbg & 2, dbg_nomma = p.dbg & 4, dbg_early = p.dbg & 8;
   if (nk > 0) issue(kt_begin, 0);
   if (nk > 1) issue(kt_begin + 1, 1);
   for (int it = 0; it < nk; ++it) {
@@ -318,6 +318,7 @@ void gemm8_kernel(const G8 p) {
       };
       // (sched_barrier on both sides of every MFMA group: left alone, hipcc hoists the NEXT group's lgkmcnt wait to just
       //  behind the first MFMA, so the wave sat out the LDS latency with five MFMAs still to issue)
+      if (dbg_early && it + 2 < nk) issue(kt_begin + it + 2, it & 1);     // (timing experiment: overwrites the tile being read)
       rd(std::integral_constant<int, 0>{});
       landed(0);
       rd(std::integral_constant<int, 1>{});                  // the reads of k-step 1 fly under the MFMAs of k-step 0
@@ -336,7 +337,7 @@ void gemm8_kernel(const G8 p) {
       __builtin_amdgcn_sched_barrier(0);
       landed(1);                                             // last read of this buffer has returned: it may be refilled
       __builtin_amdgcn_s_barrier();
-      if (it + 2 < nk && !dbg_nodma) issue(kt_begin + it + 2, it & 1);     // (address arithmetic + DMA issue interleave with the last MFMAs)
+      if (it + 2 < nk && !dbg_nodma && !dbg_early) issue(kt_begin + it + 2, it & 1);     // (address arithmetic + DMA issue interleave with the last MFMAs)
       mma(1);
     }
   }

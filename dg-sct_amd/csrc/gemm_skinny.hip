@@ -113,6 +113,159 @@ __global__ __launch_bounds__(256) void gemm_skinny_k(const SkArgs p) {
   else stv<DT_BF16, 4>(p.D, (long)m * p.ldd + n, v);
 }
 
+// ---- the same product with the neighbouring elementwise launches of the gate-MLP chain folded in (SkFuse, prims.h) -------------
+// Every [BT, C] elementwise kernel next to these products was a 5-6 us slot on a dependency chain that is launch-latency-bound at
+// stages 2-3 (tools/call_overlap.py: ~95 chain launches per adapter call, ~15 us per slot of a pair): the operand transform
+// (m1 = aq1 * mean_N vq1;  dpre = dch * ch (1 - ch)) is applied to the A fragment as it arrives and stored once by the first column of
+// workgroups, the two `da` products accumulate into one tile, and dm1's two consumers (dpa1, coef) are written from the epilogue.
+template <int AMODE>
+__device__ __forceinline__ uint4 sk_a_frag(const SkFuse& p, int row, int k) {
+  if (AMODE == 0) return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.A) + (long)row * p.lda + k);
+  float a[8], m[8];
+  if (AMODE == 1) ldv<DT_BF16, 8>(p.A, (long)row * p.lda + k, a);
+  else { ldv<DT_F32, 4>(p.A, (long)row * p.lda + k, *reinterpret_cast<float(*)[4]>(a)); ldv<DT_F32, 4>(p.A, (long)row * p.lda + k + 4, *reinterpret_cast<float(*)[4]>(a + 4)); }
+  ldv<DT_F32, 4>(p.a_mul, (long)row * p.ld_mul + k, *reinterpret_cast<float(*)[4]>(m));
+  ldv<DT_F32, 4>(p.a_mul, (long)row * p.ld_mul + k + 4, *reinterpret_cast<float(*)[4]>(m + 4));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = AMODE == 1 ? a[e] * m[e] : a[e] * m[e] * (1.f - m[e]);
+  uint4 r;
+  r.x = f2bf2(a[0], a[1]); r.y = f2bf2(a[2], a[3]); r.z = f2bf2(a[4], a[5]); r.w = f2bf2(a[6], a[7]);
+  return r;
+}
+
+template <int AMODE>
+__global__ __launch_bounds__(256) void gemm_skinny_fused_k(const SkFuse p) {
+  __shared__ float part[4][32][33];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  int ra = m0 + (lane & 31); const bool ra_ok = ra < p.M; ra = ra_ok ? ra : p.M - 1;
+  int rb = n0 + (lane & 31); rb = rb < p.N ? rb : p.N - 1;
+  sk_f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    const int kq = p.K >> 2, nks = kq >> 4;
+    const int kbase = wave * kq + 8 * (lane >> 5);
+    const unsigned short* pb = reinterpret_cast<const unsigned short*>(p.B) + (long)rb * p.ldb + kbase;
+    constexpr int CH = 2;
+    uint4 fa[2][CH], fb[2][CH];
+    auto load = [&](int s, int ks0) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        int ks = ks0 + i; ks = ks < nks ? ks : nks - 1;
+        fa[s][i] = sk_a_frag<AMODE>(p, ra, kbase + ks * 16);
+        fb[s][i] = *reinterpret_cast<const uint4*>(pb + ks * 16);
+      }
+    };
+    auto mma = [&](int s, int ks0) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        uint4 a = fa[s][i];
+        if (AMODE != 0 && p.a_store && blockIdx.x == 0 && ra_ok && ks0 + i < nks)      // the transformed operand, stored once
+          *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.a_store) + (long)ra * p.ld_store + kbase + (ks0 + i) * 16) = a;
+        if (ks0 + i >= nks) a = make_uint4(0, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8_t, a), __builtin_bit_cast(sk_bf16x8_t, fb[s][i]), acc, 0, 0, 0);
+      }
+    };
+    load(0, 0);
+    for (int ks0 = 0; ks0 < nks; ks0 += 2 * CH) {
+      load(1, ks0 + CH);
+      mma(0, ks0);
+      load(0, ks0 + 2 * CH);
+      mma(1, ks0 + CH);
+    }
+  }
+  if (p.K2 > 0) {                                             // second product into the same tile (plain bf16 operands)
+    const int kq = p.K2 >> 2, nks = kq >> 4;
+    const unsigned short* pa = reinterpret_cast<const unsigned short*>(p.A2) + (long)ra * p.lda2 + wave * kq + 8 * (lane >> 5);
+    const unsigned short* pb = reinterpret_cast<const unsigned short*>(p.B2) + (long)rb * p.ldb2 + wave * kq + 8 * (lane >> 5);
+    for (int ks0 = 0; ks0 < nks; ks0 += 4) {
+      uint4 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int ks = ks0 + i; ks = ks < nks ? ks : nks - 1;
+        fa[i] = *reinterpret_cast<const uint4*>(pa + ks * 16);
+        fb[i] = *reinterpret_cast<const uint4*>(pb + ks * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint4 a = fa[i];
+        if (ks0 + i >= nks) a = make_uint4(0, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8_t, a), __builtin_bit_cast(sk_bf16x8_t, fb[i]), acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[r];
+  __syncthreads();
+  const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+  const int m = m0 + row, n = n0 + c0;
+  if (m >= p.M || n >= p.N) return;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = part[0][row][c0 + e] + part[1][row][c0 + e] + part[2][row][c0 + e] + part[3][row][c0 + e];
+  float bn[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+  if (p.bias_n) ldv<DT_F32, 4>(p.bias_n, n, bn);
+  if (p.mask) ldv<DT_BF16, 4>(p.mask, (long)m * p.ldmask + n, mk);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = v[e] + bn[e];
+    if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+    else if (p.act == ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
+    if (p.mask && !(mk[e] > 0.f)) x = 0.f;
+    v[e] = x;
+  }
+  if (p.epi == 1) {                                           // D = v * e_mul * (e_q > 0)  (E);  D2 = v * e_q  (fp32)
+    float em[4], eq[4], o1[4], o2[4];
+    ldv<DT_F32, 4>(p.e_mul, (long)m * p.ld_emul + n, em);
+    ldv<DT_BF16, 4>(p.e_q, (long)m * p.ld_eq + n, eq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o1[e] = eq[e] > 0.f ? v[e] * em[e] : 0.f; o2[e] = v[e] * eq[e]; }
+    stv<DT_BF16, 4>(p.D, (long)m * p.ldd + n, o1);
+    stv<DT_F32, 4>(p.D2, (long)m * p.ldd2 + n, o2);
+    return;
+  }
+  if (p.ddt == DT_F32) stv<DT_F32, 4>(p.D, (long)m * p.ldd + n, v);
+  else stv<DT_BF16, 4>(p.D, (long)m * p.ldd + n, v);
+}
+
+int skfuse_mode(int set) {
+  static std::atomic<int> mode{getenv("DGSCT_NO_SKFUSE") ? 0 : 1};
+  const int old = mode.load(std::memory_order_relaxed);
+  if (set >= 0) mode.store(set ? 1 : 0, std::memory_order_relaxed);
+  return old;
+}
+
+bool skinny_fused_supported(const Ctx& ctx, int M, int N, int K, int K2) {
+  if (!skfuse_mode(-1) || !gemm_skinny_mode(-1) || ctx.mode != DT_BF16) return false;
+  if (M < 1 || M > 256 || N < 32 || N % 4) return false;
+  if (K < 64 || K % 64 || K > 4096) return false;
+  if (K2 && (K2 < 64 || K2 % 64 || K2 > 4096)) return false;
+  return true;
+}
+
+void skinny_fused(const Ctx& ctx, const SkFuse& p) {
+  auto al = [](const void* q, int a) { return (reinterpret_cast<uintptr_t>(q) & (uintptr_t)(a - 1)) == 0; };
+  bool ok = skinny_fused_supported(ctx, p.M, p.N, p.K, p.K2) && p.b_kmajor && (!p.K2 || p.b2_kmajor) && al(p.A, 16) && al(p.B, 16) && p.lda % 8 == 0 && p.ldb % 8 == 0 && al(p.D, 8) &&
+            p.ldd % 4 == 0;
+  if (p.a_mode) ok = ok && al(p.a_mul, 16) && p.ld_mul % 4 == 0 && (!p.a_store || (al(p.a_store, 16) && p.ld_store % 8 == 0));
+  if (p.K2) ok = ok && al(p.A2, 16) && al(p.B2, 16) && p.lda2 % 8 == 0 && p.ldb2 % 8 == 0;
+  if (p.mask) ok = ok && al(p.mask, 8) && p.ldmask % 4 == 0;
+  if (p.bias_n) ok = ok && al(p.bias_n, 16);
+  if (p.epi == 1) ok = ok && al(p.e_mul, 16) && p.ld_emul % 4 == 0 && al(p.e_q, 8) && p.ld_eq % 4 == 0 && al(p.D2, 16) && p.ldd2 % 4 == 0;
+  if (!ok) { set_error("skinny_fused: unsupported shape / alignment (check skinny_fused_supported first)"); return; }
+  dim3 grid((p.N + 31) / 32, (p.M + 31) / 32);
+  hipStream_t s = (hipStream_t)ctx.stream;
+  GemmProfShape shp{p.M, p.N, p.K + p.K2, 1, 1, 1, 10, 1, 1, 0, 1, 0.0};
+  shp.bytes = ((double)p.M * (p.K + p.K2) + (double)p.N * (p.K + p.K2)) * 2 + (double)p.M * p.N * 4;
+  void* rec = gemm_prof_begin(s, 2.0 * p.M * (double)p.N * (p.K + p.K2), shp);
+  if (p.a_mode == 0) hipLaunchKernelGGL(gemm_skinny_fused_k<0>, grid, dim3(256), 0, s, p);
+  else if (p.a_mode == 1) hipLaunchKernelGGL(gemm_skinny_fused_k<1>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gemm_skinny_fused_k<2>, grid, dim3(256), 0, s, p);
+  gemm_prof_end(rec, s);
+}
+
 static inline bool sk_al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 int gemm_skinny_mode(int set) {     // process-wide, test-only switch (like gemm8_mode / rowfuse_mode): atomic, DataParallel replicas run on threads

@@ -197,6 +197,8 @@ void Plan::layout() {
     wb.dT = a.take("dT", orderA ? R * Co * es : (int64_t)B * No * C * es);
     wb.rowtmp = a.take("rowtmp", R * 4);
     wb.rowpart = a.take("rowpart", row_part_floats(B, C) * 4);
+    wb.rowpart_v1 = a.take("rowpart_v1", row_part_floats(B, C) * 4);   // partial sums whose second stage runs on the aux stream: not reused
+    wb.rowpart_v2 = a.take("rowpart_v2", row_part_floats(B, C) * 4);
     ws_bwd_bytes = a.off;
   }
   // ---- gradients (flat fp32)
@@ -389,11 +391,19 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     else gemm(ctx, g3);
     colsum_batched(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C);
     stream_join(ctx);                                            // aq1 / aq2 / a from the aux stream
-    ew(ctx, EW_MUL, b.S(s.m1), E, Earg(b.S(s.aq1), E), F32(b.S(s.mvq1)), NOARG, (long)B * C, 0.f, 1);
-    Gemm g4 = mk(B, dd, C);                                      // q = relu(m1 Wb^T + b)
-    g4.A = km(b.S(s.m1), C); g4.B = km(b.W(DGSCT_P_WB), C); g4.bias_n = b.F(DGSCT_P_BB); g4.act = ACT_RELU;
-    outE(g4, b.S(s.q), E, dd);
-    gemm(ctx, g4);
+    if (skinny_fused_supported(ctx, B, dd, C, 0)) {              // q = relu(m1 Wb^T + b), m1 = aq1 * mean_N vq1 made (and stored) on the way in
+      SkFuse f; f.M = B; f.N = dd; f.K = C;
+      f.a_mode = 1; f.A = b.S(s.aq1); f.lda = C; f.a_mul = b.S<float>(s.mvq1); f.ld_mul = C; f.a_store = b.S(s.m1); f.ld_store = C;
+      f.B = b.W(DGSCT_P_WB); f.ldb = C; f.bias_n = b.F(DGSCT_P_BB); f.act = ACT_RELU;
+      f.D = b.S(s.q); f.ddt = E; f.ldd = dd;
+      skinny_fused(ctx, f);
+    } else {
+      ew(ctx, EW_MUL, b.S(s.m1), E, Earg(b.S(s.aq1), E), F32(b.S(s.mvq1)), NOARG, (long)B * C, 0.f, 1);
+      Gemm g4 = mk(B, dd, C);                                    // q = relu(m1 Wb^T + b)
+      g4.A = km(b.S(s.m1), C); g4.B = km(b.W(DGSCT_P_WB), C); g4.bias_n = b.F(DGSCT_P_BB); g4.act = ACT_RELU;
+      outE(g4, b.S(s.q), E, dd);
+      gemm(ctx, g4);
+    }
     Gemm g5 = mk(B, C, dd);                                      // ch = sigmoid(q Wcatt^T + b)
     g5.A = km(b.S(s.q), dd); g5.B = km(b.W(DGSCT_P_WCATT), dd); g5.bias_n = b.F(DGSCT_P_BCATT); g5.act = ACT_SIGMOID;
     outF(g5, b.S<float>(s.ch), C);
@@ -458,12 +468,14 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       outE(g1, b.S(s.Zp), E, ds, ds / g);
       gemm(ctx, g1);
     }
-    if (d.use_bn) {
+    if (d.use_bn) {                                              // BN1: finalised inside the pass that applies it (BnFin)
       if (d.training && !fuse89 && !gfuse) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
-      bn_finalize(ctx, b.S<float>(s.bnacc1), R, ds, b.F(DGSCT_P_BN1_W), b.F(DGSCT_P_BN1_B), b.Fm(DGSCT_P_BN1_RM),
-                  b.Fm(DGSCT_P_BN1_RV), d.bn_momentum, d.eps, d.training, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds);
+      const BnFin f1{b.S<float>(s.bnacc1), R, b.F(DGSCT_P_BN1_W), b.F(DGSCT_P_BN1_B), b.Fm(DGSCT_P_BN1_RM), b.Fm(DGSCT_P_BN1_RV),
+                     d.bn_momentum, d.eps, d.training, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds};
+      affine_act_bn(ctx, b.S(s.Zp), b.S(s.Z), R, ds, f1, 1);
+    } else {
+      affine_act(ctx, b.S(s.Zp), b.S(s.Z), R, ds, nullptr, nullptr, 1);
     }
-    affine_act(ctx, b.S(s.Zp), b.S(s.Z), R, ds, d.use_bn ? bn1 + 2 * ds : nullptr, d.use_bn ? bn1 + 3 * ds : nullptr, 1);
     const bool stats2 = d.use_bn && d.training;
     if (vproj) {                                                 // Op = Z (x)_g Wu, BN2 sums in the same pass
       gproj_wide(ctx, b.S(s.Z), R, C, ds, g, b.F(DGSCT_P_WU), cgl * dgl, 1, dgl, b.S(s.Op), stats2 ? b.S<float>(s.bnacc2) : nullptr);
@@ -474,17 +486,16 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       outE(g2, b.S(s.Op), E, C, C / g);
       gemm(ctx, g2);
     }
-    if (d.use_bn) {
-      if (stats2 && !vproj) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
-      bn_finalize(ctx, b.S<float>(s.bnacc2), R, C, b.F(DGSCT_P_BN2_W), b.F(DGSCT_P_BN2_B), b.Fm(DGSCT_P_BN2_RM),
-                  b.Fm(DGSCT_P_BN2_RV), d.bn_momentum, d.eps, d.training, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C);
-    }
+    if (d.use_bn && stats2 && !vproj) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
   }
-  // F11 ---- ln_post / gate                                              :668-671
+  // F11 ---- BN2 finalised + applied, ln_post / gate                     :668-671
+  const BnFin f2{b.S<float>(s.bnacc2), R, b.F(DGSCT_P_BN2_W), b.F(DGSCT_P_BN2_B), b.Fm(DGSCT_P_BN2_RM), b.Fm(DGSCT_P_BN2_RV),
+                 d.bn_momentum, d.eps, d.training, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C};
   tail_fwd(ctx, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr,
            d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
            d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, d.eps, R, C, out, b.S<float>(s.mu_p),
-           b.S<float>(s.rstd_p), residual);        // f2: out = residual + adapter(X, Y)
+           b.S<float>(s.rstd_p), residual,         // f2: out = residual + adapter(X, Y)
+           d.use_bn ? &f2 : nullptr);
   check_async("dgsct_adapter_forward");
   return has_error() ? 1 : 0;
 }
@@ -615,8 +626,13 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     ew2(ctx, EwCall{EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1},
         EwCall{EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd});
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
-    relu_bwd_scale(ctx, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
-                   G(DGSCT_P_BV2), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+    {
+      PartJob pj;                                                // d bias(vq2): second stage of the column sums off the chain
+      Ctx cl = ctx; cl.late = aux_stream ? &pj : nullptr;
+      relu_bwd_scale(cl, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
+                     G(DGSCT_P_BV2), b.Wk<float>(wb.rowpart_v2), row_part_floats(B, C));
+      if (pj.n) defer([=, &side] { part_reduce_run(side.stream, pj); });
+    }
     Gemm g1 = mk((int)R, C, dd);                                 // dXc = dvq2 . Wv2
     g1.A = km(b.S(s.vq2), dd);
     g1.B = b.WB(DGSCT_P_WV2, C, dd);
@@ -629,31 +645,57 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   }
   // B6 ---- channel-gate head
   {
-    ew(ctx, EW_SIGMOID_BWD, b.Wk(wb.dpre_c), E, F32(b.Wk(wb.dch)), F32(b.S(s.ch)), NOARG, (long)B * C, 0.f, 1);
+    const MatOp wcattT = b.WB(DGSCT_P_WCATT, dd, C), wbT = b.WB(DGSCT_P_WB, C, dd);
+    // the chain's four launches (sigmoid', dq, dm1, its two consumers) as two products with the elementwise parts folded in
+    const bool skf = skinny_fused_supported(ctx, B, dd, C, 0) && skinny_fused_supported(ctx, B, C, dd, 0) &&
+                     (E != DT_BF16 || (wcattT.kmajor && wbT.kmajor));
+    if (!skf) ew(ctx, EW_SIGMOID_BWD, b.Wk(wb.dpre_c), E, F32(b.Wk(wb.dch)), F32(b.S(s.ch)), NOARG, (long)B * C, 0.f, 1);
     Gemm g1 = mk(C, dd, B);                                      // dWcatt = dpre^T . q
     g1.A = mn(b.Wk(wb.dpre_c), C); g1.B = mn(b.S(s.q), dd);
     outF(g1, G(DGSCT_P_WCATT), dd);
     defer([=, &side] { gemm(side, g1); });
-    Gemm g2 = mk(B, dd, C);                                      // dq = (dpre . Wcatt) * (q > 0)
-    g2.A = km(b.Wk(wb.dpre_c), C); g2.B = b.WB(DGSCT_P_WCATT, dd, C);
-    g2.mask = b.S(s.q); g2.ldmask = dd;
-    outE(g2, b.Wk(wb.dq), E, dd);
-    gemm(ctx, g2);
+    if (skf) {                                                   // dq = (dpre . Wcatt) * (q > 0), dpre = dch ch (1 - ch) made (and stored) on the way in
+      SkFuse f; f.M = B; f.N = dd; f.K = C;
+      f.a_mode = 2; f.A = b.Wk(wb.dch); f.lda = C; f.a_mul = b.S<float>(s.ch); f.ld_mul = C; f.a_store = b.Wk(wb.dpre_c); f.ld_store = C;
+      f.B = wcattT.p; f.ldb = wcattT.ld; f.b_kmajor = wcattT.kmajor;
+      f.mask = b.S(s.q); f.ldmask = dd;
+      f.D = b.Wk(wb.dq); f.ddt = E; f.ldd = dd;
+      skinny_fused(ctx, f);
+    } else {
+      Gemm g2 = mk(B, dd, C);                                    // dq = (dpre . Wcatt) * (q > 0)
+      g2.A = km(b.Wk(wb.dpre_c), C); g2.B = wcattT;
+      g2.mask = b.S(s.q); g2.ldmask = dd;
+      outE(g2, b.Wk(wb.dq), E, dd);
+      gemm(ctx, g2);
+    }
     Gemm g3 = mk(dd, C, B);                                      // dWb = dq^T . m1
     g3.A = mn(b.Wk(wb.dq), dd); g3.B = mn(b.S(s.m1), C);
     outF(g3, G(DGSCT_P_WB), C);
     defer([=, &side] { gemm(side, g3); });
-    Gemm g4 = mk(B, C, dd);                                      // dm1 = dq . Wb
-    g4.A = km(b.Wk(wb.dq), dd); g4.B = b.WB(DGSCT_P_WB, C, dd);
-    outF(g4, b.Wk<float>(wb.dm1), C);
-    gemm(ctx, g4);
-    ew2(ctx, EwCall{EW_MUL_MASK, b.Wk(wb.dpa1), E, F32(b.Wk(wb.dm1)), F32(b.S(s.mvq1)), Earg(b.S(s.aq1), E), (long)B * C, 0.f, 1},
-        EwCall{EW_MUL, b.Wk(wb.coef), DT_F32, F32(b.Wk(wb.dm1)), Earg(b.S(s.aq1), E), NOARG, (long)B * C, 0.f, 1});
+    if (skf) {                                                   // dm1 = dq . Wb -> dpa1 = dm1 mvq1 (aq1 > 0), coef = dm1 aq1 from the epilogue
+      SkFuse f; f.M = B; f.N = C; f.K = dd;
+      f.A = b.Wk(wb.dq); f.lda = dd; f.B = wbT.p; f.ldb = wbT.ld; f.b_kmajor = wbT.kmajor;
+      f.epi = 1; f.D = b.Wk(wb.dpa1); f.ddt = E; f.ldd = C; f.e_mul = b.S<float>(s.mvq1); f.ld_emul = C; f.e_q = b.S(s.aq1); f.ld_eq = C;
+      f.D2 = b.Wk<float>(wb.coef); f.ldd2 = C;
+      skinny_fused(ctx, f);
+    } else {
+      Gemm g4 = mk(B, C, dd);                                    // dm1 = dq . Wb
+      g4.A = km(b.Wk(wb.dq), dd); g4.B = wbT;
+      outF(g4, b.Wk<float>(wb.dm1), C);
+      gemm(ctx, g4);
+      ew2(ctx, EwCall{EW_MUL_MASK, b.Wk(wb.dpa1), E, F32(b.Wk(wb.dm1)), F32(b.S(s.mvq1)), Earg(b.S(s.aq1), E), (long)B * C, 0.f, 1},
+          EwCall{EW_MUL, b.Wk(wb.coef), DT_F32, F32(b.Wk(wb.dm1)), Earg(b.S(s.aq1), E), NOARG, (long)B * C, 0.f, 1});
+    }
   }
   // B5 ---- video query 1
   {
-    relu_bwd_scale(ctx, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N,
-                   G(DGSCT_P_BV1), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+    {
+      PartJob pj;                                                // d bias(vq1), likewise
+      Ctx cl = ctx; cl.late = aux_stream ? &pj : nullptr;
+      relu_bwd_scale(cl, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N,
+                     G(DGSCT_P_BV1), b.Wk<float>(wb.rowpart_v1), row_part_floats(B, C));
+      if (pj.n) defer([=, &side] { part_reduce_run(side.stream, pj); });
+    }
     Gemm g1 = mk((int)R, C, C);                                  // dX1 += dvq1 . Wv1
     g1.A = km(b.S(s.vq1), C); g1.B = b.WB(DGSCT_P_WV1, C, C);
     resid(g1, dX1, E, C);
@@ -683,15 +725,24 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       colsum_multi(side, segs, 5);
     });
     side_flush();                                                // dWcatt, dWb, dWv1, dWa1, dWa2 and their biases
-    Gemm g3 = mk(B, C, C);                                       // da = dpa1 . Wa1 + dpa2 . Wa2
-    g3.A = km(b.Wk(wb.dpa1), C); g3.B = b.WB(DGSCT_P_WA1, C, C);
-    outF(g3, b.Wk<float>(wb.da), C);
-    gemm(ctx, g3);
-    Gemm g4 = mk(B, C, dd);
-    g4.A = km(b.Wk(wb.dpa2), dd); g4.B = b.WB(DGSCT_P_WA2, C, dd);
-    resid(g4, b.Wk(wb.da), DT_F32, C);
-    outF(g4, b.Wk<float>(wb.da), C);
-    gemm(ctx, g4);
+    const MatOp wa1T = b.WB(DGSCT_P_WA1, C, C), wa2T = b.WB(DGSCT_P_WA2, C, dd);
+    if (skinny_fused_supported(ctx, B, C, C, dd) && (E != DT_BF16 || (wa1T.kmajor && wa2T.kmajor))) {
+      SkFuse f; f.M = B; f.N = C; f.K = C;                       // da = dpa1 . Wa1 + dpa2 . Wa2: both products into one tile
+      f.A = b.Wk(wb.dpa1); f.lda = C; f.B = wa1T.p; f.ldb = wa1T.ld; f.b_kmajor = wa1T.kmajor;
+      f.K2 = dd; f.A2 = b.Wk(wb.dpa2); f.lda2 = dd; f.B2 = wa2T.p; f.ldb2 = wa2T.ld; f.b2_kmajor = wa2T.kmajor;
+      f.D = b.Wk(wb.da); f.ddt = DT_F32; f.ldd = C;
+      skinny_fused(ctx, f);
+    } else {
+      Gemm g3 = mk(B, C, C);                                     // da = dpa1 . Wa1 + dpa2 . Wa2
+      g3.A = km(b.Wk(wb.dpa1), C); g3.B = wa1T;
+      outF(g3, b.Wk<float>(wb.da), C);
+      gemm(ctx, g3);
+      Gemm g4 = mk(B, C, dd);
+      g4.A = km(b.Wk(wb.dpa2), dd); g4.B = wa2T;
+      resid(g4, b.Wk(wb.da), DT_F32, C);
+      outF(g4, b.Wk<float>(wb.da), C);
+      gemm(ctx, g4);
+    }
     if (d.temporal) {
       float* dtg = b.Wk<float>(wb.dtg);
       if (dTmap) ew(ctx, EW_ADD_BCAST, dtg, DT_F32, F32(dtg), F32(dTmap), NOARG, B, 1.f, 1);

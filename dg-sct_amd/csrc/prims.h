@@ -22,7 +22,19 @@ struct Ctx {
   void* stream;   // hipStream_t
   int mode;       // DType of E
   void* aux = nullptr;   // optional second hipStream_t for work off the critical path (weight gradients)
+  struct PartJob* late = nullptr;   // when set: a primitive whose second-stage reduction feeds PARAMETER gradients only records it here
+                                    // instead of launching it (the plan releases it on the aux stream with the weight gradients)
 };
+// second stage of the per-channel partial sums (device_util.h: part_reduce_k): dst[j][c] += scale * sum_{k<K} part[j*K + k][q][c]
+struct PartDesc { int q, J, K, S; float* dst; long dst_stride; float scale; };
+struct PartTable { PartDesc d[4]; int NQ, C; };
+struct PartJob { const float* part = nullptr; PartTable t; int n = 0; };
+void part_reduce_run(void* stream, const PartJob&);
+// diagnostics: event pair around every adapter call on its stream (dgsct_test_tune "callprof": 1 on, 0 off, 2 dump to $DGSCT_CALL_PROF)
+int call_prof_mode(int set);
+void* call_prof_begin(void* stream, int kind, int N, int C);
+void call_prof_end(void* rec);
+void call_prof_dump(const char* path);
 // aux waits for everything enqueued on stream so far / stream waits for everything enqueued on aux so far.
 // No-ops when ctx.aux is null.
 // a stream of its own priority class (-1 high, 0 normal, +1 low): the HIP runtime keeps one hardware-queue pool per
@@ -75,6 +87,22 @@ struct Gemm {
 };
 
 void gemm(const Ctx&, const Gemm&);
+// A [BT, C] gate-MLP product with its neighbouring elementwise launches folded in (gemm_skinny.hip; bf16, M <= 256, both operands
+// K-major):   D = epi( act( sum_k A'[m][k] B[n][k] + sum_k2 A2[m][k2] B2[n][k2] + bias_n ) masked by (mask > 0) )
+//   a_mode 0: A' = A (bf16)          1: A' = bf16(A (bf16) * a_mul (fp32))          2: A' = bf16(A (fp32) * s (1 - s)), s = a_mul (fp32)
+//   a_store (E, may be null): A' written once;   epi 0: D (ddt) = v      1: D (E) = v * e_mul (fp32) * (e_q (E) > 0), D2 (fp32) = v * e_q
+struct SkFuse {
+  int M = 0, N = 0, K = 0;
+  int a_mode = 0; const void* A = nullptr; long lda = 0; const float* a_mul = nullptr; long ld_mul = 0; void* a_store = nullptr; long ld_store = 0;
+  const void* B = nullptr; long ldb = 0; int b_kmajor = 1;      // (the HIP kernel takes K-major operands only; the flags serve the host emulation)
+  int K2 = 0; const void* A2 = nullptr; long lda2 = 0; const void* B2 = nullptr; long ldb2 = 0; int b2_kmajor = 1;
+  const float* bias_n = nullptr; int act = ACT_NONE; const void* mask = nullptr; long ldmask = 0;
+  int epi = 0; void* D = nullptr; int ddt = DT_F32; long ldd = 0;
+  const float* e_mul = nullptr; long ld_emul = 0; const void* e_q = nullptr; long ld_eq = 0; float* D2 = nullptr; long ldd2 = 0;
+};
+int skfuse_mode(int set);         // dgsct_test_tune "skfuse"
+bool skinny_fused_supported(const Ctx&, int M, int N, int K, int K2);
+void skinny_fused(const Ctx&, const SkFuse&);
 // bench-only: time every GEMM launch of this thread with HIP events (see gemm.hip)
 void gemm_prof_enable(int on);
 void gemm_prof_collect(long* launches, double* total_ms, double* total_flops);
@@ -191,6 +219,15 @@ void bn_finalize(const Ctx&, const float* acc, long rows, int C, const float* w,
                  float* run_var, float momentum, float eps, int training, float* mean, float* rstd, float* sc, float* sh);
 // y = x*sc + sh (sc == null -> identity), optional relu.  E -> E
 void affine_act(const Ctx&, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu);
+// The arguments of bn_finalize as one value: a CONSUMER of the scale / shift vectors (affine_act_bn, tail_fwd with `fin`) derives
+// them from the batch sums itself (two loads, an rsqrt per channel) and its first workgroup stores mean / rstd / sc / sh and
+// updates the running statistics -- one launch less on the dependency chain per BatchNorm (dgsct_test_tune "bnfold").
+struct BnFin {
+  const float* acc; long rows; const float* w; const float* b; float* run_mean; float* run_var; float momentum, eps; int training;
+  float* mean; float* rstd; float* sc; float* sh;
+};
+int bnfold_mode(int set);
+void affine_act_bn(const Ctx&, const void* x, void* y, long rows, int C, const BnFin& fin, int relu);
 // sums[0][c] += sum dyb, sums[1][c] += sum dyb*xh with dyb = dy * (relu ? (x*sc+sh > 0) : 1), xh = (x-mean)*rstd
 void bn_bwd_stats(const Ctx&, const void* dy, const void* x, long rows, int C, const float* mean, const float* rstd,
                   const float* sc, const float* sh, int relu, float* sums, float* part = nullptr, long part_floats = 0);
@@ -202,7 +239,8 @@ void bn_bwd_apply(const Ctx&, const void* dy, const void* x, void* dx, long rows
 // else: L = lnw ? LN(O) : O, out = gate ? gate*L : L.  mu/rstd [B*N] written when lnw.
 void tail_fwd(const Ctx&, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
               const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd,
-              const void* residual = nullptr);     // out += residual (E [rows][C]) when given
+              const void* residual = nullptr,      // out += residual (E [rows][C]) when given
+              const BnFin* fin2 = nullptr);        // BN2 finalised inside (sc2 / sh2 are then the OUTPUT vectors fin2->sc / sh)
 // backward of tail_fwd: writes dO (E); accumulates dlnw, dlnb [C], *dgate, and (if bnsums) bnsums[0][c] += sum dO,
 // bnsums[1][c] += sum dO * (Op - mean2)*rstd2.
 void tail_bwd(const Ctx&, const void* dOut, const void* Op, const float* sc2, const float* sh2, const float* mean2,

@@ -90,6 +90,12 @@ void stream_join(const Ctx& ctx) {
   order_after((hipStream_t)ctx.stream, (hipStream_t)ctx.aux, 1);
 }
 
+void part_reduce_run(void* stream, const PartJob& j) {
+  if (!j.n) return;
+  PartTable t = j.t;
+  part_reduce(stream, j.part, t, j.n);
+}
+
 void zero(const Ctx& ctx, void* p, size_t bytes) {
   if (bytes) (void)hipMemsetAsync(p, 0, bytes, STREAM(ctx));
 }
@@ -443,7 +449,7 @@ template <int DT, int VE, int MAXNV>
 __global__ __launch_bounds__(256) void tail_fwd_k(const void* Op, const float* sc2, const float* sh2, const float* lnw,
                                                   const float* lnb, const float* gate, int gate_first, float eps,
                                                   long rows, int C, int gs, int nv, int rpc, void* out, float* mu,
-                                                  float* rstd, const void* res) {
+                                                  float* rstd, const void* res, const BnFin fin, int has_fin) {
   const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
   const long r_end = lmin_d(rows, (long)(blockIdx.x + 1) * rpc);
   const float gv = gate ? *gate : 1.f;
@@ -452,7 +458,9 @@ __global__ __launch_bounds__(256) void tail_fwd_k(const void* Op, const float* s
   for (int v = 0; v < MAXNV; ++v) {
     const int col = (v * gs + gl) * VE;
     if (v < nv && col < C) {
-      if (sc2) { ldf<VE>(sc2, col, sc[v]); ldf<VE>(sh2, col, sh[v]); }
+      if (has_fin) {                                   // BN2 finalised here (BnFin, prims.h): sc2 / sh2 are its output vectors
+        bn_fin_vec<VE>(fin, C, col, blockIdx.x == 0 && sub == 0, sc[v], sh[v]);
+      } else if (sc2) { ldf<VE>(sc2, col, sc[v]); ldf<VE>(sh2, col, sh[v]); }
       if (lnw) { ldf<VE>(lnw, col, w[v]); ldf<VE>(lnb, col, bb[v]); }
     }
   }
@@ -516,7 +524,15 @@ __global__ __launch_bounds__(256) void tail_fwd_k(const void* Op, const float* s
 
 void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
               const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd,
-              const void* residual) {
+              const void* residual, const BnFin* fin2) {
+  BnFin fin{};
+  int has_fin = 0;
+  if (fin2 && (!bnfold_mode(-1) || rows < 1)) {
+    bn_finalize(ctx, fin2->acc, fin2->rows, C, fin2->w, fin2->b, fin2->run_mean, fin2->run_var, fin2->momentum, fin2->eps,
+                fin2->training, fin2->mean, fin2->rstd, fin2->sc, fin2->sh);
+  } else if (fin2) {
+    fin = *fin2; has_fin = 1;
+  }
   RowGeom g = row_geom(C, row_ve(ctx, C), (int)rows, 1);
   {
     int cap = 2048;
@@ -524,7 +540,7 @@ void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2
     g = row_geom(C, row_ve(ctx, C), (int)rows, 1, cap, 1, true);
   }
   ROW_DISPATCH(ctx, C, g.nv, tail_fwd_k, dim3(g.chunks), Op, sc2, sh2, lnw, lnb, gate, gate_first, eps, rows, C, g.gs, g.nv, g.rpc,
-               out, mu, rstd, residual);
+               out, mu, rstd, residual, fin, has_fin);
 }
 
 // AVE = the flag set of the AVE / AVVP / AVQA-visual / pretrain flavours (BN2 on, ln_post on, gate present, LN before

@@ -10,6 +10,7 @@
 // channel per workgroup.  The UNR loads of a trip are UNCONDITIONAL (tail rows read a clamped, valid row and are
 // masked afterwards): a per-row "load or zero" makes hipcc branch around each load and emit s_waitcnt vmcnt(0)
 // after every one of them, i.e. four serial HBM round trips instead of four loads in flight.
+#include <atomic>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "prims.h"
@@ -300,6 +301,57 @@ __global__ __launch_bounds__(256) void affine_act_k(const void* x, void* y, long
   }
 }
 
+// the same pass with BN's finalisation inside (BnFin, prims.h)
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void affine_act_bn_k(const void* x, void* y, long rows, int C, int tpr, int rpp, int rpc,
+                                                       const BnFin fin, int relu) {
+  constexpr int UNR = UNR1;
+  STRIP_PROLOGUE(lmin_d(rows, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    if (!(tr < rpp && vc < nvr)) continue;
+    float a[VE], bsh[VE];
+    bn_fin_vec<VE>(fin, C, vc * VE, blockIdx.x == 0 && tr == 0, a, bsh);
+    for (long r = r_begin + tr; r < r_end; r += (long)rpp * UNR) {
+      float t[UNR][VE];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = r + (long)u * rpp;
+        ldv<DT, VE>(x, (rr < r_end ? rr : r_end - 1) * C + vc * VE, t[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = r + (long)u * rpp;
+        if (rr < r_end) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) { float v = t[u][e] * a[e] + bsh[e]; t[u][e] = relu ? fmaxf(v, 0.f) : v; }
+          stv<DT, VE>(y, rr * C + vc * VE, t[u]);
+        }
+      }
+    }
+  }
+}
+
+int bnfold_mode(int set) {
+  static std::atomic<int> mode{getenv("DGSCT_NO_BNFOLD") ? 0 : 1};
+  const int old = mode.load(std::memory_order_relaxed);
+  if (set >= 0) mode.store(set ? 1 : 0, std::memory_order_relaxed);
+  return old;
+}
+
+void affine_act_bn(const Ctx& ctx, const void* x, void* y, long rows, int C, const BnFin& fin, int relu) {
+  if (!bnfold_mode(-1) || rows < 1) {
+    bn_finalize(ctx, fin.acc, fin.rows, C, fin.w, fin.b, fin.run_mean, fin.run_var, fin.momentum, fin.eps, fin.training, fin.mean,
+                fin.rstd, fin.sc, fin.sh);
+    affine_act(ctx, x, y, rows, C, fin.sc, fin.sh, relu);
+    return;
+  }
+  const int ve = col_ve(ctx, C);
+  ColGeom g = col_geom(UNR1, C, ve, rows, 1);
+  if (stream_cap()) { int cap = 4096; COL_CAPACITY(cap, ctx, ve, affine_act_bn_k, 0); g = col_geom(UNR1, C, ve, rows, 1, cap, true); }
+  COL_DISPATCH(ctx, ve, affine_act_bn_k, dim3(g.chunks), 0, x, y, rows, C, g.tpr, g.rpp, g.rpc, fin, relu);
+}
+
 void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu) {
   const int ve = col_ve(ctx, C);
   ColGeom g = col_geom(UNR1, C, ve, rows, 1);
@@ -571,7 +623,8 @@ void relu_bwd_scale(const Ctx& ctx, const void* x, void* y, int B, int N, int C,
   if (part) {
     PartTable t; t.NQ = 1; t.C = C;
     t.d[0] = PartDesc{0, 1, g.chunks * B, 1, colsum_out, 0, 1.f};
-    part_reduce(ctx.stream, part, t, 1);
+    if (ctx.late) { ctx.late->part = part; ctx.late->t = t; ctx.late->n = 1; }   // a bias gradient: nothing downstream reads it
+    else part_reduce(ctx.stream, part, t, 1);
   }
 }
 

@@ -33,6 +33,11 @@ void gemm_prof_collect(long* n, double* ms, double* fl) { if (n) *n = 0; if (ms)
 void* stream_create(int) { return nullptr; }
 void stream_destroy(void*) {}
 void stream_fork(const Ctx&) {}
+int call_prof_mode(int) { return 0; }
+void* call_prof_begin(void*, int, int, int) { return nullptr; }
+void call_prof_end(void*) {}
+void call_prof_dump(const char*) {}
+void part_reduce_run(void*, const PartJob&) {}   // (the host primitives never leave a second stage behind)
 void stream_join(const Ctx&) {}
 void check_async(const char*) {}
 void clear_async() {}
@@ -106,6 +111,45 @@ void gemm(const Ctx& ctx, const Gemm& g) {
         if (g.atomic) ((float*)g.D)[o] += v;
         else st(g.D, g.ddt, o, v);
       }
+}
+
+static int g_skfuse = 1;
+int skfuse_mode(int set) { const int old = g_skfuse; if (set >= 0) g_skfuse = set ? 1 : 0; return old; }
+bool skinny_fused_supported(const Ctx&, int M, int, int, int) { return g_skfuse && M <= 256; }   // (host loops: any width, either element type)
+void skinny_fused(const Ctx& ctx, const SkFuse& p) {
+  const int E = ctx.mode;
+  std::vector<float> a((size_t)p.M * p.K);
+  for (int m = 0; m < p.M; ++m)
+    for (int k = 0; k < p.K; ++k) {
+      float v;
+      if (p.a_mode == 0) v = ld(p.A, E, (long)m * p.lda + k);
+      else {
+        const float mu = p.a_mul[(long)m * p.ld_mul + k];
+        v = p.a_mode == 1 ? ld(p.A, E, (long)m * p.lda + k) * mu : ((const float*)p.A)[(long)m * p.lda + k] * mu * (1.f - mu);
+        if (E == DT_BF16) v = bf2f(f2bf(v));                   // the operand is rounded to E before it is multiplied
+        if (p.a_store) st(p.a_store, E, (long)m * p.ld_store + k, v);
+      }
+      a[(size_t)m * p.K + k] = v;
+    }
+  for (int m = 0; m < p.M; ++m)
+    for (int n = 0; n < p.N; ++n) {
+      double acc = 0;
+      for (int k = 0; k < p.K; ++k) acc += (double)a[(size_t)m * p.K + k] * ld(p.B, E, p.b_kmajor ? (long)n * p.ldb + k : (long)k * p.ldb + n);
+      for (int k = 0; k < p.K2; ++k)
+        acc += (double)ld(p.A2, E, (long)m * p.lda2 + k) * ld(p.B2, E, p.b2_kmajor ? (long)n * p.ldb2 + k : (long)k * p.ldb2 + n);
+      float v = (float)acc;
+      if (p.bias_n) v += p.bias_n[n];
+      if (p.act == ACT_RELU) v = std::max(v, 0.f);
+      else if (p.act == ACT_SIGMOID) v = sigm(v);
+      if (p.mask && !(ld(p.mask, E, (long)m * p.ldmask + n) > 0.f)) v = 0.f;
+      if (p.epi == 1) {
+        const float q = ld(p.e_q, E, (long)m * p.ld_eq + n);
+        st(p.D, E, (long)m * p.ldd + n, q > 0.f ? v * p.e_mul[(long)m * p.ld_emul + n] : 0.f);
+        p.D2[(long)m * p.ldd2 + n] = v * q;
+      } else {
+        st(p.D, p.ddt, (long)m * p.ldd + n, v);
+      }
+    }
 }
 
 void softmax_rows(const Ctx&, const float* in, long ld_in, void* out, int odt, long ld_out, long rows, int L, int pre_tanh) {
@@ -478,6 +522,14 @@ void bn_finalize(const Ctx&, const float* acc, long rows, int C, const float* w,
   }
 }
 
+static int g_bnfold = 1;
+int bnfold_mode(int set) { const int old = g_bnfold; if (set >= 0) g_bnfold = set ? 1 : 0; return old; }
+void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu);
+void affine_act_bn(const Ctx& ctx, const void* x, void* y, long rows, int C, const BnFin& f, int relu) {
+  bn_finalize(ctx, f.acc, f.rows, C, f.w, f.b, f.run_mean, f.run_var, f.momentum, f.eps, f.training, f.mean, f.rstd, f.sc, f.sh);
+  affine_act(ctx, x, y, rows, C, f.sc, f.sh, relu);
+}
+
 void affine_act(const Ctx& ctx, const void* x, void* y, long rows, int C, const float* sc, const float* sh, int relu) {
   for (long r = 0; r < rows; ++r)
     for (int c = 0; c < C; ++c) {
@@ -519,7 +571,8 @@ void bn_bwd_apply(const Ctx& ctx, const void* dy, const void* x, void* dx, long 
 
 void tail_fwd(const Ctx& ctx, const void* Op, const float* sc2, const float* sh2, const float* lnw, const float* lnb,
               const float* gate, int gate_first, float eps, long rows, int C, void* out, float* mu, float* rstd,
-              const void* residual) {
+              const void* residual, const BnFin* f) {
+  if (f) bn_finalize(ctx, f->acc, f->rows, C, f->w, f->b, f->run_mean, f->run_var, f->momentum, f->eps, f->training, f->mean, f->rstd, f->sc, f->sh);
   std::vector<float> x(C);
   const float gv = gate ? *gate : 1.f;
   for (long r = 0; r < rows; ++r) {

@@ -285,3 +285,106 @@ def test_fused_gate_passes_equal_the_launches_they_replace(shape, flavour, BT):
     if a[5]:        # BatchNorm-1 running statistics (the fused pass sums with its own shift): means relative to the channel's spread
         sd = b[5][1].sqrt()
         assert float(((a[5][0] - b[5][0]).abs() / sd).max()) < 2e-3 and _l2(a[5][1], b[5][1]) < 5e-3
+
+
+@pytest.mark.parametrize("shape,dtype,training", [((144, 512, 256, 384), torch.bfloat16, True), ((64, 768, 36, 1024), torch.bfloat16, True),
+                                                  ((576, 256, 1024, 192), torch.bfloat16, True), ((144, 512, 256, 384), torch.float32, True),
+                                                  ((256, 384, 144, 512), torch.bfloat16, False)])
+def test_bn_finalise_folded_into_its_consumer(shape, dtype, training):
+    """BatchNorm's finalisation (mean / rstd / scale / shift from the batch sums, running statistics) runs inside the pass that
+    applies it -- affine_act_bn for BN1, tail_fwd for BN2 -- instead of as two one-workgroup launches on the dependency chain.
+    Against the unfolded schedule (dgsct_test_tune "bnfold" = 0) on the same inputs: same arithmetic per channel, so outputs,
+    saved BN vectors and running statistics must agree to the last bit or two (fp32: rsqrt / fma contraction differences only)."""
+    N, C, No, Co = shape
+    BT = 10
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS["ave"]})
+    p = O.random_params(cfg, "ave", seed=5, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    gen = torch.Generator().manual_seed(13)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    res = []
+    old = lib.test_tune("bnfold", -1)
+    assert old == 1
+    try:
+        for mode in (1, 0):
+            lib.test_tune("bnfold", mode)
+            params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+            prep = ops.prepare(lib, spec, params, dtype, DEV)
+            out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, training)
+            torch.cuda.synchronize()
+            regs = lib.saved_regions(d)
+            keep = {}
+            for name, n in (("bn1", 4 * (C // cfg.r)), ("bn2", 4 * C)):
+                off, nb = regs[name]
+                keep[name] = saved[off:off + 4 * n].view(torch.float32).clone()
+            dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, None, None)
+            torch.cuda.synchronize()
+            run = [params[PARAM_NAMES.index(n)].clone() for n in ("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var")]
+            res.append((out.float(), dX.float(), dY.float(), keep, run))
+    finally:
+        lib.test_tune("bnfold", old)
+    a, b = res
+    for name in ("bn1", "bn2"):
+        assert _l2(a[3][name], b[3][name]) < 1e-6, (name, _l2(a[3][name], b[3][name]))
+    for ra, rb in zip(a[4], b[4]):
+        assert _l2(ra, rb) < 1e-6
+    tol = 1e-6 if dtype == torch.float32 else 4e-3      # bf16: a last-bit difference of a scale moves a few outputs by one bf16 ulp
+    for i, name in enumerate(("out", "dX", "dY")):
+        assert _l2(a[i], b[i]) < (tol if i == 0 else 10 * tol), (name, _l2(a[i], b[i]))
+
+
+@pytest.mark.parametrize("shape,flavour", [((144, 512, 256, 384), "ave"), ((256, 384, 144, 512), "ave"), ((36, 1024, 64, 768), "ave"),
+                                           ((576, 256, 1024, 192), "pretrain"), ((2304, 128, 4096, 96), "avqa")])
+def test_folded_gate_products_equal_the_launches_they_replace(shape, flavour):
+    """gemm_skinny_fused_k (the operand transforms m1 = aq1 * mean_N vq1 and dpre = dch ch (1 - ch), dm1's two consumers and both `da`
+    products folded into the skinny gate-MLP products) against the separate elementwise + product launches (dgsct_test_tune
+    "skfuse" = 0) on the same inputs, bf16: every rounding point is the same (operands rounded to bf16 once, fp32 accumulation), so
+    only the summation order inside a product differs."""
+    N, C, No, Co = shape
+    BT = 10
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour]})
+    p = O.random_params(cfg, flavour, seed=7, scale=0.577)
+    if cfg.remap == "bicubic":
+        p["_bicubic"] = O.bicubic_matrix(No, N)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(17)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    dMap = torch.randn(BT, N, generator=gen).to(DEV)
+    res = []
+    old = lib.test_tune("skfuse", -1)
+    assert old == 1
+    try:
+        for mode in (1, 0):
+            lib.test_tune("skfuse", mode)
+            params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+            prep = ops.prepare(lib, spec, params, dtype, DEV)
+            out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+            torch.cuda.synchronize()
+            regs = lib.saved_regions(d)
+            keep = {}
+            for name, (n, dt) in {"m1": (BT * C, dtype), "q": (BT * (C // 2), dtype), "ch": (BT * C, torch.float32)}.items():
+                off, nb = regs[name]
+                keep[name] = saved[off:off + n * (4 if dt == torch.float32 else 2)].view(dt).float().clone()
+            dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, None)
+            torch.cuda.synchronize()
+            res.append((out.float(), amap, dX.float(), dY.float(), [g.clone() if g is not None else None for g in grads], keep))
+    finally:
+        lib.test_tune("skfuse", old)
+    a, b = res
+    assert torch.equal(a[5]["m1"], b[5]["m1"])                      # same product, same single rounding
+    assert _l2(a[5]["q"], b[5]["q"]) < 4e-3 and _l2(a[5]["ch"], b[5]["ch"]) < 1e-3
+    for i, name in enumerate(("out", "map")):
+        assert _l2(a[i], b[i]) < 1e-2, (name, _l2(a[i], b[i]))
+    for i, name in ((2, "dX"), (3, "dY")):
+        assert _l2(a[i], b[i]) < 6e-2, (name, _l2(a[i], b[i]))       # un-pinned ReLU masks downstream of q (DESIGN.md 7.1)
+    for name, ga, gb in zip(PARAM_NAMES, a[4], b[4]):
+        if ga is None or ga.float().norm() == 0 or name in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias"):
+            continue
+        assert _l2(ga, gb) < 8e-2, (name, _l2(ga, gb))

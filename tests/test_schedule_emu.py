@@ -60,6 +60,25 @@ def test_schedule_without_the_gate_fusion_fp32(emu, name):
         assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
 
 
+@pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "pretrain", "avqa"])
+def test_schedule_without_the_folded_gate_products_fp32(emu, name):
+    """by default the schedule folds the [BT, C] elementwise launches of the gate-MLP chain into its skinny products (SkFuse:
+    m1 / sigmoid' on the operand, dm1's two consumers in the epilogue, both `da` products in one tile) wherever
+    skinny_fused_supported says so -- everywhere in the emulation; with dgsct_test_tune("skfuse", 0) the same goldens go through
+    the separate launches (the device's fp32 path)"""
+    fx = load_golden(name)
+    old = emu.test_tune("skfuse", 0)
+    try:
+        r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
+    finally:
+        emu.test_tune("skfuse", old)
+    tol = 1e-4
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(r[k], fx[k]) < tol, k
+    for k, g in fx["grads"].items():
+        assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
+
+
 @pytest.mark.parametrize("name", ["ave_orderA", "avs_s4", "avqa"])
 def test_schedule_eval_mode(emu, name):
     fx = load_golden(name)
