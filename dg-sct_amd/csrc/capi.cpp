@@ -262,6 +262,7 @@ int dgsct_test_tune(const char* key, int value) {
   if (key && !strcmp(key, "gatefuse")) return gatefuse_mode(value);
   if (key && !strcmp(key, "bnfold")) return bnfold_mode(value);
   if (key && !strcmp(key, "skfuse")) return skfuse_mode(value);
+  if (key && !strcmp(key, "vq1fuse")) return vq1fuse_mode(value);
   if (key && !strcmp(key, "callprof")) {
     if (value == 2) { call_prof_dump(getenv("DGSCT_CALL_PROF") ? getenv("DGSCT_CALL_PROF") : "/tmp/dgsct_callprof.txt"); return 0; }
     return call_prof_mode(value);

@@ -791,8 +791,285 @@ __global__ __launch_bounds__(256) void gate_bwd_finish_k(const GFin p) {
   if (dst) *dst += s;
 }
 
+// =====================================================================================================================
+// Channel-gate query vq1 = relu(X1 Wv1^T + bv1) without the tensor (net_trans.py:593-594 and their autograd), C in {96, 128}.
+// The forward only wants mean_N vq1 per frame and the backward only  dvq1 = (vq1 > 0) * coef_b / N  -- a [rows, C] tensor written,
+// re-read by a column sum, re-read and rewritten by the ReLU backward and re-read twice by the two products behind it (126 MB a
+// pass at stage 0).  Here:
+//   vq1_fwd_k: one pass over X1: the product in token-rows-as-M orientation (the lane holds an output CHANNEL: the sum over tokens
+//              is an in-lane sum of the 16 accumulator registers), ReLU, per-(frame, channel) sums.  Nothing else is stored.
+//   vq1_bwd_k: one pass over X1 and dX1: the same product again (same operands, same MFMA order: same bits, same ReLU decisions),
+//              dvq1 = mask * bf16(coef_b / N), d bv1 += dvq1, dX1 += dvq1 Wv1 in place (the weight image read MN-major), and dvq1
+//              leaves once for the dWv1 product on the aux stream.
+template <int C_>
+struct VG {
+  static constexpr int C = C_, KS = C / 16, NT = C / 32, PW = C * 2 + 16, NV = C / 16, CPR = C / 8;
+  static constexpr int W_BYTES = C * PW, XIMG = 32 * PW;
+  static constexpr int SMEM_F = W_BYTES + 4 * XIMG + (C + 4 * C) * 4;
+  static constexpr int SMEM_B = W_BYTES + 8 * XIMG + (2 * C + 4 * C) * 4;
+  static_assert(SMEM_B <= 160 * 1024, "LDS budget");
+};
+struct VF { const unsigned short* X1; const unsigned short* W; const float* bias; int N, wpf; float invN; float* msum; unsigned short* vq1; };
+struct VB {
+  const unsigned short* X1; const unsigned short* W; const float* bias; const float* coef; int B, N, wpf; float invN;
+  unsigned short* dX1; unsigned short* dvq1; float* part;
+};
+
+template <int C>
+__device__ __forceinline__ void vg_build(char* wimg, float* bs, const unsigned short* W, const float* bias, int tid) {
+  using G = VG<C>;
+  for (int i = tid; i < C * G::CPR; i += 256) {
+    const int j = i / G::CPR, c8 = i - j * G::CPR;
+    *reinterpret_cast<uint4*>(wimg + j * G::PW + c8 * 16) = *reinterpret_cast<const uint4*>(W + (long)j * C + c8 * 8);
+  }
+  for (int i = tid; i < C; i += 256) bs[i] = bias[i];
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void vq1_fwd_k(const VF p) {
+  using G = VG<C>;
+  __shared__ __attribute__((aligned(16))) char smem[G::SMEM_F];
+  char* wimg = smem;
+  char* ximg0 = wimg + G::W_BYTES;
+  float* bs = reinterpret_cast<float*>(ximg0 + 4 * G::XIMG);
+  float* red = bs + C;                                       // [4][C]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, tl = lane & 31;
+  const int b = blockIdx.y;
+  vg_build<C>(wimg, bs, p.W, p.bias, tid);
+  __syncthreads();
+  const int nblk = p.N / 32, stride = p.wpf * 4;
+  char* img = ximg0 + wave * G::XIMG;
+  const long frame0 = (long)b * p.N;
+  fg_u32x4 nx[G::NV];
+  int blk = blockIdx.x * 4 + wave;
+  fg_gload<G::NV>(nx, p.X1 + (frame0 + (long)(blk < nblk ? blk : nblk - 1) * 32) * C, lane);
+  float a_s[G::NT], bb[G::NT];
+#pragma unroll
+  for (int jt = 0; jt < G::NT; ++jt) { a_s[jt] = 0.f; bb[jt] = bs[32 * jt + tl]; }
+  for (; blk < nblk; blk += stride) {
+#pragma unroll
+    for (int i = 0; i < G::NV; ++i) {
+      const int idx = i * 64 + lane, r = idx / G::CPR, c8 = idx - r * G::CPR;
+      *reinterpret_cast<fg_u32x4*>(img + r * G::PW + c8 * 16) = nx[i];
+    }
+    fg_wave_sync();
+    fg_gload<G::NV>(nx, p.X1 + (frame0 + (long)(blk + stride < nblk ? blk + stride : nblk - 1) * 32) * C, lane);
+    const char* arow = img + tl * G::PW + h * 16;
+#pragma unroll
+    for (int jt = 0; jt < G::NT; ++jt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* brow = wimg + (32 * jt + tl) * G::PW + h * 16;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg_lds8(arow + kk * 32), fg_lds8(brow + kk * 32), acc, 0, 0, 0);
+      float sv = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv += fmaxf(acc[r] + bb[jt], 0.f);
+      a_s[jt] += sv;
+      if (p.vq1) {                                           // test mode ("vq1fuse" = 2): the tensor as well, for tests that pin the ReLU masks
+        const long row0 = frame0 + (long)blk * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.vq1[(row0 + mt_row(r, lane)) * C + 32 * jt + tl] = f2bf(fmaxf(acc[r] + bb[jt], 0.f));
+      }
+    }
+    fg_wave_sync();
+  }
+#pragma unroll
+  for (int jt = 0; jt < G::NT; ++jt) {
+    const float v = a_s[jt] + fg_xor32(a_s[jt]);
+    if (lane < 32) red[wave * C + 32 * jt + tl] = v;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256)
+    unsafeAtomicAdd(p.msum + (long)b * C + c, p.invN * ((red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c])));
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void vq1_bwd_k(const VB p) {
+  using G = VG<C>;
+  __shared__ __attribute__((aligned(16))) char smem[G::SMEM_B];
+  char* wimg = smem;
+  char* wave0 = wimg + G::W_BYTES;
+  float* bs = reinterpret_cast<float*>(wave0 + 8 * G::XIMG);
+  float* cn = bs + C;
+  float* red = cn + C;                                       // [4][C]
+  const int tid = threadIdx.x, lane_ = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  vg_build<C>(wimg, bs, p.W, p.bias, tid);
+  // work items = (frame, part of the frame), one workgroup per CU walking items blockIdx.x, + gridDim.x, ... (as gatemod_bwd_k)
+  const int nitems = p.B * p.wpf;
+  float keep = 0.f;                                          // thread c < C: d bv1[c] over this workgroup's items
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const int b = item / p.wpf, part = item - b * p.wpf;
+  __syncthreads();                                           // the previous item's reduction has read cn / red (and wimg is built)
+  for (int i = tid; i < C; i += 256) cn[i] = bf2f(f2bf(p.invN * p.coef[(long)b * C + i]));      // dvq1's one non-zero value per (frame, channel), as stored
+  __syncthreads();
+  const int nblk = p.N / 32, stride = p.wpf * 4;
+  char* ximg = wave0 + wave * 2 * G::XIMG;
+  char* dvimg = ximg + G::XIMG;
+  const long frame0 = (long)b * p.N;
+  fg_u32x4 nx[G::NV], ndx[G::NV];
+  int blk = part * 4 + wave;
+  {
+    const long r0 = frame0 + (long)(blk < nblk ? blk : nblk - 1) * 32;
+    fg_gload<G::NV>(nx, p.X1 + r0 * C, lane_);
+    fg_gload<G::NV>(ndx, p.dX1 + r0 * C, lane_);
+  }
+  float a_bv[G::NT];
+#pragma unroll
+  for (int jt = 0; jt < G::NT; ++jt) a_bv[jt] = 0.f;
+  for (; blk < nblk; blk += stride) {
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));                           // (per-lane addresses recomputed per block instead of hoisted into 100 VGPRs: see gatemod_bwd_k)
+    const int h = lane >> 5, tl = lane & 31;
+    char* const xcol = ximg + 4 * h * G::PW + tl * 2;
+    char* const dvcol = dvimg + 4 * h * G::PW + tl * 2;
+    const long r0 = frame0 + (long)blk * 32;
+#pragma unroll
+    for (int i = 0; i < G::NV; ++i) {
+      const int idx = i * 64 + lane, r = idx / G::CPR, c8 = idx - r * G::CPR;
+      *reinterpret_cast<fg_u32x4*>(ximg + r * G::PW + c8 * 16) = nx[i];
+    }
+    fg_wave_sync();
+    // ---- vq1 again (token rows x Wv1 rows: the forward's product), dvq1 = mask * cn, d bv1
+    const char* arow = ximg + tl * G::PW + h * 16;
+#pragma unroll
+    for (int jt = 0; jt < G::NT; ++jt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* brow = wimg + (32 * jt + tl) * G::PW + h * 16;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg_lds8(arow + kk * 32), fg_lds8(brow + kk * 32), acc, 0, 0, 0);
+      const int c = 32 * jt + tl;
+      const float bb = bs[c], cv = cn[c];
+      const unsigned short cvb = f2bf(cv);
+      float sv = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool on = acc[r] + bb > 0.f;
+        sv += on ? cv : 0.f;
+        *reinterpret_cast<unsigned short*>(dvcol + ((r & 3) + 8 * (r >> 2)) * G::PW + 64 * jt) = on ? cvb : (unsigned short)0;
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      a_bv[jt] += sv;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fg_wave_sync();
+    // X1's image is dead: the block's dX1 rows take its place; dvq1 rows leave as 16-byte stores
+    {
+      fg_u32x4* dst = reinterpret_cast<fg_u32x4*>(p.dvq1 + r0 * C);
+#pragma unroll
+      for (int i = 0; i < G::NV; ++i) {
+        const int idx = i * 64 + lane, r = idx / G::CPR, c8 = idx - r * G::CPR;
+        dst[idx] = *reinterpret_cast<const fg_u32x4*>(dvimg + r * G::PW + c8 * 16);
+        *reinterpret_cast<fg_u32x4*>(ximg + r * G::PW + c8 * 16) = ndx[i];
+      }
+    }
+    fg_wave_sync();
+    {
+      const long rn = frame0 + (long)(blk + stride < nblk ? blk + stride : nblk - 1) * 32;
+      fg_gload<G::NV>(nx, p.X1 + rn * C, lane);
+      fg_gload<G::NV>(ndx, p.dX1 + rn * C, lane);
+    }
+    // ---- dX1 += dvq1 Wv1
+    const char* drow = dvimg + tl * G::PW + h * 16;
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg_lds8(drow + kk * 32), mt_frag_mn(wimg, G::PW, 32 * nt, kk, lane), acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        char* px = xcol + ((r & 3) + 8 * (r >> 2)) * G::PW + 64 * nt;
+        *reinterpret_cast<unsigned short*>(px) = f2bf(bf2f(fg_ldsu16(px)) + acc[r]);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fg_wave_sync();
+    {
+      fg_u32x4* dst = reinterpret_cast<fg_u32x4*>(p.dX1 + r0 * C);
+#pragma unroll
+      for (int i = 0; i < G::NV; ++i) {
+        const int idx = i * 64 + lane, r = idx / G::CPR, c8 = idx - r * G::CPR;
+        dst[idx] = *reinterpret_cast<const fg_u32x4*>(ximg + r * G::PW + c8 * 16);
+      }
+    }
+    fg_wave_sync();
+  }
+  {
+    const int tl = lane_ & 31;
+#pragma unroll
+    for (int jt = 0; jt < G::NT; ++jt) {
+      const float v = a_bv[jt] + fg_xor32(a_bv[jt]);
+      if (lane_ < 32) red[wave * C + 32 * jt + tl] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < C) keep += (red[tid] + red[C + tid]) + (red[2 * C + tid] + red[3 * C + tid]);
+  }   // items
+  if (tid < C) p.part[(long)blockIdx.x * C + tid] = keep;
+}
+
+std::atomic<int> g_vq1fuse{-1};
 std::atomic<int> g_gatefuse{-1};
 }  // namespace
+
+int vq1fuse_mode(int set) {
+  if (g_vq1fuse.load(std::memory_order_relaxed) < 0) g_vq1fuse.store(getenv("DGSCT_NO_VQ1FUSE") ? 0 : 1, std::memory_order_relaxed);
+  const int old = g_vq1fuse.load(std::memory_order_relaxed);
+  if (set >= 0) g_vq1fuse.store(set > 2 ? 1 : set, std::memory_order_relaxed);      // 2: fused, and the forward also stores vq1 (tests)
+  return old;
+}
+bool vq1_fused_supported(int mode, int N, int C) {
+  return vq1fuse_mode(-1) && mode == DT_BF16 && (C == 96 || C == 128) && N >= 32 && N % 32 == 0;
+}
+static int vq1_wpf(const void* kern, int B, int N) {
+  int cap = wg_capacity(kern, 0);
+  int wpf = cap / B;
+  const int maxw = (N / 32 + 7) / 8;                         // >= 2 blocks per wave
+  if (wpf > maxw) wpf = maxw;
+  return wpf < 1 ? 1 : wpf;
+}
+void vq1sum_fwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, int B, int N, int C, float invN, float* msum, void* vq1) {
+  VF a{(const unsigned short*)X1, (const unsigned short*)Wv1, bv1, N, 1, invN, msum, (unsigned short*)vq1};
+  auto launch = [&](auto kern) {
+    a.wpf = vq1_wpf(reinterpret_cast<const void*>(kern), B, N);
+    hipLaunchKernelGGL(kern, dim3(a.wpf, B), dim3(256), 0, (hipStream_t)ctx.stream, a);
+  };
+  if (C == 96) launch(vq1_fwd_k<96>); else if (C == 128) launch(vq1_fwd_k<128>); else set_error("vq1sum_fwd: unsupported width %d", C);
+}
+void vq1_bwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, const float* coef, int B, int N, int C, float invN,
+             void* dX1, void* dvq1, float* dbv1, float* part, long part_floats) {
+  VB a{(const unsigned short*)X1, (const unsigned short*)Wv1, bv1, coef, B, N, 1, invN, (unsigned short*)dX1, (unsigned short*)dvq1, part};
+  auto launch = [&](auto kern) {
+    // parts per frame: >= 2 blocks per wave of an item, the items filling whole rounds of the resident workgroups (gatemod_bwd's rule)
+    const int cap = wg_capacity(reinterpret_cast<const void*>(kern), 0);
+    int maxw = (N / 32) / 8; if (maxw < 1) maxw = 1;
+    int best = 1; double be = -1;
+    for (int w = 1; w <= maxw; ++w) {
+      const long items = (long)B * w;
+      const double e = (double)items / (double)(((items + cap - 1) / cap) * cap);
+      if (e > be + 1e-9) { be = e; best = w; }
+    }
+    a.wpf = best;
+    const long items = (long)B * best;
+    const int nwg = (int)(items < cap ? items : cap);
+    if ((long)nwg * C > part_floats) { set_error("vq1_bwd: partial-sum scratch too small"); return; }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, (hipStream_t)ctx.stream, a);
+    PartJob j; j.part = part; j.n = 1; j.t.NQ = 1; j.t.C = C;
+    j.t.d[0] = PartDesc{0, 1, nwg, 1, dbv1, 0, 1.f};
+    if (ctx.late) *ctx.late = j;                             // a bias gradient: its second stage may run on the aux stream
+    else part_reduce_run(ctx.stream, j);
+  };
+  if (C == 96) launch(vq1_bwd_k<96>); else if (C == 128) launch(vq1_bwd_k<128>); else set_error("vq1_bwd: unsupported width %d", C);
+}
+
 
 int gatefuse_mode(int set) {
   if (g_gatefuse.load(std::memory_order_relaxed) < 0) g_gatefuse.store(getenv("DGSCT_NO_GATEFUSE") ? 0 : 1, std::memory_order_relaxed);

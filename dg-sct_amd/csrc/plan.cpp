@@ -384,12 +384,19 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1), tokpk);
   // F4-F6 ---- channel gate                                              :593-598
   {
-    Gemm g3 = mk((int)R, C, C);                                  // vq1 = relu(X1 Wv1^T + b)
-    g3.A = km(b.S(s.X1), C); g3.B = km(b.W(DGSCT_P_WV1), C); g3.bias_n = b.F(DGSCT_P_BV1); g3.act = ACT_RELU;
-    outE(g3, b.S(s.vq1), E, C);
-    if (fp8) gemm_fp8(ctx, (int)R, C, C, b.S(s.X1), C, b.prep + prep_w8[1], (const float*)(b.prep + prep_w8scale) + 1, b.F(DGSCT_P_BV1), 1, b.S(s.vq1), C);
-    else gemm(ctx, g3);
-    colsum_batched(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C);
+    if (vq1_fused_supported(ctx.mode, N, C) && !fp8) {
+      // stages 0 (C = 96 / 128): only mean_N vq1 exists -- one pass over X1, the [rows, C] tensor is never written (the backward
+      // recomputes the ReLU decisions from X1: vq1_bwd)
+      vq1sum_fwd(ctx, b.S(s.X1), b.W(DGSCT_P_WV1), b.F(DGSCT_P_BV1), B, N, C, invN, b.S<float>(s.mvq1),
+                 vq1fuse_mode(-1) == 2 ? b.S(s.vq1) : nullptr);
+    } else {
+      Gemm g3 = mk((int)R, C, C);                                // vq1 = relu(X1 Wv1^T + b)
+      g3.A = km(b.S(s.X1), C); g3.B = km(b.W(DGSCT_P_WV1), C); g3.bias_n = b.F(DGSCT_P_BV1); g3.act = ACT_RELU;
+      outE(g3, b.S(s.vq1), E, C);
+      if (fp8) gemm_fp8(ctx, (int)R, C, C, b.S(s.X1), C, b.prep + prep_w8[1], (const float*)(b.prep + prep_w8scale) + 1, b.F(DGSCT_P_BV1), 1, b.S(s.vq1), C);
+      else gemm(ctx, g3);
+      colsum_batched(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C);
+    }
     stream_join(ctx);                                            // aq1 / aq2 / a from the aux stream
     if (skinny_fused_supported(ctx, B, dd, C, 0)) {              // q = relu(m1 Wb^T + b), m1 = aq1 * mean_N vq1 made (and stored) on the way in
       SkFuse f; f.M = B; f.N = dd; f.K = C;
@@ -689,6 +696,14 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   }
   // B5 ---- video query 1
   {
+    if (vq1_fused_supported(ctx.mode, N, C) && !fp8) {
+      // the forward kept no vq1: ReLU decisions recomputed from X1, dvq1 (into vq1's region, for dWv1 below), d bias, dX1 += dvq1 . Wv1
+      PartJob pj;
+      Ctx cl = ctx; cl.late = aux_stream ? &pj : nullptr;
+      vq1_bwd(cl, b.S(s.X1), b.W(DGSCT_P_WV1), b.F(DGSCT_P_BV1), b.Wk<float>(wb.coef), B, N, C, 1.f / (float)N, dX1, b.S(s.vq1),
+              G(DGSCT_P_BV1), b.Wk<float>(wb.rowpart_v1), row_part_floats(B, C));
+      if (pj.n) defer([=, &side] { part_reduce_run(side.stream, pj); });
+    } else {
     {
       PartJob pj;                                                // d bias(vq1), likewise
       Ctx cl = ctx; cl.late = aux_stream ? &pj : nullptr;
@@ -701,6 +716,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     resid(g1, dX1, E, C);
     outE(g1, dX1, E, C);
     gemm(ctx, g1);
+    }
     Gemm g2 = mk(C, C, (int)R);                                  // dWv1 = dvq1^T . X1
     g2.A = mn(b.S(s.vq1), C); g2.B = mn(b.S(s.X1), C);
     outF(g2, G(DGSCT_P_WV1), C);

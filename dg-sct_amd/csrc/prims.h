@@ -201,6 +201,16 @@ void gatemod_fwd(const Ctx&, const void* X1, const float* ch, const void* aq2, c
 //        dch [B][C] +=, u [B][C/2] += sum_n dsl vq2, dtg [B] += (tg != null), dlnw / dlnb [C] += (lnw != null), dbv2 [C/2] +=, *dbs +=
 //   mapdot_scratch: B floats; part: gate_bwd_part_floats(B, C) floats of scratch.
 bool gate_bwd_fused_supported(int mode, int N, int C, int ds, int g);
+// vq1 = relu(X1 Wv1^T + bv1) without the tensor (fused_gate.hip; bf16, C in {96, 128}; dgsct_test_tune "vq1fuse"):
+//   vq1sum_fwd: msum[b][c] += invN * sum_n vq1[b][n][c]          (Wv1: the prepared E copy, K-major [C][C])
+//   vq1_bwd:    dvq1 = (vq1 > 0) * E(coef[b][c] * invN) (written, E), dbv1[c] += sum dvq1, dX1 += dvq1 Wv1 (in place, E)
+//               part: >= 1024 * C floats of scratch; with ctx.late set the second stage of dbv1 is left to the caller
+int vq1fuse_mode(int set);
+bool vq1_fused_supported(int mode, int N, int C);
+void vq1sum_fwd(const Ctx&, const void* X1, const void* Wv1, const float* bv1, int B, int N, int C, float invN, float* msum,
+                void* vq1 = nullptr);     // vq1: test mode ("vq1fuse" = 2), the tensor is stored as well
+void vq1_bwd(const Ctx&, const void* X1, const void* Wv1, const float* bv1, const float* coef, int B, int N, int C, float invN,
+             void* dX1, void* dvq1, float* dbv1, float* part, long part_floats);
 // the same test without the tuning switch: what the buffer LAYOUT keys on (Xc is scratch, not a saved activation, for these shapes)
 bool gate_bwd_fused_shape(int mode, int N, int C, int ds, int g);
 long gate_bwd_part_floats(int B, int C);

@@ -113,6 +113,46 @@ void gemm(const Ctx& ctx, const Gemm& g) {
       }
 }
 
+static int g_vq1fuse = 1;
+int vq1fuse_mode(int set) { const int old = g_vq1fuse; if (set >= 0) g_vq1fuse = set > 2 ? 1 : set; return old; }
+bool vq1_fused_supported(int, int, int) { return g_vq1fuse != 0; }     // (host loops: any shape, either element type)
+void vq1sum_fwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, int B, int N, int C, float invN, float* msum, void* vq1) {
+  const int E = ctx.mode;
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      double sum = 0;
+      for (int n = 0; n < N; ++n) {
+        double acc = 0;
+        for (int k = 0; k < C; ++k) acc += (double)ld(X1, E, ((long)b * N + n) * C + k) * ld(Wv1, E, (long)c * C + k);
+        sum += std::max((float)acc + bv1[c], 0.f);
+        if (vq1) st(vq1, E, ((long)b * N + n) * C + c, std::max((float)acc + bv1[c], 0.f));
+      }
+      msum[(long)b * C + c] += invN * (float)sum;
+    }
+}
+void vq1_bwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, const float* coef, int B, int N, int C, float invN,
+             void* dX1, void* dvq1, float* dbv1, float*, long) {
+  const int E = ctx.mode;
+  std::vector<float> dv(C);
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      const long row = (long)b * N + n;
+      for (int c = 0; c < C; ++c) {
+        double acc = 0;
+        for (int k = 0; k < C; ++k) acc += (double)ld(X1, E, row * C + k) * ld(Wv1, E, (long)c * C + k);
+        float v = (float)acc + bv1[c] > 0.f ? invN * coef[(long)b * C + c] : 0.f;
+        st(dvq1, E, row * C + c, v);
+        dv[c] = ld(dvq1, E, row * C + c);
+        dbv1[c] += dv[c];
+      }
+      for (int k = 0; k < C; ++k) {
+        double acc = 0;
+        for (int c = 0; c < C; ++c) acc += (double)dv[c] * ld(Wv1, E, (long)c * C + k);
+        st(dX1, E, row * C + k, ld(dX1, E, row * C + k) + (float)acc);
+      }
+    }
+}
+
 static int g_skfuse = 1;
 int skfuse_mode(int set) { const int old = g_skfuse; if (set >= 0) g_skfuse = set ? 1 : 0; return old; }
 bool skinny_fused_supported(const Ctx&, int M, int, int, int) { return g_skfuse && M <= 256; }   // (host loops: any width, either element type)

@@ -74,12 +74,15 @@ def test_bf16_backward_with_device_relu_masks(case):
     prep = ops.prepare(lib, spec, params, dt, DEV)
     # (the fused gate passes of stages 0-1 recompute vq2 in backward instead of storing it: "gatefuse" = 2 makes the forward
     #  materialise it as well, so that the device's ReLU decisions can be read back)
+    # (likewise vq1 at C = 96 / 128: "vq1fuse" = 2)
     old = lib.test_tune("gatefuse", 2)
+    old1 = lib.test_tune("vq1fuse", 2)
     try:
         out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
         torch.cuda.synchronize()
     finally:
         lib.test_tune("gatefuse", old)
+        lib.test_tune("vq1fuse", old1)
     masks = device_relu_masks(lib, d, saved, spec, BT, dt)
     dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(DEV, dt).contiguous(), dMap.to(DEV), None)
     torch.cuda.synchronize()

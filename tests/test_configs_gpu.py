@@ -388,3 +388,53 @@ def test_folded_gate_products_equal_the_launches_they_replace(shape, flavour):
         if ga is None or ga.float().norm() == 0 or name in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias"):
             continue
         assert _l2(ga, gb) < 8e-2, (name, _l2(ga, gb))
+
+
+@pytest.mark.parametrize("shape,flavour,BT", [((4096, 96, 2304, 128), "ave", 10), ((2304, 128, 4096, 96), "ave", 10), ((2304, 128, 4096, 96), "pretrain", 10),
+                                              ((4096, 96, 2304, 128), "avqa", 20), ((1024, 96, 576, 128), "ave", 7)])
+def test_vq1_without_the_tensor_equals_the_launches_it_replaces(shape, flavour, BT):
+    """vq1_fwd_k / vq1_bwd_k (stage 0, bf16: mean_N relu(X1 Wv1^T + b) in one pass over X1 with nothing stored; the backward recomputes
+    the ReLU decisions and applies dX1 += dvq1 Wv1 in place) against product + column sum / ReLU backward + product (dgsct_test_tune
+    "vq1fuse" = 0) on the same inputs.  Forward: the fused pass sums fp32 values, the unfused one bf16-rounded ones (mvq1 agrees to
+    ~1e-3).  Backward: same ReLU decisions (same product bits) and the same single rounding of dvq1 and of dX1."""
+    N, C, No, Co = shape
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour]})
+    p = O.random_params(cfg, flavour, seed=9, scale=0.577)
+    if cfg.remap == "bicubic":
+        p["_bicubic"] = O.bicubic_matrix(No, N)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(19)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    dMap = torch.randn(BT, N, generator=gen).to(DEV)
+    res = []
+    old = lib.test_tune("vq1fuse", -1)
+    assert old == 1
+    try:
+        for mode in (1, 0):
+            lib.test_tune("vq1fuse", mode)
+            params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+            prep = ops.prepare(lib, spec, params, dtype, DEV)
+            out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+            torch.cuda.synchronize()
+            regs = lib.saved_regions(d)
+            off, nb = regs["mvq1"]
+            mvq1 = saved[off:off + 4 * BT * C].view(torch.float32).clone()
+            dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, None)
+            torch.cuda.synchronize()
+            res.append((out.float(), amap, dX.float(), dY.float(), [g.clone() if g is not None else None for g in grads], mvq1))
+    finally:
+        lib.test_tune("vq1fuse", old)
+    a, b = res
+    assert _l2(a[5], b[5]) < 2e-3, _l2(a[5], b[5])
+    for i, name in enumerate(("out", "map")):
+        assert _l2(a[i], b[i]) < 1e-2, (name, _l2(a[i], b[i]))
+    for i, name in ((2, "dX"), (3, "dY")):
+        assert _l2(a[i], b[i]) < 6e-2, (name, _l2(a[i], b[i]))       # un-pinned ReLU masks downstream of the gate (DESIGN.md 7.1)
+    for name, ga, gb in zip(PARAM_NAMES, a[4], b[4]):
+        if ga is None or ga.float().norm() == 0 or name in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias"):
+            continue
+        assert _l2(ga, gb) < 8e-2, (name, _l2(ga, gb))

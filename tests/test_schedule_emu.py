@@ -79,6 +79,24 @@ def test_schedule_without_the_folded_gate_products_fp32(emu, name):
         assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
 
 
+@pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "pretrain", "avs_s4"])
+def test_schedule_with_vq1_materialised_fp32(emu, name):
+    """by default the emulation takes the schedule branch in which vq1 = relu(X1 Wv1^T + b) is never stored (vq1sum_fwd /
+    vq1_bwd: the device's stage-0 path); with dgsct_test_tune("vq1fuse", 0) the same goldens go through the product + column sum +
+    ReLU backward + product launches"""
+    fx = load_golden(name)
+    old = emu.test_tune("vq1fuse", 0)
+    try:
+        r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
+    finally:
+        emu.test_tune("vq1fuse", old)
+    tol = 1e-4
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(r[k], fx[k]) < tol, k
+    for k, g in fx["grads"].items():
+        assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
+
+
 @pytest.mark.parametrize("name", ["ave_orderA", "avs_s4", "avqa"])
 def test_schedule_eval_mode(emu, name):
     fx = load_golden(name)
