@@ -808,11 +808,13 @@ struct VG {
   static constexpr int SMEM_F = W_BYTES + 4 * XIMG + (C + 4 * C) * 4;
   static constexpr int SMEM_B = W_BYTES + 8 * XIMG + (2 * C + 4 * C) * 4;
   static_assert(SMEM_B <= 160 * 1024, "LDS budget");
+  static_assert(8 * XIMG >= C * C * 4, "the wave images double as the dWv1 reduction scratch");
 };
 struct VF { const unsigned short* X1; const unsigned short* W; const float* bias; int N, wpf; float invN; float* msum; unsigned short* vq1; };
 struct VB {
   const unsigned short* X1; const unsigned short* W; const float* bias; const float* coef; int B, N, wpf; float invN;
   unsigned short* dX1; unsigned short* dvq1; float* part;
+  float* wpart;        // DW: [workgroup][C][C] partial dWv1 (dvq1 is then not written at all)
 };
 
 template <int C>
@@ -886,7 +888,10 @@ __global__ __launch_bounds__(256) void vq1_fwd_k(const VF p) {
     unsafeAtomicAdd(p.msum + (long)b * C + c, p.invN * ((red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c])));
 }
 
-template <int C>
+// DW (experiment, "vq1fuse" = 3, off by default: slower, see plan.cpp B5): dWv1 = dvq1^T X1 accumulated HERE (both operands read
+// MN-major from the block's two images, C x C fp32 accumulators per wave: 144 / 256 registers) -- dvq1 never reaches HBM and the
+// weight-gradient product of the aux stream disappears.
+template <int C, bool DW>
 __global__ __launch_bounds__(256) void vq1_bwd_k(const VB p) {
   using G = VG<C>;
   __shared__ __attribute__((aligned(16))) char smem[G::SMEM_B];
@@ -900,6 +905,13 @@ __global__ __launch_bounds__(256) void vq1_bwd_k(const VB p) {
   // work items = (frame, part of the frame), one workgroup per CU walking items blockIdx.x, + gridDim.x, ... (as gatemod_bwd_k)
   const int nitems = p.B * p.wpf;
   float keep = 0.f;                                          // thread c < C: d bv1[c] over this workgroup's items
+  f32x16 accw[DW ? G::NT : 1][DW ? G::NT : 1];               // dWv1 tile (c_out tile, c_in tile), over all of this wave's blocks
+#pragma unroll
+  for (int i = 0; i < (DW ? G::NT : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (DW ? G::NT : 1); ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw[i][j][r] = 0.f;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
   const int b = item / p.wpf, part = item - b * p.wpf;
   __syncthreads();                                           // the previous item's reduction has read cn / red (and wimg is built)
@@ -957,13 +969,29 @@ __global__ __launch_bounds__(256) void vq1_bwd_k(const VB p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     fg_wave_sync();
-    // X1's image is dead: the block's dX1 rows take its place; dvq1 rows leave as 16-byte stores
+    if (DW) {                                                // dWv1 += dvq1^T X1: contraction over the block's 32 tokens (two k-steps)
+      // (operand fragments re-read per tile: held for the whole block they are 2 x 8 NT registers next to NT^2 x 16 accumulators --
+      //  at C = 128 that spilled)
+#pragma unroll
+      for (int jt = 0; jt < G::NT; ++jt) {
+        const bfx8 a0 = mt_frag_mn(dvimg, G::PW, 32 * jt, 0, lane), a1 = mt_frag_mn(dvimg, G::PW, 32 * jt, 1, lane);
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt) {
+          const bfx8 b0 = mt_frag_mn(ximg, G::PW, 32 * nt, 0, lane), b1 = mt_frag_mn(ximg, G::PW, 32 * nt, 1, lane);
+          accw[jt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, accw[jt][nt], 0, 0, 0);
+          accw[jt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, accw[jt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      fg_wave_sync();                                        // every lane is done with X1's image
+    }
+    // X1's image is dead: the block's dX1 rows take its place; dvq1 rows leave as 16-byte stores (unless dWv1 is made here)
     {
       fg_u32x4* dst = reinterpret_cast<fg_u32x4*>(p.dvq1 + r0 * C);
 #pragma unroll
       for (int i = 0; i < G::NV; ++i) {
         const int idx = i * 64 + lane, r = idx / G::CPR, c8 = idx - r * G::CPR;
-        dst[idx] = *reinterpret_cast<const fg_u32x4*>(dvimg + r * G::PW + c8 * 16);
+        if (!DW) dst[idx] = *reinterpret_cast<const fg_u32x4*>(dvimg + r * G::PW + c8 * 16);
         *reinterpret_cast<fg_u32x4*>(ximg + r * G::PW + c8 * 16) = ndx[i];
       }
     }
@@ -1014,6 +1042,25 @@ __global__ __launch_bounds__(256) void vq1_bwd_k(const VB p) {
   if (tid < C) keep += (red[tid] + red[C + tid]) + (red[2 * C + tid] + red[3 * C + tid]);
   }   // items
   if (tid < C) p.part[(long)blockIdx.x * C + tid] = keep;
+  if (DW) {   // the four waves' C x C tiles meet in LDS (the wave images are free now), one partial matrix per workgroup leaves
+    float* wred = reinterpret_cast<float*>(wave0);
+    const int h = lane_ >> 5, tl = lane_ & 31;
+    __syncthreads();
+    for (int i = tid; i < C * C / 4; i += 256) reinterpret_cast<float4*>(wred)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < G::NT; ++jt)
+#pragma unroll
+      for (int nt = 0; nt < G::NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)                         // (LDS float add: the four waves in any order)
+          atomicAdd(wred + (32 * jt + (r & 3) + 8 * (r >> 2) + 4 * h) * C + 32 * nt + tl, accw[jt][nt][r]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(p.wpart + (long)blockIdx.x * C * C);
+    for (int i = tid; i < C * C / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(wred)[i];
+  }
 }
 
 std::atomic<int> g_vq1fuse{-1};
@@ -1023,12 +1070,11 @@ std::atomic<int> g_gatefuse{-1};
 int vq1fuse_mode(int set) {
   if (g_vq1fuse.load(std::memory_order_relaxed) < 0) g_vq1fuse.store(getenv("DGSCT_NO_VQ1FUSE") ? 0 : 1, std::memory_order_relaxed);
   const int old = g_vq1fuse.load(std::memory_order_relaxed);
-  if (set >= 0) g_vq1fuse.store(set > 2 ? 1 : set, std::memory_order_relaxed);      // 2: fused, and the forward also stores vq1 (tests)
+  if (set >= 0) g_vq1fuse.store(set > 3 ? 1 : set, std::memory_order_relaxed);      // 2: fused, and the forward also stores vq1 (tests); 3: dWv1 accumulated inside vq1_bwd_k (experiment, slower)
   return old;
 }
-bool vq1_fused_supported(int mode, int N, int C) {
-  return vq1fuse_mode(-1) && mode == DT_BF16 && (C == 96 || C == 128) && N >= 32 && N % 32 == 0;
-}
+bool vq1_fused_shape(int mode, int N, int C) { return mode == DT_BF16 && (C == 96 || C == 128) && N >= 32 && N % 32 == 0; }
+bool vq1_fused_supported(int mode, int N, int C) { return vq1fuse_mode(-1) && vq1_fused_shape(mode, N, C); }
 static int vq1_wpf(const void* kern, int B, int N) {
   int cap = wg_capacity(kern, 0);
   int wpf = cap / B;
@@ -1044,9 +1090,12 @@ void vq1sum_fwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv
   };
   if (C == 96) launch(vq1_fwd_k<96>); else if (C == 128) launch(vq1_fwd_k<128>); else set_error("vq1sum_fwd: unsupported width %d", C);
 }
+long vq1_wpart_floats(int C) { return (long)512 * C * C; }
 void vq1_bwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, const float* coef, int B, int N, int C, float invN,
-             void* dX1, void* dvq1, float* dbv1, float* part, long part_floats) {
-  VB a{(const unsigned short*)X1, (const unsigned short*)Wv1, bv1, coef, B, N, 1, invN, (unsigned short*)dX1, (unsigned short*)dvq1, part};
+             void* dX1, void* dvq1, float* dbv1, float* part, long part_floats, float* dWv1, float* wpart) {
+  VB a{(const unsigned short*)X1, (const unsigned short*)Wv1, bv1, coef, B, N, 1, invN, (unsigned short*)dX1, (unsigned short*)dvq1, part, wpart};
+  const bool dw = dWv1 != nullptr;
+  if (!dw && !dvq1) { set_error("vq1_bwd: neither dvq1 nor dWv1 requested"); return; }
   auto launch = [&](auto kern) {
     // parts per frame: >= 2 blocks per wave of an item, the items filling whole rounds of the resident workgroups (gatemod_bwd's rule)
     const int cap = wg_capacity(reinterpret_cast<const void*>(kern), 0);
@@ -1060,14 +1109,20 @@ void vq1_bwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, 
     a.wpf = best;
     const long items = (long)B * best;
     const int nwg = (int)(items < cap ? items : cap);
-    if ((long)nwg * C > part_floats) { set_error("vq1_bwd: partial-sum scratch too small"); return; }
+    if ((long)nwg * C > part_floats || (dw && nwg > 512)) { set_error("vq1_bwd: partial-sum scratch too small"); return; }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, (hipStream_t)ctx.stream, a);
     PartJob j; j.part = part; j.n = 1; j.t.NQ = 1; j.t.C = C;
     j.t.d[0] = PartDesc{0, 1, nwg, 1, dbv1, 0, 1.f};
-    if (ctx.late) *ctx.late = j;                             // a bias gradient: its second stage may run on the aux stream
+    if (dw) {                                                // second job: the C x C partial matrices, as one row of C * C "channels"
+      j.part2 = wpart; j.n2 = 1; j.t2.NQ = 1; j.t2.C = C * C;
+      j.t2.d[0] = PartDesc{0, 1, nwg, 1, dWv1, 0, 1.f};
+    }
+    if (ctx.late) *ctx.late = j;                             // parameter gradients: their second stages may run on the aux stream
     else part_reduce_run(ctx.stream, j);
   };
-  if (C == 96) launch(vq1_bwd_k<96>); else if (C == 128) launch(vq1_bwd_k<128>); else set_error("vq1_bwd: unsupported width %d", C);
+  if (C == 96) { if (dw) launch(vq1_bwd_k<96, true>); else launch(vq1_bwd_k<96, false>); }
+  else if (C == 128) { if (dw) launch(vq1_bwd_k<128, true>); else launch(vq1_bwd_k<128, false>); }
+  else set_error("vq1_bwd: unsupported width %d", C);
 }
 
 

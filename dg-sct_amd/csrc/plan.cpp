@@ -199,6 +199,7 @@ void Plan::layout() {
     wb.rowpart = a.take("rowpart", row_part_floats(B, C) * 4);
     wb.rowpart_v1 = a.take("rowpart_v1", row_part_floats(B, C) * 4);   // partial sums whose second stage runs on the aux stream: not reused
     wb.rowpart_v2 = a.take("rowpart_v2", row_part_floats(B, C) * 4);
+    wb.vq1part = vq1_fused_shape(E, N, C) ? a.take("vq1part", vq1_wpart_floats(C) * 4) : -1;   // per-workgroup dWv1 partials of vq1_bwd
     ws_bwd_bytes = a.off;
   }
   // ---- gradients (flat fp32)
@@ -695,13 +696,19 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     }
   }
   // B5 ---- video query 1
+  bool vq1_in_kernel_dw = false;
   {
     if (vq1_fused_supported(ctx.mode, N, C) && !fp8) {
       // the forward kept no vq1: ReLU decisions recomputed from X1, dvq1 (into vq1's region, for dWv1 below), d bias, dX1 += dvq1 . Wv1
       PartJob pj;
       Ctx cl = ctx; cl.late = aux_stream ? &pj : nullptr;
+      // "vq1fuse" = 3: dWv1 accumulated inside vq1_bwd (no dvq1 tensor, no product on the aux stream).  Measured (tools/call_overlap.py,
+      // AB=vq1fuse=3): the stage-0 pair's backward 3340 -> 3417 us -- C x C accumulators cost the pass its second workgroup per CU and
+      // the 32-deep contraction per block feeds the MFMAs badly; the aux-stream product it removes was overlapped anyway.  Off by default.
+      vq1_in_kernel_dw = wb.vq1part >= 0 && vq1fuse_mode(-1) == 3;
       vq1_bwd(cl, b.S(s.X1), b.W(DGSCT_P_WV1), b.F(DGSCT_P_BV1), b.Wk<float>(wb.coef), B, N, C, 1.f / (float)N, dX1, b.S(s.vq1),
-              G(DGSCT_P_BV1), b.Wk<float>(wb.rowpart_v1), row_part_floats(B, C));
+              G(DGSCT_P_BV1), b.Wk<float>(wb.rowpart_v1), row_part_floats(B, C), vq1_in_kernel_dw ? G(DGSCT_P_WV1) : nullptr,
+              vq1_in_kernel_dw ? b.Wk<float>(wb.vq1part) : nullptr);
       if (pj.n) defer([=, &side] { part_reduce_run(side.stream, pj); });
     } else {
     {
@@ -721,7 +728,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g2.A = mn(b.S(s.vq1), C); g2.B = mn(b.S(s.X1), C);
     outF(g2, G(DGSCT_P_WV1), C);
     atomic_out(g2);
-    defer([=, &side] { gemm(side, g2); });
+    if (!vq1_in_kernel_dw) defer([=, &side] { gemm(side, g2); });
   }
   // B4 ---- audio queries
   {

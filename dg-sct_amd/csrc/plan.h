@@ -36,7 +36,7 @@ struct Plan {
   struct { int64_t tokscr, Xc; } wf;
   struct {
     int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, dtokF, dT0b, zero_end;
-    int64_t dO, dZ, dX3, dX1, dXc, Xc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart, rowpart_v1, rowpart_v2;
+    int64_t dO, dZ, dX3, dX1, dXc, Xc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart, rowpart_v1, rowpart_v2, vq1part;
   } wb;
   int64_t ws_fwd_bytes, ws_bwd_bytes;
   // gradients

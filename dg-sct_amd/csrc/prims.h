@@ -28,7 +28,7 @@ struct Ctx {
 // second stage of the per-channel partial sums (device_util.h: part_reduce_k): dst[j][c] += scale * sum_{k<K} part[j*K + k][q][c]
 struct PartDesc { int q, J, K, S; float* dst; long dst_stride; float scale; };
 struct PartTable { PartDesc d[4]; int NQ, C; };
-struct PartJob { const float* part = nullptr; PartTable t; int n = 0; };
+struct PartJob { const float* part = nullptr; PartTable t; int n = 0; const float* part2 = nullptr; PartTable t2; int n2 = 0; };   // (t2: rows of another width)
 void part_reduce_run(void* stream, const PartJob&);
 // diagnostics: event pair around every adapter call on its stream (dgsct_test_tune "callprof": 1 on, 0 off, 2 dump to $DGSCT_CALL_PROF)
 int call_prof_mode(int set);
@@ -206,11 +206,15 @@ bool gate_bwd_fused_supported(int mode, int N, int C, int ds, int g);
 //   vq1_bwd:    dvq1 = (vq1 > 0) * E(coef[b][c] * invN) (written, E), dbv1[c] += sum dvq1, dX1 += dvq1 Wv1 (in place, E)
 //               part: >= 1024 * C floats of scratch; with ctx.late set the second stage of dbv1 is left to the caller
 int vq1fuse_mode(int set);
+bool vq1_fused_shape(int mode, int N, int C);        // (without the switch: layout decisions)
 bool vq1_fused_supported(int mode, int N, int C);
 void vq1sum_fwd(const Ctx&, const void* X1, const void* Wv1, const float* bv1, int B, int N, int C, float invN, float* msum,
                 void* vq1 = nullptr);     // vq1: test mode ("vq1fuse" = 2), the tensor is stored as well
+//               dWv1 != null: dWv1 [C][C] += dvq1^T X1 accumulated in the same pass (wpart: vq1_wpart_floats(C) floats of scratch) and
+//               dvq1 is not written (may be null)
+long vq1_wpart_floats(int C);
 void vq1_bwd(const Ctx&, const void* X1, const void* Wv1, const float* bv1, const float* coef, int B, int N, int C, float invN,
-             void* dX1, void* dvq1, float* dbv1, float* part, long part_floats);
+             void* dX1, void* dvq1, float* dbv1, float* part, long part_floats, float* dWv1 = nullptr, float* wpart = nullptr);
 // the same test without the tuning switch: what the buffer LAYOUT keys on (Xc is scratch, not a saved activation, for these shapes)
 bool gate_bwd_fused_shape(int mode, int N, int C, int ds, int g);
 long gate_bwd_part_floats(int B, int C);

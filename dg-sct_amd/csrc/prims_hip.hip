@@ -94,6 +94,7 @@ void part_reduce_run(void* stream, const PartJob& j) {
   if (!j.n) return;
   PartTable t = j.t;
   part_reduce(stream, j.part, t, j.n);
+  if (j.n2) { PartTable t2 = j.t2; part_reduce(stream, j.part2, t2, j.n2); }
 }
 
 void zero(const Ctx& ctx, void* p, size_t bytes) {

@@ -114,8 +114,10 @@ void gemm(const Ctx& ctx, const Gemm& g) {
 }
 
 static int g_vq1fuse = 1;
-int vq1fuse_mode(int set) { const int old = g_vq1fuse; if (set >= 0) g_vq1fuse = set > 2 ? 1 : set; return old; }
-bool vq1_fused_supported(int, int, int) { return g_vq1fuse != 0; }     // (host loops: any shape, either element type)
+int vq1fuse_mode(int set) { const int old = g_vq1fuse; if (set >= 0) g_vq1fuse = set > 3 ? 1 : set; return old; }
+long vq1_wpart_floats(int C) { return (long)C * C; }
+bool vq1_fused_shape(int, int, int) { return true; }                   // (host loops: any shape, either element type)
+bool vq1_fused_supported(int, int, int) { return g_vq1fuse != 0; }
 void vq1sum_fwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, int B, int N, int C, float invN, float* msum, void* vq1) {
   const int E = ctx.mode;
   for (int b = 0; b < B; ++b)
@@ -131,9 +133,11 @@ void vq1sum_fwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv
     }
 }
 void vq1_bwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, const float* coef, int B, int N, int C, float invN,
-             void* dX1, void* dvq1, float* dbv1, float*, long) {
+             void* dX1, void* dvq1_out, float* dbv1, float*, long, float* dWv1, float*) {
   const int E = ctx.mode;
   std::vector<float> dv(C);
+  std::vector<char> one_row((size_t)C * 4);
+  std::vector<double> dw(dWv1 ? (size_t)C * C : 0, 0.0);
   for (int b = 0; b < B; ++b)
     for (int n = 0; n < N; ++n) {
       const long row = (long)b * N + n;
@@ -141,9 +145,11 @@ void vq1_bwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, 
         double acc = 0;
         for (int k = 0; k < C; ++k) acc += (double)ld(X1, E, row * C + k) * ld(Wv1, E, (long)c * C + k);
         float v = (float)acc + bv1[c] > 0.f ? invN * coef[(long)b * C + c] : 0.f;
-        st(dvq1, E, row * C + c, v);
-        dv[c] = ld(dvq1, E, row * C + c);
+        st(one_row.data(), E, c, v);                         // rounded to E once, as the stored tensor would be
+        dv[c] = ld(one_row.data(), E, c);
+        if (!dWv1) st(dvq1_out, E, row * C + c, v);
         dbv1[c] += dv[c];
+        if (dWv1) for (int k = 0; k < C; ++k) dw[(size_t)c * C + k] += (double)dv[c] * ld(X1, E, row * C + k);
       }
       for (int k = 0; k < C; ++k) {
         double acc = 0;
@@ -151,6 +157,7 @@ void vq1_bwd(const Ctx& ctx, const void* X1, const void* Wv1, const float* bv1, 
         st(dX1, E, row * C + k, ld(dX1, E, row * C + k) + (float)acc);
       }
     }
+  if (dWv1) for (size_t i = 0; i < dw.size(); ++i) dWv1[i] += (float)dw[i];
 }
 
 static int g_skfuse = 1;

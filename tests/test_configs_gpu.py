@@ -438,3 +438,34 @@ def test_vq1_without_the_tensor_equals_the_launches_it_replaces(shape, flavour, 
         if ga is None or ga.float().norm() == 0 or name in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias"):
             continue
         assert _l2(ga, gb) < 8e-2, (name, _l2(ga, gb))
+
+
+def test_vq1_backward_with_the_weight_gradient_inside():
+    """the experiment variant of vq1_bwd_k ("vq1fuse" = 3: dWv1 accumulated in the pass, no dvq1 tensor) against the default (dvq1
+    written, dWv1 as a product on the aux stream): same operands, fp32 accumulation in a different order"""
+    N, C, No, Co, BT = 2304, 128, 4096, 96, 6
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS["ave"]})
+    p = O.random_params(cfg, "ave", seed=9, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(23)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    res = []
+    old = lib.test_tune("vq1fuse", -1)
+    try:
+        for mode in (1, 3):
+            lib.test_tune("vq1fuse", mode)
+            params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+            prep = ops.prepare(lib, spec, params, dtype, DEV)
+            out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+            dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, None, None)
+            torch.cuda.synchronize()
+            res.append((dX.float(), grads[PARAM_NAMES.index("fc_affine_video_1.weight")].clone(), grads[PARAM_NAMES.index("fc_affine_video_1.bias")].clone()))
+    finally:
+        lib.test_tune("vq1fuse", old)
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    assert _l2(a[1], b[1]) < 1e-4 and _l2(a[2], b[2]) < 1e-5, (_l2(a[1], b[1]), _l2(a[2], b[2]))

@@ -85,12 +85,17 @@ def test_schedule_with_vq1_materialised_fp32(emu, name):
     vq1_bwd: the device's stage-0 path); with dgsct_test_tune("vq1fuse", 0) the same goldens go through the product + column sum +
     ReLU backward + product launches"""
     fx = load_golden(name)
-    old = emu.test_tune("vq1fuse", 0)
+    tol = 1e-4
+    old = emu.test_tune("vq1fuse", 3)        # 3: dWv1 accumulated inside vq1_bwd (the experiment variant of the schedule)
     try:
+        r3 = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
+        emu.test_tune("vq1fuse", 0)
         r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
     finally:
         emu.test_tune("vq1fuse", old)
-    tol = 1e-4
+    for k, g in fx["grads"].items():
+        assert rel_err(r3["grads"][k].reshape(g.shape), g) < tol, k
+    assert rel_err(r3["dX"], fx["dX"]) < tol
     for k in ("out", "map", "dX", "dY"):
         assert rel_err(r[k], fx[k]) < tol, k
     for k, g in fx["grads"].items():

@@ -64,7 +64,8 @@ base, wall = measure()
 show(base, wall, "default")
 # A/B inside one process (two boxes differ by 2 %): each named switch off, then the default again
 for key in [k for k in os.environ.get("AB", "").split(",") if k]:
-    old = lib.test_tune(key, 0)
+    key, _, offv = key.partition("=")            # "vq1fuse=3": the value standing for "off" in this comparison
+    old = lib.test_tune(key, int(offv) if offv else 0)
     off, w_off = measure()
     lib.test_tune(key, old)
     on, w_on = measure()
