@@ -548,7 +548,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
            dO, G(DGSCT_P_LNP_W), G(DGSCT_P_LNP_B), G(DGSCT_P_GATE), d.use_bn ? G(DGSCT_P_BN2_B) : nullptr,
            d.eps, b.Wk<float>(wb.rowpart), row_part_floats(B, C));
   // B10 ---- BN2 backward, up projection
-  if (d.use_bn) {
+  const bool bnb = d.use_bn && vproj;                            // BN2 backward inside the narrow projection's pass (stages 0-1)
+  if (d.use_bn && !bnb) {
     bn_bwd_apply(ctx, dO, b.S(s.Op), dO, R, C, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C, G(DGSCT_P_BN2_B), 0, 1, d.training);
   }
   {
@@ -558,7 +559,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     outF(g1, G(DGSCT_P_WU), dg, (long)cg * dg);
     atomic_out(g1);
     defer([=, &side] { gemm(side, g1); });                       // released with dWd
-    if (vproj) {                                                 // dZ = dOp (x)_g Wu
+    if (bnb) {                                                   // dOp = BN2 backward of dO (in place), dZ = dOp (x)_g Wu
+      gproj_narrow_bnb(ctx, dO, b.S(s.Op), dO, R, C, ds, g, b.F(DGSCT_P_WU), (long)cg * dg, 1, dg, b.Wk(wb.dZ), bn2, bn2 + C, bn2 + 2 * C,
+                       G(DGSCT_P_BN2_B), d.training);
+    } else if (vproj) {                                          // dZ = dOp (x)_g Wu
       gproj_narrow(ctx, dO, R, C, ds, g, b.F(DGSCT_P_WU), (long)cg * dg, 1, dg, b.Wk(wb.dZ));
     } else {
       Gemm g2 = mk((int)R, dg, cg, g);                           // dZ = dOp (x)_g Wu

@@ -80,9 +80,13 @@ bool gproj_supported(int mode, int C, int ds, int g) {
 // UNR rows per lane per trip: all loads are issued before the first use (latency hiding).  DG = 8 (stage 0: dg = 6, 8)
 // keeps 4 rows in flight; DG = 16 (stage 1: dg = 12, 16) has a 128-register weight block and runs 2 rows at 2 WG/CU.
 
-template <int DT, int VE, int PROJ_DG, int PROJ_UNR>
+// BNB: the BatchNorm backward of the wide tensor (bn_bwd_apply: dx = k1 dy - k2 - xv k3 per channel) applied to the row on its way in
+// and the result stored (the dWu product of the aux stream reads it) -- one pass over dOp less, one launch less on the chain.  The
+// projection multiplies the value AS STORED (rounded to E): the numbers are the two-launch path's.
+struct BnbArgs { const void* xv; void* dx; const float* mean; const float* rstd; const float* sc; const float* sums; float inv_rows; int training; };
+template <int DT, int VE, int PROJ_DG, int PROJ_UNR, bool BNB>
 __global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void gproj_narrow_k(const void* x, long rows, int C, int ds, int g, const float* W, long sg,
-                                                      long sj, long sc, int gs, int rpc, void* y) {
+                                                      long sj, long sc, int gs, int rpc, void* y, const BnbArgs bn) {
   // [UNR][row slot][lane][DG] partial dot products (+8 floats per row slot: spreads the slots over the banks)
   __shared__ __attribute__((aligned(16))) float lds[PROJ_UNR * (256 * PROJ_DG + 128 * 8)];
   const int gl = threadIdx.x & (gs - 1), sub = threadIdx.x / gs, rpp = 256 / gs;
@@ -104,6 +108,17 @@ __global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void gproj_narrow_k(const
 #pragma unroll
     for (int e = 0; e < VE; ++e) w[jl][e] = (valid && jl < dg) ? lds[(gi * dg + jl) * cg + cl0 + e] : 0.f;
   __syncthreads();                                    // lds is reused for the partial sums below
+  float k1[BNB ? VE : 1], k2[BNB ? VE : 1], k3[BNB ? VE : 1];
+  if (BNB) {
+    float a[VE], rs[VE], mn[VE], s0[VE], s1[VE];
+    ldf<VE>(bn.sc, colc, a); ldf<VE>(bn.rstd, colc, rs); ldf<VE>(bn.mean, colc, mn); ldf<VE>(bn.sums, colc, s0); ldf<VE>(bn.sums, (long)C + colc, s1);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      k1[e] = a[e];
+      k3[e] = bn.training ? a[e] * rs[e] * s1[e] * bn.inv_rows : 0.f;
+      k2[e] = bn.training ? a[e] * s0[e] * bn.inv_rows - mn[e] * k3[e] : 0.f;
+    }
+  }
   const int slot_stride = gs * PROJ_DG + 8;
   float* const slot0 = lds + sub * slot_stride;
   const int unr_stride = 256 * PROJ_DG + 128 * 8;
@@ -114,10 +129,24 @@ __global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void gproj_narrow_k(const
     // Unconditional loads from clamped addresses: a per-element "load or zero" makes hipcc branch around every load and
     // wait vmcnt(0) after each one, which serialises the four HBM round trips of a trip.
     float t[PROJ_UNR][VE];
+    float xv[BNB ? PROJ_UNR : 1][VE];
 #pragma unroll
     for (int u = 0; u < PROJ_UNR; ++u) {
       const long row = rb + (long)u * rpp + sub;
       ldv<DT, VE>(x, (row < r_end ? row : r_end - 1) * C + colc, t[u]);
+      if (BNB) ldv<DT, VE>(bn.xv, (row < r_end ? row : r_end - 1) * C + colc, xv[u]);
+    }
+    if (BNB) {
+#pragma unroll
+      for (int u = 0; u < PROJ_UNR; ++u) {
+        const long row = rb + (long)u * rpp + sub;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float v = k1[e] * t[u][e] - k2[e] - xv[u][e] * k3[e];
+          t[u][e] = DT == DT_BF16 ? bf2f(f2bf(v)) : v;
+        }
+        if (valid && row < r_end) stv<DT, VE>(bn.dx, row * C + colc, t[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < PROJ_UNR; ++u) {
@@ -159,17 +188,38 @@ __global__ __launch_bounds__(256, PROJ_DG > 8 ? 2 : 3) void gproj_narrow_k(const
   }
 }
 
-void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,
-                  void* y) {
+static void gproj_narrow_launch(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,
+                                void* y, const BnbArgs* bn) {
   ProjGeom pg;
   if (!proj_geom(ctx.mode, C, ds, g, rows, 2048, pg)) { set_error("gproj_narrow: unsupported shape C=%d ds=%d g=%d", C, ds, g); return; }
   const bool big = ds / g > 8;
-#define NARROW_(DT_, VE_, DG_, UNR_) \
-  hipLaunchKernelGGL((gproj_narrow_k<DT_, VE_, DG_, UNR_>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc, \
-                     pg.gs, pg.rpc, y)
-  if (ctx.mode == DT_BF16) { if (big) NARROW_(DT_BF16, 8, 16, 2); else NARROW_(DT_BF16, 8, 8, 4); }
-  else { if (big) NARROW_(DT_F32, 4, 16, 2); else NARROW_(DT_F32, 4, 8, 4); }
+  const BnbArgs b = bn ? *bn : BnbArgs{};
+#define NARROW_(DT_, VE_, DG_, UNR_, BNB_) \
+  hipLaunchKernelGGL((gproj_narrow_k<DT_, VE_, DG_, UNR_, BNB_>), dim3(pg.chunks), dim3(256), 0, STREAM(ctx), x, rows, C, ds, g, W, sg, sj, sc, \
+                     pg.gs, pg.rpc, y, b)
+  if (bn) {
+    if (ctx.mode == DT_BF16) { if (big) NARROW_(DT_BF16, 8, 16, 2, true); else NARROW_(DT_BF16, 8, 8, 3, true); }   // (3 rows in flight: 4 spill at 3 workgroups per CU)
+    else { if (big) NARROW_(DT_F32, 4, 16, 2, true); else NARROW_(DT_F32, 4, 8, 4, true); }
+  } else {
+    if (ctx.mode == DT_BF16) { if (big) NARROW_(DT_BF16, 8, 16, 2, false); else NARROW_(DT_BF16, 8, 8, 4, false); }
+    else { if (big) NARROW_(DT_F32, 4, 16, 2, false); else NARROW_(DT_F32, 4, 8, 4, false); }
+  }
 #undef NARROW_
+}
+void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,
+                  void* y) {
+  gproj_narrow_launch(ctx, x, rows, C, ds, g, W, sg, sj, sc, y, nullptr);
+}
+// dx = BN backward of dy (bn_bwd_apply, no ReLU), y = dx (x)_g W -- one pass (gproj_narrow_k<BNB>)
+void gproj_narrow_bnb(const Ctx& ctx, const void* dy, const void* xv, void* dx, long rows, int C, int ds, int g, const float* W, long sg,
+                      long sj, long sc, void* y, const float* mean, const float* rstd, const float* bsc, const float* sums, int training) {
+  if (!rowfuse_mode(-1)) {
+    bn_bwd_apply(ctx, dy, xv, dx, rows, C, mean, rstd, bsc, nullptr, sums, 0, 1, training);
+    gproj_narrow(ctx, dx, rows, C, ds, g, W, sg, sj, sc, y);
+    return;
+  }
+  const BnbArgs b{xv, dx, mean, rstd, bsc, sums, 1.f / (float)rows, training};
+  gproj_narrow_launch(ctx, dy, rows, C, ds, g, W, sg, sj, sc, y, &b);
 }
 
 // ---- modulation + ln_before + narrow + BatchNorm sums in ONE pass ------------------------------------------------------

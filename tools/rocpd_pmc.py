@@ -29,7 +29,7 @@ tab = defaultdict(dict)
 cnt = {}
 for k, n, v, d in rows:
     if pat.search(k):
-        k2 = re.sub(r"\(.*", "", re.sub(r"^void ", "", k)).replace("dgsct::", "")
+        k2 = re.sub(r"\(.*", "", re.sub(r"^void ", "", k.replace("(anonymous namespace)::", ""))).replace("dgsct::", "")
         tab[k2][n] = v
         cnt[k2] = d
 names = sorted({n for v in tab.values() for n in v})
