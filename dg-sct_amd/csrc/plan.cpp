@@ -561,7 +561,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     defer([=, &side] { gemm(side, g1); });                       // released with dWd
     if (bnb) {                                                   // dOp = BN2 backward of dO (in place), dZ = dOp (x)_g Wu
       gproj_narrow_bnb(ctx, dO, b.S(s.Op), dO, R, C, ds, g, b.F(DGSCT_P_WU), (long)cg * dg, 1, dg, b.Wk(wb.dZ), bn2, bn2 + C, bn2 + 2 * C,
-                       G(DGSCT_P_BN2_B), d.training);
+                       bn2 + 3 * C, G(DGSCT_P_BN2_B), d.training);
     } else if (vproj) {                                          // dZ = dOp (x)_g Wu
       gproj_narrow(ctx, dO, R, C, ds, g, b.F(DGSCT_P_WU), (long)cg * dg, 1, dg, b.Wk(wb.dZ));
     } else {

@@ -173,7 +173,7 @@ void gproj_narrow(const Ctx&, const void* x, long rows, int C, int ds, int g, co
 // dx = BatchNorm backward of dy (as bn_bwd_apply with relu = 0, has_bn = 1; written, E), y = dx (x)_g W: one pass over the wide tensors
 // (dgsct_test_tune "rowfuse" = 0: the two launches)
 void gproj_narrow_bnb(const Ctx&, const void* dy, const void* xv, void* dx, long rows, int C, int ds, int g, const float* W, long sg,
-                      long sj, long sc, void* y, const float* mean, const float* rstd, const float* bsc, const float* sums, int training);
+                      long sj, long sc, void* y, const float* mean, const float* rstd, const float* bsc, const float* bsh, const float* sums, int training);
 // modln_fwd + gproj_narrow + bn_stats(y) in one pass over X1 (lnw may be null; stats null = no sums)
 bool modln_gproj_supported(int mode, int C, int ds, int g);
 int rowfuse_mode(int set);        // test / tuning switch of the fused row passes (dgsct_test_tune "rowfuse")

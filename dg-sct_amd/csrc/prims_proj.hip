@@ -212,9 +212,9 @@ void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g
 }
 // dx = BN backward of dy (bn_bwd_apply, no ReLU), y = dx (x)_g W -- one pass (gproj_narrow_k<BNB>)
 void gproj_narrow_bnb(const Ctx& ctx, const void* dy, const void* xv, void* dx, long rows, int C, int ds, int g, const float* W, long sg,
-                      long sj, long sc, void* y, const float* mean, const float* rstd, const float* bsc, const float* sums, int training) {
+                      long sj, long sc, void* y, const float* mean, const float* rstd, const float* bsc, const float* bsh, const float* sums, int training) {
   if (!rowfuse_mode(-1)) {
-    bn_bwd_apply(ctx, dy, xv, dx, rows, C, mean, rstd, bsc, nullptr, sums, 0, 1, training);
+    bn_bwd_apply(ctx, dy, xv, dx, rows, C, mean, rstd, bsc, bsh, sums, 0, 1, training);
     gproj_narrow(ctx, dx, rows, C, ds, g, W, sg, sj, sc, y);
     return;
   }

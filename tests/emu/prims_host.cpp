@@ -424,8 +424,8 @@ bool gproj_supported(int mode, int C, int ds, int g) {
 }
 void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc, void* y);
 void gproj_narrow_bnb(const Ctx& ctx, const void* dy, const void* xv, void* dx, long rows, int C, int ds, int g, const float* W, long sg,
-                      long sj, long sc, void* y, const float* mean, const float* rstd, const float* bsc, const float* sums, int training) {
-  bn_bwd_apply(ctx, dy, xv, dx, rows, C, mean, rstd, bsc, nullptr, sums, 0, 1, training);
+                      long sj, long sc, void* y, const float* mean, const float* rstd, const float* bsc, const float* bsh, const float* sums, int training) {
+  bn_bwd_apply(ctx, dy, xv, dx, rows, C, mean, rstd, bsc, bsh, sums, 0, 1, training);
   gproj_narrow(ctx, dx, rows, C, ds, g, W, sg, sj, sc, y);
 }
 void gproj_narrow(const Ctx& ctx, const void* x, long rows, int C, int ds, int g, const float* W, long sg, long sj, long sc,

@@ -470,7 +470,7 @@ def test_vq1_backward_with_the_weight_gradient_inside():
     # (upstream of vq1's backward the per-frame gate gradients are fp32 atomic sums: two runs differ in their last bits, and so
     #  does everything downstream -- hence not torch.equal)
     assert _l2(a[0], b[0]) < 2e-3, _l2(a[0], b[0])
-    assert _l2(a[1], b[1]) < 2e-3 and _l2(a[2], b[2]) < 2e-3, (_l2(a[1], b[1]), _l2(a[2], b[2]))
+    assert _l2(a[1], b[1]) < 6e-3 and _l2(a[2], b[2]) < 6e-3, (_l2(a[1], b[1]), _l2(a[2], b[2]))
 
 
 @pytest.mark.parametrize("shape,dtype", [((4096, 96, 2304, 128), torch.bfloat16), ((1024, 192, 576, 256), torch.bfloat16), ((576, 256, 1024, 192), torch.bfloat16),
