@@ -258,6 +258,7 @@ int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, cons
 int dgsct_test_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm8")) return gemm8_mode(value);
   if (key && !strcmp(key, "skinny")) return gemm_skinny_mode(value);
+  if (key && !strcmp(key, "gemmtall")) return gemm_tall_mode(value);
   if (key && !strcmp(key, "rowfuse")) return rowfuse_mode(value);
   if (key && !strcmp(key, "gatefuse")) return gatefuse_mode(value);
   if (key && !strcmp(key, "bnfold")) return bnfold_mode(value);

@@ -888,6 +888,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   k.atomic = g.atomic;
   if constexpr (MODE == DT_BF16) {
     if (gemm_skinny_try(ctx, g)) return;                        // [BT, C] gate-MLP products: K split over the waves (gemm_skinny.hip)
+    if (gemm_tall_try(ctx, g)) return;                          // weight gradients over the token rows of stages 0-1 (gemm_tall.hip)
     if (gemm8_try(ctx, g)) return;                              // deep products: 8-wave LDS-DMA pipelined kernel (gemm8.hip)
   }
   const bool rowwise = g.act == ACT_SOFTMAX || g.act == ACT_SOFTMAX_BWD;

@@ -21,4 +21,9 @@ int gemm8_mode(int set);
 bool gemm_skinny_try(const Ctx& ctx, const Gemm& g);
 int gemm_skinny_mode(int set);      // 0: off, 1: on (default; DGSCT_GEMM_SKINNY).  set < 0: query.
 
+// Weight gradients over the token rows (both operands [rows][width], a small output, a very deep contraction): one stream over the
+// two tensors, output tiles dealt to the waves (gemm_tall.hip).  Same contract as gemm8_try.
+bool gemm_tall_try(const Ctx& ctx, const Gemm& g);
+int gemm_tall_mode(int set);        // 0: off, 1: on (default; DGSCT_NO_GEMM_TALL).  set < 0: query.
+
 }  // namespace dgsct

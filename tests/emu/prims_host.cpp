@@ -42,6 +42,7 @@ void stream_join(const Ctx&) {}
 void check_async(const char*) {}
 void clear_async() {}
 int gemm_skinny_mode(int) { return 0; }
+int gemm_tall_mode(int) { return 0; }
 int gemm8_mode(int) { return 0; }                 // (the 8-wave GEMM kernel is a device-side choice: nothing to emulate)
 
 void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }

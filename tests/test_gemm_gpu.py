@@ -334,3 +334,28 @@ def test_gemm_skinny_is_actually_used():
     finally:
         os.environ.pop("DGSCT_PROF_DUMP", None)
         lib.prof_enable(False)
+
+
+# ---- gemm_tall.hip: weight gradients over the token rows (both operands [rows][width], small output, very deep contraction) ----------
+@pytest.mark.parametrize("M,N,pad", [(96, 96, 0), (128, 128, 0), (48, 96, 0), (8, 48, 4), (48, 8, 4), (96, 128, 0), (12, 192, 0), (32, 256, 0), (72, 120, 0)])
+def test_gemm_tall_weight_gradients(M, N, pad):
+    """the weight-gradient products of stages 0-1 (dWu, dWd, dWv2, dWv1, dWc: plan.cpp B10, B9, B5, B1) on gemm_tall.hip: a stream over
+    two [rows, width] tensors in 64-row blocks, output tiles dealt to the waves, fp32 atomics at the end; padded row pitches (a slab of
+    a wider tensor), outputs smaller than a tile, and the check that the kernel is the one that ran"""
+    import csv, os, tempfile
+    lib = default_lib()
+    lib.prof_enable(True)
+    try:
+        path = os.path.join(tempfile.mkdtemp(), "g.csv")
+        os.environ["DGSCT_PROF_DUMP"] = path
+        run_case(1, M, N, 64 * 1100, 0, 0, batch=1, atomic=True, splitk=0, pad=pad)
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] == "11", rows[-1]
+        run_case(1, M, N, 64 * 1100 + 32, 0, 0, batch=1, atomic=True, splitk=0, pad=pad)          # not whole 64-row blocks: the tiled engine
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] != "11", rows[-1]
+    finally:
+        os.environ.pop("DGSCT_PROF_DUMP", None)
+        lib.prof_enable(False)
