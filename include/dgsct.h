@@ -251,7 +251,17 @@ int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, cons
  *   eligible shape (lets the unit tests reach it with small matrices); value < 0 only queries.
  *   "skinny": 0 / 1 = the K-split kernel of the [BT, C] gate-MLP products off / on (default on).
  *   "rowfuse": 0 / 1 = the fused row passes of stages 0-1 (modulation + ln_before + down-projection + BN1 sums in one
- *   kernel) off / on (default on; off = the three separate launches). */
+ *   kernel; BatchNorm-2's backward inside the narrow projection's pass) off / on (default on; off = the separate launches).
+ *   "gatefuse": 0 / 1 = the fused gate / bottleneck passes of the early stages (fused_gate.hip) off / on; 2 = on, and the forward
+ *   also stores vq2 (for tests that read the device's ReLU decisions back).
+ *   "vq1fuse": 0 / 1 = vq1 never stored at C = 96 / 128 (vq1_fwd_k / vq1_bwd_k) off / on; 2 = on + the tensor stored as well;
+ *   3 = on, with dWv1 accumulated inside the backward pass (experiment, slower).  Forward and backward of one call must run
+ *   under the same setting of "gatefuse" / "vq1fuse" (0 vs non-0): the backward of a fused forward has no stored tensor to read.
+ *   "skfuse": 0 / 1 = elementwise neighbours folded into the gate-MLP products off / on.
+ *   "bnfold": 0 / 1 = BatchNorm finalisation inside its consumers off / on.
+ *   "gemmtall": 0 / 1 = gemm_tall.hip for the weight gradients over the token rows off / on.
+ *   "callprof": 1 / 0 = record an event pair around every adapter call on its stream / stop; 2 = dump "kind N C stream t0 t1" (us)
+ *   to $DGSCT_CALL_PROF (default /tmp/dgsct_callprof.txt) and clear. */
 int dgsct_test_tune(const char* key, int value);
 
 int dgsct_prof_enable(int on);
