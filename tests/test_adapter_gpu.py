@@ -331,10 +331,10 @@ def test_module_under_data_parallel(flavour, flat):
 
     def same(a, b, what):
         for i, (x, y) in enumerate(zip(a[:4], b[:4])):
-            assert rel_err(x, y) < 1e-4, (what, i)         # (two runs of the same kernels: fp32 atomics reorder sums)
+            assert fp32_err(x, y) < 1e-3, (what, i)        # (two runs of the same kernels: fp32 atomics reorder sums; no absolute floor)
         assert set(b[4]) <= set(a[4]) and b[4], what
         for k in b[4]:
-            assert rel_err(a[4][k], b[4][k]) < 1e-4, (what, k)
+            assert grad_close_fp32(a[4][k], b[4][k], tol=1e-3, name=k.split(".", 1)[-1] if "." in k else k), (what, k)
         for k in set(a[4]) - set(b[4]):                    # Broadcast.backward hands unused parameters a ZERO gradient (stock
             assert float(a[4][k].abs().max()) == 0.0, (what, k)   # nn.DataParallel behaviour), the bare module leaves them None
 

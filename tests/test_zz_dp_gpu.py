@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.distributed as dist
 
-from helpers import load_golden, rel_err
+from helpers import grad_close_fp32, load_golden
 
 import dgsct_amd  # noqa: F401
 from dgsct_amd import AdapterStack, GradAllReducer, init_process_group
@@ -58,7 +58,9 @@ def test_rccl_single_rank_allreduce_keeps_the_gradients(overlap):
                     for pn, (off, cnt, shape) in m._flat_layout.items():
                         ref = fx["grads"].get(name + "." + pn)
                         if ref is not None:
-                            assert rel_err(m.flat_param.grad[off:off + cnt].view(shape), ref) < 1e-3, name + "." + pn
+                            # (the no-floor fp32 metric of the parity tests; the stack fixture's gradients come from the un-pinned
+                            #  reference, so a ReLU flip may move a row of a weight gradient: grad_close_fp32 allows two)
+                            assert grad_close_fp32(m.flat_param.grad[off:off + cnt].view(shape), ref, tol=2e-3, name=pn), name + "." + pn
                             n += 1
             assert n == len(fx["grads"])
     finally:
