@@ -47,13 +47,16 @@ __global__ __launch_bounds__(256) void gemm_tall_k(const GT p) {
   if (blk0 >= blk1) return;
   const int pa = (int)p.lda * 2, pb = (int)p.ldb * 2;
   // this wave's tiles: t = wave, wave + 4, ...  ->  (group, m-tile, n-tile)
-  int colA[GT_MAXT], colB[GT_MAXT];
+  // (a group's slab may start on any even column -- 6 at ds = 12, g = 2 -- but a transpose read wants 4-column alignment: the tile
+  //  starts at the aligned column below and its first `sh` rows / columns are skipped when it is written out)
+  int colA[GT_MAXT], colB[GT_MAXT], shA[GT_MAXT], shB[GT_MAXT];
 #pragma unroll
   for (int i = 0; i < GT_MAXT; ++i) {
     int t = wave + 4 * i; t = t < p.ntiles ? t : 0;
     const int b = t / (p.mt * p.nt), r = t - b * p.mt * p.nt, m = r / p.nt, n = r - m * p.nt;
-    colA[i] = (int)(b * p.a_bs) + 32 * m;
-    colB[i] = (int)(b * p.b_bs) + 32 * n;
+    const int ca = (int)(b * p.a_bs) + 32 * m, cb = (int)(b * p.b_bs) + 32 * n;
+    colA[i] = ca & ~3; shA[i] = ca & 3;
+    colB[i] = cb & ~3; shB[i] = cb & 3;
   }
   mt_f32x16 acc[GT_MAXT];
 #pragma unroll
@@ -99,11 +102,11 @@ __global__ __launch_bounds__(256) void gemm_tall_k(const GT p) {
     const int t = wave + 4 * i;
     if (t < p.ntiles) {
       const int b = t / (p.mt * p.nt), r0 = t - b * p.mt * p.nt, mi = r0 / p.nt, ni = r0 - mi * p.nt;
-      const int n = 32 * ni + (lane & 31);
+      const int nl = (lane & 31) - shB[i], n = 32 * ni + nl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < p.M && n < p.N) unsafeAtomicAdd(p.D + b * p.dbs + (long)m * p.ldd + n, acc[i][r]);
+        const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) - shA[i], m = 32 * mi + ml;
+        if (ml >= 0 && nl >= 0 && m < p.M && n < p.N) unsafeAtomicAdd(p.D + b * p.dbs + (long)m * p.ldd + n, acc[i][r]);
       }
     }
   }
@@ -115,7 +118,7 @@ std::atomic<int> g_tall{-1};
 int gemm_tall_mode(int set) {
   if (g_tall.load(std::memory_order_relaxed) < 0) g_tall.store(getenv("DGSCT_NO_GEMM_TALL") ? 0 : 1, std::memory_order_relaxed);
   const int old = g_tall.load(std::memory_order_relaxed);
-  if (set >= 0) g_tall.store(set ? 1 : 0, std::memory_order_relaxed);
+  if (set >= 0) g_tall.store(set > 2 ? 1 : set, std::memory_order_relaxed);
   return old;
 }
 
@@ -123,14 +126,20 @@ bool gemm_tall_try(const Ctx& ctx, const Gemm& g) {
   if (!gemm_tall_mode(-1) || ctx.mode != DT_BF16) return false;
   if (g.A.kmajor || g.B.kmajor || g.KB != 1 || !g.atomic || g.ddt != DT_F32) return false;
   if (g.act != ACT_NONE || g.mask || g.R || g.R2 || g.bias_m || g.bias_n || g.r1_m || g.r1_n || g.alpha_ptr || g.alpha != 1.f || g.sm_scale || g.sm_dot) return false;
-  if (g.K < 16384 || g.K % GT_RB) return false;              // tall only; whole 64-row blocks
+  // tall only; whole 64-row blocks.  Default gate = the stage-0 depths (368 640 / 655 360 rows): in the step the stage-1 products
+  // (92 160 / 163 840 rows) measured +30..+47 us per pair with this kernel although each is as fast or faster alone
+  // (tools/call_overlap.py AB=gemmtall); "gemmtall" = 2 takes everything from 16 384 rows (tests)
+  const long kmin = gemm_tall_mode(-1) >= 2 ? 16384 : 262144;
+  if (g.K < kmin || g.K % GT_RB) return false;
   if (g.A.ld > GT_MAXW || g.B.ld > GT_MAXW) return false;
   if (g.A.ld % 4 || g.B.ld % 4) return false;                // 8-byte aligned transpose reads
   if ((reinterpret_cast<uintptr_t>(g.A.p) & 15) || (reinterpret_cast<uintptr_t>(g.B.p) & 15)) return false;
   if ((g.A.ld * GT_RB * 2) % 16 || (g.B.ld * GT_RB * 2) % 16) return false;
-  if (g.A.bs % 4 || g.B.bs % 4) return false;
+  if (g.A.bs % 2 || g.B.bs % 2) return false;
+  const int wsa = g.batch > 1 && g.A.bs % 4 ? 2 : 0, wsb = g.batch > 1 && g.B.bs % 4 ? 2 : 0;     // worst shift of a slab start
   // the column slabs must lie inside a row (a padded tile may read past its slab, never past the image + 64 bytes)
   if ((long)(g.batch - 1) * g.A.bs + g.M > g.A.ld || (long)(g.batch - 1) * g.B.bs + g.N > g.B.ld) return false;
+  if ((wsa && g.M > 30) || (wsb && g.N > 30)) return false;   // (a shifted slab must fit ONE tile: the stage-0 bottleneck widths do)
   const int mt = (g.M + 31) / 32, nt = (g.N + 31) / 32;
   const int ntiles = g.batch * mt * nt;
   if (ntiles > 4 * GT_MAXT) return false;

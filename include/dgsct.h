@@ -259,7 +259,8 @@ int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, cons
  *   under the same setting of "gatefuse" / "vq1fuse" (0 vs non-0): the backward of a fused forward has no stored tensor to read.
  *   "skfuse": 0 / 1 = elementwise neighbours folded into the gate-MLP products off / on.
  *   "bnfold": 0 / 1 = BatchNorm finalisation inside its consumers off / on.
- *   "gemmtall": 0 / 1 = gemm_tall.hip for the weight gradients over the token rows off / on.
+ *   "gemmtall": 0 / 1 = gemm_tall.hip for the weight gradients over the token rows off / on (from 262 144 rows: stage 0);
+ *   2 = on from 16 384 rows (tests).
  *   "callprof": 1 / 0 = record an event pair around every adapter call on its stream / stop; 2 = dump "kind N C stream t0 t1" (us)
  *   to $DGSCT_CALL_PROF (default /tmp/dgsct_callprof.txt) and clear. */
 int dgsct_test_tune(const char* key, int value);

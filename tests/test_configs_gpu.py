@@ -513,3 +513,39 @@ def test_bn2_backward_inside_the_narrow_projection(shape, dtype):
     for name, ga, gb in zip(PARAM_NAMES, a[2], b[2]):
         if ga is not None and name in ("up_sampler.weight", "down_sampler.weight", "bn1.bias", "bn1.weight", "bn2.bias", "bn2.weight"):
             assert _l2(ga, gb) < tol, (name, _l2(ga, gb))
+
+
+@pytest.mark.parametrize("shape", [(4096, 96, 2304, 128), (2304, 128, 4096, 96)])
+def test_weight_gradients_on_gemm_tall_equal_the_tiled_engine(shape):
+    """the five weight gradients over the token rows (dWu, dWd with their group slabs starting on column 6 at C = 96; dWv2, dWv1, dWc) on
+    gemm_tall.hip ("gemmtall" = 2: from 16 384 rows, so that 10 frames reach it) against the tiled engine's split-K products
+    ("gemmtall" = 0) inside one adapter backward: same operands, fp32 accumulation in a different order"""
+    N, C, No, Co = shape
+    BT = 10
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS["ave"]})
+    p = O.random_params(cfg, "ave", seed=17, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(37)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+    prep = ops.prepare(lib, spec, params, dtype, DEV)
+    res = []
+    old = lib.test_tune("gemmtall", -1)
+    try:
+        for mode in (2, 0):
+            out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, False)     # eval mode: the parameters do not move
+            lib.test_tune("gemmtall", mode)
+            dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, None, None)
+            torch.cuda.synchronize()
+            lib.test_tune("gemmtall", old)
+            res.append({n: g.clone() for n, g in zip(PARAM_NAMES, grads) if g is not None})
+    finally:
+        lib.test_tune("gemmtall", old)
+    a, b = res
+    for name in ("up_sampler.weight", "down_sampler.weight", "fc_affine_video_1.weight", "fc_affine_video_2.weight", "fc.weight", "conv_adapter.weight"):
+        if name in a:
+            assert _l2(a[name], b[name]) < 2e-3, (name, _l2(a[name], b[name]))

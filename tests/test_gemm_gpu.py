@@ -345,6 +345,7 @@ def test_gemm_tall_weight_gradients(M, N, pad):
     import csv, os, tempfile
     lib = default_lib()
     lib.prof_enable(True)
+    old = lib.test_tune("gemmtall", 2)              # 2: from 16 384 rows (the default gate is the stage-0 depth)
     try:
         path = os.path.join(tempfile.mkdtemp(), "g.csv")
         os.environ["DGSCT_PROF_DUMP"] = path
@@ -357,5 +358,6 @@ def test_gemm_tall_weight_gradients(M, N, pad):
         rows = list(csv.DictReader(open(path)))
         assert rows and rows[-1]["cfg"] != "11", rows[-1]
     finally:
+        lib.test_tune("gemmtall", old)
         os.environ.pop("DGSCT_PROF_DUMP", None)
         lib.prof_enable(False)
