@@ -122,8 +122,13 @@ int gemm_tall_mode(int set) {
   return old;
 }
 
-bool gemm_tall_try(const Ctx& ctx, const Gemm& g) {
+bool gemm_tall_try(const Ctx& ctx, const Gemm& g0) {
   if (!gemm_tall_mode(-1) || ctx.mode != DT_BF16) return false;
+  Gemm g = g0;
+  // a two-level contraction over (frame, row) whose frames lie back to back in BOTH operands is one flat stream of KB * K rows
+  // (dWc of the audio direction: sum_b dT2[b]^T Y[b])
+  if (g.KB > 1 && !g.A.kmajor && !g.B.kmajor && g.A.kbs == (long)g.K * g.A.ld && g.B.kbs == (long)g.K * g.B.ld &&
+      (long)g.K * g.KB < 0x7fffffffL) { g.K *= g.KB; g.KB = 1; }
   if (g.A.kmajor || g.B.kmajor || g.KB != 1 || !g.atomic || g.ddt != DT_F32) return false;
   if (g.act != ACT_NONE || g.mask || g.R || g.R2 || g.bias_m || g.bias_n || g.r1_m || g.r1_n || g.alpha_ptr || g.alpha != 1.f || g.sm_scale || g.sm_dot) return false;
   // tall only; whole 64-row blocks.  Default gate = the stage-0 depths (368 640 / 655 360 rows): in the step the stage-1 products

@@ -353,6 +353,10 @@ def test_gemm_tall_weight_gradients(M, N, pad):
         lib.prof_collect()
         rows = list(csv.DictReader(open(path)))
         assert rows and rows[-1]["cfg"] == "11", rows[-1]
+        run_case(1, M, N, 64 * 70, 0, 0, batch=1, KB=16, atomic=True, splitk=0, pad=pad)           # (frame, row) contraction, frames back to back: one flat stream
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] == "11", rows[-1]
         run_case(1, M, N, 64 * 1100 + 32, 0, 0, batch=1, atomic=True, splitk=0, pad=pad)          # not whole 64-row blocks: the tiled engine
         lib.prof_collect()
         rows = list(csv.DictReader(open(path)))
