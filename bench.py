@@ -83,7 +83,55 @@ def make_inputs(stages, BT, dtype, device, seed):
     return feats, cots, mcots
 
 
-def cpu_baseline(backbone, max_seconds=30.0):
+def stage_breakdown(lib, stages, run_step, BT, peak_tflops, nsteps=2):
+    """Where the step is: per backbone stage, the wall span of its adapter calls inside the REAL schedule (both
+    adapter streams + aux streams; the library records an event pair around every forward / backward call on the call's own stream:
+    dgsct_test_tune("callprof"), no tracer), the stage's algorithmic FLOPs and the fraction of the dense MFMA peak."""
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"dgsct_callprof_{os.getpid()}.txt")
+    old_env = os.environ.get("DGSCT_CALL_PROF")
+    os.environ["DGSCT_CALL_PROF"] = path
+    by_n = {}
+    for i, st in enumerate(stages):
+        by_n[(st["Nv"], st["Cv"])] = i
+        by_n[(st["Na"], st["Ca"])] = i
+    acc = [[0.0, 0.0] for _ in stages]
+    try:
+        for _ in range(nsteps):
+            lib.test_tune("callprof", 1)
+            run_step()
+            torch.cuda.synchronize()
+            lib.test_tune("callprof", 0)
+            lib.test_tune("callprof", 2)                       # dump + clear
+            spans = {}
+            for ln in open(path):
+                kind, N, C, _, a, b = ln.split()
+                i = by_n.get((int(N), int(C)))
+                if i is None:
+                    continue
+                e = spans.setdefault((i, kind), [float("inf"), 0.0])
+                e[0] = min(e[0], float(a)); e[1] = max(e[1], float(b))
+            for (i, kind), (a, b) in spans.items():
+                acc[i][0 if kind == "fwd" else 1] += (b - a) * 1e-3
+    finally:
+        if old_env is None:
+            os.environ.pop("DGSCT_CALL_PROF", None)
+        else:
+            os.environ["DGSCT_CALL_PROF"] = old_env
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    out = []
+    for i, st in enumerate(stages):
+        f, b = acc[i][0] / nsteps, acc[i][1] / nsteps
+        tf = 3.0 * alg_flops_per_frame([st]) * BT / 1e12
+        out.append(dict(stage=i, adapter_calls=4 * st["layers"], fwd_ms=round(f, 3), bwd_ms=round(b, 3), ms=round(f + b, 3),
+                        alg_tflop=round(tf, 3), frac_of_mfma_peak=round(tf / ((f + b) * 1e-3) / peak_tflops, 4) if f + b > 0 else None))
+    return out
+
+
+def cpu_baseline(backbone, max_seconds=30.0, b16_seconds=45.0):
     """The oracle's autograd 'port' (op-for-op ATen restatement of the reference adapter, token-major) timed on the
     host cores: ONE clip (BT = 10 frames) through all 48 adapters, forward + backward, fp32."""
     from oracle import dgsct_oracle as O
@@ -140,20 +188,19 @@ def cpu_baseline(backbone, max_seconds=30.0):
     # B = 16 (the batch the GPU number is quoted on; SURVEY.md 8d: "B=16 ... fall back to per-stage timing and sum"): ONE
     # forward+backward of each of the 8 distinct adapter shapes at BT = 160, scaled by how often the stack runs that shape --
     # about a fifth of a full 48-adapter pass of CPU work (a full pass holds ~40 GB of saved activations and takes ~30 s)
-    t16, n16 = 0.0, 0
+    t16, n16, cold16 = 0.0, 0, 0
     seen = {}
     for cfg, p in adapters:
         key = (cfg.N, cfg.C, cfg.No, cfg.Co)
         seen.setdefault(key, [cfg, p, 0])[2] += 1
-    t_budget = time.perf_counter() + max_seconds
+    # its OWN budget (round 4's driver line lost this leg to the B=1 leg's clock): one warm-up pass + one timed pass per shape while
+    # the budget lasts, then ONE (cold, timed) pass per remaining shape -- the leg always completes, `cold_shapes` says how
+    t_budget = time.perf_counter() + b16_seconds
     for key, (cfg, p, cnt) in seen.items():
-        if time.perf_counter() > t_budget:
-            t16 = None
-            break
         X = torch.randn(160, cfg.N, cfg.C, requires_grad=True)
         Y = torch.randn(160, cfg.No, cfg.Co, requires_grad=True)
         dts = []
-        for rep in range(3):              # one warm-up pass (first touch of the multi-GB saved activations), then <= 2 timed ones
+        for rep in range(2):              # warm-up pass (first touch of the multi-GB saved activations), then the timed one
             go, gm = torch.randn(160, cfg.N, cfg.C), torch.randn(160, 1, cfg.N)
             t0 = time.perf_counter()
             out, amap, _ = O.forward_autograd(p, X, Y, cfg, training=True)
@@ -164,12 +211,12 @@ def cpu_baseline(backbone, max_seconds=30.0):
                     v.grad = None
             X.grad = Y.grad = None
             del out, amap
-            if rep:
-                dts.append(dt)
-            if time.perf_counter() + dt > t_budget and dts:
+            dts.append(dt)
+            if time.perf_counter() + dt > t_budget:
                 break
         del X, Y
-        t16 += cnt * min(dts) if dts else cnt * dt
+        cold16 += len(dts) == 1
+        t16 += cnt * dts[-1]
         n16 += 1
     model = "unknown"
     physical = None
@@ -193,9 +240,10 @@ def cpu_baseline(backbone, max_seconds=30.0):
     b1 = round(1.0 / t, 4)
     b16 = round(16.0 / t16, 4) if t16 else None
     return dict(value=b16 if b16 is not None else b1, unit="clips/s", cores=torch.get_num_threads(), kind="port", cpu_model=model,
-                logical_cpus=ncpu, physical_cores=physical, value_b1=b1, value_b16=b16,
-                sample=(f"B=16: fwd+bwd of each of the {n16} distinct adapter shapes at BT=160 (one warm-up pass, best of <= 2 timed), weighted by the stack's call "
-                        f"counts (= {t16:.1f} s for the 48-adapter step; `value`); " if b16 is not None else "B=16 sample skipped (time budget); ") +
+                logical_cpus=ncpu, physical_cores=physical, value_b1=b1, value_b16=b16, b16_cold_shapes=cold16,
+                sample=(f"B=16: fwd+bwd of each of the {n16} distinct adapter shapes at BT=160 (one warm-up pass + one timed pass; {cold16} shape(s) timed cold "
+                        f"once the leg's own {b16_seconds:.0f} s budget ran out), weighted by the stack's call "
+                        f"counts (= {t16:.1f} s for the 48-adapter step; `value`); ") +
                        f"B=1: 1 clip (BT=10) x 48 adapters, median of {len(times)} passes after 1 warm-up ({t:.2f} s/pass; `value_b1`).  "
                        f"fp32, oracle.forward_autograd (ATen op-for-op port of the reference adapter on token-major maps: at least as fast "
                        f"as the reference's permuted-view path), thread count picked by a sweep")
@@ -423,6 +471,11 @@ def main():
         except Exception:
             pass
         stack.concurrent, _ops.USE_AUX_STREAM = conc, aux
+        per_stage = None
+        try:                                            # the step's own (concurrent) schedule again, with per-call event pairs
+            per_stage = stage_breakdown(lib, stages, local_step, BT, MFMA_PEAK_TFLOPS[args.dtype])
+        except Exception as ex:                         # diagnostics only: never lose the bench line over it
+            per_stage = dict(error=str(ex))
         if reducer is not None:
             reducer.paused = False
         alg = 3.0 * alg_flops_per_frame(stages) * BT                 # fwd + bwd, per step
@@ -465,7 +518,7 @@ def main():
                         launches_per_step=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
                         gemm_ms_per_step=round(gemm_ms / nprof, 3), heaviest_launch=heaviest,
-                        step_frac_of_mfma_peak=step_block["frac_of_mfma_peak"], step=step_block)
+                        step_frac_of_mfma_peak=step_block["frac_of_mfma_peak"], step=step_block, per_stage=per_stage)
     dp_info = None
     if dp:
         # what a driver log needs to diagnose a multi-GPU run without a second one: ranks RCCL really has, buckets launched from
@@ -476,6 +529,8 @@ def main():
         mine = torch.tensor([host_s / args.steps * 1e3, elapsed_local / args.steps * 1e3], device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
+        hook_launches = int(getattr(reducer, "last_hook_launches", 0))      # of the last TIMED step: the A/B leg below runs paused,
+        relaunches = int(getattr(reducer, "relaunches", 0))                 # and its finish() resets the counters
         reducer.paused = reducer.skip_exchange = True
         nab = max(3, min(args.steps, 10))
         step()
@@ -489,8 +544,8 @@ def main():
         tt = torch.tensor([no_comm_ms], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dp_info = dict(world=world, backend=dist.get_backend(), rccl_ranks=dist.get_world_size(), overlap=bool(reducer.overlap),
-                       buckets=len(reducer.buckets), hook_launches_last_step=int(getattr(reducer, "last_hook_launches", 0)),
-                       relaunches=int(getattr(reducer, "relaunches", 0)), grad_mbytes=round(sum(p.numel() for p in params) * 4 / 1e6, 1),
+                       buckets=len(reducer.buckets), hook_launches_last_step=hook_launches,
+                       relaunches=relaunches, grad_mbytes=round(sum(p.numel() for p in params) * 4 / 1e6, 1),
                        rank_ms_per_step_min_max=[round(min(float(a[1]) for a in allr), 3), round(max(float(a[1]) for a in allr), 3)],
                        rank_host_ms_min_max=[round(min(float(a[0]) for a in allr), 2), round(max(float(a[0]) for a in allr), 2)],
                        ms_per_step_without_exchange=round(tt.item(), 3), allreduce_exposed_ms=round(ms_per_step - tt.item(), 3),

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void gate_bwd_finish_k(const GFin p) {
   if (sl != 0 || i >= p.L) return;
   const float s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
   float* dst = i < p.C ? (p.dlnw ? p.dlnw + i : nullptr) : i < 2 * p.C ? (p.dlnb ? p.dlnb + (i - p.C) : nullptr)
-             : i < 2 * p.C + p.DD ? p.dbv2 + (i - 2 * p.C) : p.dbs;
+             : i < 2 * p.C + p.DD ? (p.dbv2 ? p.dbv2 + (i - 2 * p.C) : nullptr) : p.dbs;
   if (dst) *dst += s;
 }
 
@@ -1204,6 +1204,7 @@ void gatemod_bwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq
     a.wpf = best;
     const long items = (long)B * best;
     nwg = (int)(items < cus ? items : cus);
+    if ((long)nwg * L > part_floats) { set_error("gatemod_bwd: partial-sum scratch too small for %d workgroups", nwg); nwg = 0; return; }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, st, a);
   };
   if ((long)1024 * L > part_floats) { set_error("gatemod_bwd: partial-sum scratch too small"); return; }
@@ -1212,6 +1213,7 @@ void gatemod_bwd(const Ctx& ctx, const void* X1, const float* ch, const void* aq
     case 128: if (lnw) launch(gatemod_bwd_k<128, true>); else launch(gatemod_bwd_k<128, false>); break;
     default: set_error("gatemod_bwd: unsupported width %d", C); return;
   }
+  if (nwg <= 0) return;
   GFin f{part, nwg, L, C, C / 2, dlnw, dlnb, dbv2, dbs};
   hipLaunchKernelGGL(gate_bwd_finish_k, dim3((L + 63) / 64), dim3(256), 0, st, f);
 }

@@ -22,7 +22,9 @@ bool gemm_skinny_try(const Ctx& ctx, const Gemm& g);
 int gemm_skinny_mode(int set);      // 0: off, 1: on (default; DGSCT_GEMM_SKINNY).  set < 0: query.
 
 // Weight gradients over the token rows (both operands [rows][width], a small output, a very deep contraction): one stream over the
-// two tensors, output tiles dealt to the waves (gemm_tall.hip).  Same contract as gemm8_try.
+// two tensors, output tiles dealt to the waves (gemm_tall.hip).  Same contract as gemm8_try.  CONTRACT: MN-major operands handed to gemm() must point at
+// COLUMN 0 of their [rows][ld] tensor (a column slab is selected with `bs`, not by offsetting the base pointer): this kernel reads
+// whole ld-wide rows from the pointer, and an offset base would run past the end of the tensor in the last 64-row block.
 bool gemm_tall_try(const Ctx& ctx, const Gemm& g);
 int gemm_tall_mode(int set);        // 0: off, 1: on (default; DGSCT_NO_GEMM_TALL).  set < 0: query.
 

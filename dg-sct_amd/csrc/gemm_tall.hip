@@ -142,7 +142,10 @@ bool gemm_tall_try(const Ctx& ctx, const Gemm& g0) {
   if ((g.A.ld * GT_RB * 2) % 16 || (g.B.ld * GT_RB * 2) % 16) return false;
   if (g.A.bs % 2 || g.B.bs % 2) return false;
   const int wsa = g.batch > 1 && g.A.bs % 4 ? 2 : 0, wsb = g.batch > 1 && g.B.bs % 4 ? 2 : 0;     // worst shift of a slab start
-  // the column slabs must lie inside a row (a padded tile may read past its slab, never past the image + 64 bytes)
+  // The kernel streams WHOLE 64-row x ld blocks starting at A.p / B.p, so both pointers must sit at COLUMN 0 of a row (ADVICE r4:
+  // a base + column_offset operand reads column_offset elements past the tensor in its last block).  That cannot be seen from the
+  // pointer; what can be is checked -- the column slabs must lie inside a row -- and the contract is stated in gemm_int.h: every
+  // caller in plan.cpp passes whole tensors (slabs selected through `bs`, never through the base pointer).
   if ((long)(g.batch - 1) * g.A.bs + g.M > g.A.ld || (long)(g.batch - 1) * g.B.bs + g.N > g.B.ld) return false;
   if ((wsa && g.M > 30) || (wsb && g.N > 30)) return false;   // (a shifted slab must fit ONE tile: the stage-0 bottleneck widths do)
   const int mt = (g.M + 31) / 32, nt = (g.N + 31) / 32;

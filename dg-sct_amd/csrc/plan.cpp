@@ -75,6 +75,11 @@ static bool wt_enabled() {
   return !off;
 }
 
+static bool vq1_dw_enabled() {
+  const char* e = getenv("DGSCT_VQ1_DW");
+  return e && atoi(e) != 0;
+}
+
 void Plan::layout() {
   // ---- prep: E copies of the GEMM weights (bf16 mode only) + derived fp32 vectors
   {
@@ -199,7 +204,10 @@ void Plan::layout() {
     wb.rowpart = a.take("rowpart", row_part_floats(B, C) * 4);
     wb.rowpart_v1 = a.take("rowpart_v1", row_part_floats(B, C) * 4);   // partial sums whose second stage runs on the aux stream: not reused
     wb.rowpart_v2 = a.take("rowpart_v2", row_part_floats(B, C) * 4);
-    wb.vq1part = vq1_fused_shape(E, N, C) ? a.take("vq1part", vq1_wpart_floats(C) * 4) : -1;   // per-workgroup dWv1 partials of vq1_bwd
+    // per-workgroup dWv1 partials of vq1_bwd's experiment variant ("vq1fuse" = 3, slower, off by default): 19-34 MB that only that
+    // mode reads, so the region exists only when the process opted in (DGSCT_VQ1_DW=1, read per layout: tests set it around the call);
+    // without it "vq1fuse" = 3 behaves like 1
+    wb.vq1part = (vq1_fused_shape(E, N, C) && vq1_dw_enabled()) ? a.take("vq1part", vq1_wpart_floats(C) * 4) : -1;
     ws_bwd_bytes = a.off;
   }
   // ---- gradients (flat fp32)

@@ -56,14 +56,25 @@ static void order_after(hipStream_t waiter, hipStream_t producer, int dir) {
 // Launch errors are sticky per thread: one check at the end of an entry point reports the first failed launch of the call
 // (a wrong current device, an invalid configuration) instead of returning 0 with uninitialised outputs.
 // A pending (non-sticky) HIP error may belong to ANOTHER user of the runtime on this thread (a PyTorch launch whose status has not
-// been read yet): it is remembered at entry, NOT consumed, and an error found at exit counts as this call's only when it differs
-// from it -- the other library still sees its own error.
+// been read yet): it is remembered at entry and NOT consumed while this call raises nothing.  At exit:
+//   * no error, or the very error that was pending at entry and no launch of ours in between could tell them apart -> see below;
+//   * a DIFFERENT code than the one pending at entry: ours, consumed and reported;
+//   * the SAME code as at entry: hipPeekAtLastError cannot say whether one of this call's own launches failed with that
+//     code as well (launch errors overwrite each other, they do not queue), and returning 0 with unwritten outputs is the worse
+//     mistake -- so it is reported as this call's error too (the message names the ambiguity) and consumed, which also ends the
+//     masking for later calls.  (HIP-version note: this relies on hipPeekAtLastError / hipGetLastError returning the LAST non-sticky
+//     error of the calling thread, which is what ROCm 6.x / 7.x implement; HIP releases before 5.6 kept a per-device value.)
 static thread_local hipError_t g_pre_err = hipSuccess;
 void check_async(const char* where) {
   const hipError_t e = hipPeekAtLastError();
-  if (e == hipSuccess || e == g_pre_err) return;
+  if (e == hipSuccess) return;
   (void)hipGetLastError();
-  set_error("%s: HIP error '%s' (is the current device the one that owns the buffers and streams?)", where, hipGetErrorString(e));
+  if (e == g_pre_err)
+    set_error("%s: HIP error '%s' was already pending on this thread when the call started (raised by another user of the HIP runtime) "
+              "and cannot be told from a failed launch of this call: the outputs are not to be trusted", where, hipGetErrorString(e));
+  else
+    set_error("%s: HIP error '%s' (is the current device the one that owns the buffers and streams?)", where, hipGetErrorString(e));
+  g_pre_err = hipSuccess;
 }
 void clear_async() { g_pre_err = hipPeekAtLastError(); }
 void* stream_create(int priority_class) {

@@ -430,6 +430,7 @@ def test_vq1_without_the_tensor_equals_the_launches_it_replaces(shape, flavour, 
             res.append((out.float(), amap, dX.float(), dY.float(), [g.clone() if g is not None else None for g in grads], mvq1))
     finally:
         lib.test_tune("vq1fuse", old)
+        os.environ.pop("DGSCT_VQ1_DW", None)
     a, b = res
     assert _l2(a[5], b[5]) < 2e-3, _l2(a[5], b[5])
     for i, name in enumerate(("out", "map")):
@@ -457,9 +458,11 @@ def test_vq1_backward_with_the_weight_gradient_inside():
     dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
     res = []
     old = lib.test_tune("vq1fuse", -1)
+    os.environ["DGSCT_VQ1_DW"] = "1"           # the variant's scratch region is laid out only for processes that opt in (plan.cpp)
     try:
         for mode in (1, 3):
             lib.test_tune("vq1fuse", mode)
+            spec = spec_of(cfg)                # (fresh descriptor: dgsct_query results are cached per descriptor object)
             params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
             prep = ops.prepare(lib, spec, params, dtype, DEV)
             out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
@@ -468,6 +471,7 @@ def test_vq1_backward_with_the_weight_gradient_inside():
             res.append((dX.float(), grads[PARAM_NAMES.index("fc_affine_video_1.weight")].clone(), grads[PARAM_NAMES.index("fc_affine_video_1.bias")].clone()))
     finally:
         lib.test_tune("vq1fuse", old)
+        os.environ.pop("DGSCT_VQ1_DW", None)
     a, b = res
     # (upstream of vq1's backward the per-frame gate gradients are fp32 atomic sums: two runs differ in their last bits, and so
     #  does everything downstream -- hence not torch.equal)

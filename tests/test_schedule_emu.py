@@ -87,12 +87,14 @@ def test_schedule_with_vq1_materialised_fp32(emu, name):
     fx = load_golden(name)
     tol = 1e-4
     old = emu.test_tune("vq1fuse", 3)        # 3: dWv1 accumulated inside vq1_bwd (the experiment variant of the schedule)
+    os.environ["DGSCT_VQ1_DW"] = "1"         # its scratch region is laid out only on request (plan.cpp: layout())
     try:
         r3 = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
         emu.test_tune("vq1fuse", 0)
         r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
     finally:
         emu.test_tune("vq1fuse", old)
+        os.environ.pop("DGSCT_VQ1_DW", None)
     for k, g in fx["grads"].items():
         assert rel_err(r3["grads"][k].reshape(g.shape), g) < tol, k
     assert rel_err(r3["dX"], fx["dX"]) < tol

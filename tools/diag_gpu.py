@@ -41,8 +41,13 @@ def main(name="ave_orderA", dtype=torch.float32):
     params = param_table(state, spec, dev)
     X = fx["X"].to(dev, dtype).contiguous(); Y = fx["Y"].to(dev, dtype).contiguous()
     prep = ops.prepare(lib, spec, params, dtype, dev)
-    out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
-    torch.cuda.synchronize()
+    old = [(k, lib.test_tune(k, 2)) for k in ("gatefuse", "vq1fuse")]     # 2: the fused passes also materialise vq2 / vq1 for this dump
+    try:
+        out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+        torch.cuda.synchronize()
+    finally:
+        for k, v in old:
+            lib.test_tune(k, v)
     regs = lib.saved_regions(d)
     B, N, C, No, Co, tk = X.shape[0], spec.N, spec.C, spec.No, spec.Co, spec.tk
     Np, Nop, tkp = (N + 7) // 8 * 8, (No + 7) // 8 * 8, (tk + 7) // 8 * 8
@@ -50,6 +55,8 @@ def main(name="ave_orderA", dtype=torch.float32):
     E = dtype
 
     def view(nm, dt, shape):
+        if nm not in regs:                 # region not part of this shape's layout (P1 / P2 since round 2, Xc for the fused gate passes)
+            return None
         off, nb = regs[nm]
         n = 1
         for x in shape:
@@ -57,6 +64,9 @@ def main(name="ave_orderA", dtype=torch.float32):
         return saved[off:off + n * torch.empty(0, dtype=dt).element_size()].view(dt).view(*shape).float().cpu()
 
     def show(tag, got, ref):
+        if got is None:
+            print(f"  {tag:10s} (not stored by this schedule)")
+            return
         ref = ref.float()
         e = (got - ref).abs().max().item()
         print(f"  {tag:10s} max|err| {e:.3e}   max|ref| {ref.abs().max().item():.3e}   {'<<<<< BAD' if not e < 2e-2 * max(1, ref.abs().max().item()) else ''}")
@@ -67,10 +77,8 @@ def main(name="ave_orderA", dtype=torch.float32):
         show("T1", view("T", E, (B, N, Co)), s["T1"])
     else:
         show("T2t", view("T", E, (B, C, Nop))[..., :No], s["T2t"])
-    show("P1", view("P1", E, (B, tk, Np))[..., :N], s["P1"])
-    show("tok", view("tok", E, (B, tk, C)), s["tok"])
+    show("tok", view("tok", torch.float32, (B, tk, C)), s["tok"])
     show("a", view("a", torch.float32, (B, C)), s["a"])
-    show("P2", view("P2", E, (B * N, tkp))[..., :tk].view(B, N, tk), s["P2"])
     show("X1", view("X1", E, (B, N, C)), s["X1"])
     show("aq1", view("aq1", E, (B, C)), s["aq1"])
     show("aq2", view("aq2", E, (B, dd)), s["aq2"])
