@@ -865,6 +865,10 @@ static void launch_cfg(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s,
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// what-if switch (TIMING ONLY, results wrong): split-K partial tiles leave as plain stores instead of fp32 atomics -- what the atomics cost
+static std::atomic<int> g_noatomic{0};
+int gemm_noatomic_mode(int set) { const int old = g_noatomic.load(); if (set >= 0) g_noatomic.store(set); return old; }
+
 template <int MODE>
 static void gemm_mode(const Ctx& ctx, const Gemm& g) {
   constexpr int ES = MODE == DT_BF16 ? 2 : 4;
@@ -1004,6 +1008,7 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     k.xgm = (k.tiles_m + ngroups - 1) / ngroups;
     k.xnb = g.batch / 8;
   }
+  if (g_noatomic.load(std::memory_order_relaxed)) k.atomic = 0;
   hipStream_t s = (hipStream_t)ctx.stream;
   ProfRec shp{};
   shp.M = g.M; shp.N = g.N; shp.K = g.K; shp.KB = g.KB; shp.batch = g.batch; shp.splitk = splitk; shp.cfg = cfg;

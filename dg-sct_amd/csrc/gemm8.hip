@@ -441,6 +441,11 @@ int gemm8_mode(int set) {
   return old;
 }
 
+// experiment knob ("g8wg"): late-stage weight gradients (few output tiles, very deep contraction) on this kernel with only as many
+// split-K slabs as give ~`target` workgroups (one per CU): fewer CUs for longer instead of every CU for a short, atomics-heavy burst
+static std::atomic<int> g_g8wg{getenv("DGSCT_G8WG") ? atoi(getenv("DGSCT_G8WG")) : 0};
+int gemm8_wg_target(int set) { const int old = g_g8wg.load(); if (set >= 0) g_g8wg.store(set); return old; }
+
 bool gemm8_try(const Ctx& ctx, const Gemm& g) {
   // DGSCT_GEMM8=0 switches the kernel off (A/B runs against the tiled engine); =2 also takes shapes below the size gates
   const int mode = gemm8_mode(-1);
@@ -496,6 +501,13 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
 
     // Few output tiles = many splits of a handful of k-tiles each: prologue / epilogue bound and 60-way atomics per address.
     // Measured (tools/gemm8_ab_all.sh): 512 x 512 x 23 040 36.7 -> 61 us, 1024 x 1024 x 5 760 35.9 -> 59 us -- the tiled engine keeps them.
+    const int wgt = g_g8wg.load(std::memory_order_relaxed);
+    if (wgt > 0 && tiles < 96 && !two && kt_total >= 48) {
+      splitk = (int)((wgt + tiles - 1) / tiles);
+      if (splitk > kt_total / 8) splitk = kt_total / 8;
+      if (splitk < 1) splitk = 1;
+      goto split_done;
+    }
     if (mode < 2 && tiles < 96) return false;
     // dWn with both operands K-major (2304 x 4096 x (160 x 96)): 434 vs 443 us alone, 455 vs 515 us inside the step (seven 256 x 256
     // fp32 atomic slabs per tile against the tiled engine's two) -- stays on the tiled engine; the K-major x MN-major one gains 12 %
@@ -514,6 +526,7 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
     return false;                                               // too few tiles to fill the chip without split-K
   }
   if (mode < 2 && !plain && tiles * splitk < 128) return false;
+split_done:
   const int kt_per_split = (kt_total + splitk - 1) / splitk;
   splitk = (kt_total + kt_per_split - 1) / kt_per_split;
 

@@ -11,6 +11,7 @@
 #include "plan.h"
 #include <cstdlib>
 
+#include <atomic>
 #include <functional>
 #include <vector>
 
@@ -70,6 +71,16 @@ bool Plan::validate() {
   return true;
 }
 
+// ---- what-if switches (TIMING EXPERIMENTS ONLY: results are garbage).  dgsct_test_tune("skip", mask) leaves classes of launches out
+// of the schedule so that the wall-time share of each class can be measured inside the real step (tools/call_overlap.py):
+//   1 weight-gradient GEMMs on the aux stream    2 relu_bwd_scale    4 xc_bwd    8 bn_bwd_apply    16 scale_cols + rowdot (forward)
+//   32 bn_stats + affine_act    64 colsum of vq1 / u    128 the four attention kernels    256 modln fwd / bwd    512 tail fwd / bwd
+//   1024 the [rows, C] x [C, C] chain GEMMs (vq1, vq2, dXc, dX1 +=)    2048 the remap GEMMs    4096 the bottleneck GEMMs
+// "skipminc": only for adapters at least that wide (default 0).
+static std::atomic<int> g_skip{0}, g_skip_minc{0};
+int plan_skip_mode(int set) { const int old = g_skip.load(); if (set >= 0) g_skip.store(set); return old; }
+int plan_skip_minc(int set) { const int old = g_skip_minc.load(); if (set >= 0) g_skip_minc.store(set); return old; }
+
 static bool wt_enabled() {
   static const bool off = getenv("DGSCT_NO_WT") != nullptr;      // A/B switch: no transposed weight copies
   return !off;
@@ -108,6 +119,9 @@ void Plan::layout() {
     wcopy(DGSCT_P_WU, (int64_t)C * (ds / g));
     wtcopy(DGSCT_P_WC, Co); wtcopy(DGSCT_P_WA1, C); wtcopy(DGSCT_P_WV1, C); wtcopy(DGSCT_P_WB, C); wtcopy(DGSCT_P_WV2, C);
     wtcopy(DGSCT_P_WA2, C); wtcopy(DGSCT_P_WCATT, dd);
+    // (round 5) the grouped bottleneck weights as well: the data-gradient products of the late stages run on the fused engine
+    // (gemm_fx.hip: BatchNorm backward applied while the A operand is staged), which takes K-major operands only
+    wtcopy(DGSCT_P_WU, ds / g); wtcopy(DGSCT_P_WD, C / g);
     prep_rowb = a.take("rowb", (int64_t)N * 4);
     prep_colb = a.take("colb", (int64_t)C * 4);
     prep_colb2 = a.take("colb2", (int64_t)C * 4);
@@ -126,6 +140,8 @@ void Plan::layout() {
     // zero block first (atomically accumulated in forward)
     s.a = a.take("a", (int64_t)B * C * 4);
     s.mvq1 = a.take("mvq1", (int64_t)B * C * 4);
+    s.cnt1 = a.take("cnt1", (int64_t)B * C * 4);             // number of positive vq1 entries per (frame, channel): the bias gradient of
+                                                              // fc_affine_video_1 once its ReLU backward is folded into the next product
     s.bnacc1 = a.take("bnacc1", (int64_t)3 * ds * 4);
     s.bnacc2 = a.take("bnacc2", (int64_t)3 * C * 4);
     s.zero_end = a.off;
@@ -178,6 +194,7 @@ void Plan::layout() {
     wb.dwcsum = a.take("dwcsum", (int64_t)C * 4);
     wb.dtokF = a.take("dtokF", (int64_t)B * tk * C * 4);
     wb.dT0b = a.take("dT0b", (int64_t)B * tk * C * 4);
+    wb.w2 = a.take("w2", (int64_t)B * dd * 4);                 // sum_n dsl (vq2 > 0) per (frame, channel): d bias(vq2) without the dvq2 column sum
     wb.zero_end = a.off;
     wb.dO = a.take("dO", R * C * es);
     wb.dZ = a.take("dZ", R * ds * es);
@@ -185,6 +202,11 @@ void Plan::layout() {
     wb.dX1 = a.take("dX1", R * C * es);
     wb.dXc = a.take("dXc", R * C * es);
     wb.Xc = xc_scratch ? a.take("Xc", R * C * es) : -1;
+    wb.dvq1 = a.take("dvq1", R * C * es);                      // fused engine: the masked cotangents are written beside their inputs
+    wb.dvq2 = a.take("dvq2", R * dd * es);                     // (another n-tile may still be reading the input: not in place)
+    wb.dZp = a.take("dZp", R * ds * es);
+    wb.t1 = a.take("t1", (int64_t)B * C * 4);
+    wb.t3 = a.take("t3", (int64_t)B * dd * 4);
     wb.dsg = a.take("dsg", R * 4);
     wb.dsl = a.take("dsl", R * 4);
     wb.tmpBd = a.take("tmpBd", (int64_t)B * dd * 4);
@@ -282,6 +304,11 @@ struct Bound {
   MatOp WB(int id, long in, long out) const {
     return P.prep_wt[id] >= 0 ? km(prep + P.prep_wt[id], out) : mn(W(id), in);
   }
+  // ... of a GROUPED projection W [out][in / g] (row stride `in_g`, group stride gs): the transposed copy [in_g][out] puts group b's
+  // block at column b * out_g (K-major: row = in-group input channel, ld = out, batch stride out_g)
+  MatOp WBg(int id, long in_g, long out, long out_g, long gs) const {
+    return P.prep_wt[id] >= 0 ? km(prep + P.prep_wt[id], out, out_g) : mn(W(id), in_g, gs);
+  }
   template <typename T = void> T* S(int64_t off) const { return reinterpret_cast<T*>(saved + off); }
   template <typename T = void> T* Wk(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
   const float* rowb() const { return reinterpret_cast<const float*>(prep + P.prep_rowb); }
@@ -340,6 +367,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   Ctx side = ctx;
   if (aux_stream) { side.stream = aux_stream; side.aux = nullptr; }
   const float invN = 1.f / (float)N;
+  const int SK = C >= g_skip_minc.load(std::memory_order_relaxed) ? g_skip.load(std::memory_order_relaxed) : 0;   // what-if switches
   zero(ctx, b.S(0), (size_t)s.zero_end);
 
   // F1 ---- cross-modal remap                                            net_trans.py:553-555
@@ -349,7 +377,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     g1.A = km(b.W(DGSCT_P_WN), No);
     g1.B = mn(Y, Co, (long)No * Co);
     outE(g1, b.S(s.T), E, Co, (long)N * Co);
-    gemm(ctx, g1);
+    if (!(SK & 2048)) gemm(ctx, g1);
     Gemm g2 = mk((int)R, C, Co);                                 // Yp = T1 . Wc^T + rank-1 bias
     g2.A = km(b.S(s.T), Co);
     g2.B = km(b.W(DGSCT_P_WC), Co);
@@ -359,24 +387,24 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       gemm_fp8(ctx, (int)R, C, Co, b.S(s.T), Co, b.prep + prep_w8[0], (const float*)(b.prep + prep_w8scale) + 0, b.colb2(), 0, Yp, C,
                b.rowb(), b.colb(), N);
     } else {
-      gemm(ctx, g2);
+      if (!(SK & 2048)) gemm(ctx, g2);
     }
   } else {
     Gemm g1 = mk(C, No, Co, B);                                  // T2t[b] = Wc . Y[b]^T   [C][No]
     g1.A = km(b.W(DGSCT_P_WC), Co);
     g1.B = km(Y, Co, (long)No * Co);
     outE(g1, b.S(s.T), E, Nop, (long)C * Nop);
-    gemm(ctx, g1);
+    if (!(SK & 2048)) gemm(ctx, g1);
     Gemm g2 = mk(N, C, No, B);                                   // Yp[b] = Wn . T2[b]
     g2.A = km(b.W(DGSCT_P_WN), No);
     g2.B = km(b.S(s.T), Nop, (long)C * Nop);
     g2.r1_m = b.rowb(); g2.r1_n = b.colb(); g2.bias_n = b.colb2();
     outE(g2, Yp, E, C, (long)N * C);
-    gemm(ctx, g2);
+    if (!(SK & 2048)) gemm(ctx, g2);
   }
   // F2 ---- latent tokens attend to the remapped tokens (one pass over Yp)   :572-580, :592
   void* tokpk = s.tokpk >= 0 ? b.S(s.tokpk) : nullptr;
-  tokattn_fwd(ctx, Yp, b.F(DGSCT_P_TOKENS), B, N, C, tk, b.S<float>(s.tok), b.S<float>(s.lse), b.S<float>(s.a), b.S(s.aE),
+  if (!(SK & 128)) tokattn_fwd(ctx, Yp, b.F(DGSCT_P_TOKENS), B, N, C, tk, b.S<float>(s.tok), b.S<float>(s.lse), b.S<float>(s.a), b.S(s.aE),
               b.Wk<float>(wf.tokscr), tokpk, prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr);
   {
     stream_fork(ctx);                                            // a = mean_N(Yp) is complete on the main stream
@@ -390,7 +418,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     gemm(side, g2);
   }
   // F3 ---- X attends to the latent tokens (one pass over X)             :583-589
-  xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1), tokpk);
+  if (!(SK & 128)) xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1), tokpk);
   // F4-F6 ---- channel gate                                              :593-598
   {
     if (vq1_fused_supported(ctx.mode, N, C) && !fp8) {
@@ -403,8 +431,9 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       g3.A = km(b.S(s.X1), C); g3.B = km(b.W(DGSCT_P_WV1), C); g3.bias_n = b.F(DGSCT_P_BV1); g3.act = ACT_RELU;
       outE(g3, b.S(s.vq1), E, C);
       if (fp8) gemm_fp8(ctx, (int)R, C, C, b.S(s.X1), C, b.prep + prep_w8[1], (const float*)(b.prep + prep_w8scale) + 1, b.F(DGSCT_P_BV1), 1, b.S(s.vq1), C);
-      else gemm(ctx, g3);
-      colsum_batched(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C);
+      else if (!(SK & 1024)) gemm(ctx, g3);
+      // mean_N vq1, and the number of positive entries per (frame, channel) for the backward (same pass over vq1)
+      if (!(SK & 64)) colsum_batched_pos(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C, b.S<float>(s.cnt1), C);
     }
     stream_join(ctx);                                            // aq1 / aq2 / a from the aux stream
     if (skinny_fused_supported(ctx, B, dd, C, 0)) {              // q = relu(m1 Wb^T + b), m1 = aq1 * mean_N vq1 made (and stored) on the way in
@@ -446,13 +475,13 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map), map);   // saved copy + the returned map
   } else {
     void* Xcf = xc_scratch ? b.Wk(wf.Xc) : b.S(s.Xc);
-    scale_cols(ctx, b.S(s.X1), Xcf, B, N, C, b.S<float>(s.ch), 1.f);              // Xc = X1 * (1 + ch)
+    if (!(SK & 16)) scale_cols(ctx, b.S(s.X1), Xcf, B, N, C, b.S<float>(s.ch), 1.f);              // Xc = X1 * (1 + ch)
     Gemm g1 = mk((int)R, dd, C);                                 // vq2 = relu(Xc Wv2^T + b)
     g1.A = km(Xcf, C); g1.B = km(b.W(DGSCT_P_WV2), C); g1.bias_n = b.F(DGSCT_P_BV2); g1.act = ACT_RELU;
     outE(g1, b.S(s.vq2), E, dd);
     if (fp8) gemm_fp8(ctx, (int)R, dd, C, Xcf, C, b.prep + prep_w8[2], (const float*)(b.prep + prep_w8scale) + 2, b.F(DGSCT_P_BV2), 1, b.S(s.vq2), dd);
-    else gemm(ctx, g1);
-    rowdot_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.S(s.aq2), E, dd, b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
+    else if (!(SK & 1024)) gemm(ctx, g1);
+    if (!(SK & 16)) rowdot_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.S(s.aq2), E, dd, b.F(DGSCT_P_WS), b.F(DGSCT_P_BS),
                    b.S<float>(s.sl));
     spatial_fwd(ctx, b.S<float>(s.sl), B, N, b.S<float>(s.sg), b.S<float>(s.map), map);   // saved copy + the returned map
     // (stages 0-1 without the gate fusion: modulation + ln_before + down-projection + BN1 sums in one pass, see modln_gproj)
@@ -461,7 +490,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
                   d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C, ds, g,
                   b.F(DGSCT_P_WD), (long)(ds / g) * (C / g), C / g, 1, b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b), b.S(s.Zp),
                   d.use_bn && d.training ? b.S<float>(s.bnacc1) : nullptr);
-    else
+    else if (!(SK & 256))
       modln_fwd(ctx, b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), d.temporal ? b.S<float>(s.tg) : nullptr, d.alpha, d.beta,
                 d.gamma, d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, d.ln_before ? b.F(DGSCT_P_LNB_B) : nullptr, d.eps, B, N, C,
                 b.S(s.X3), b.S<float>(s.mu_b), b.S<float>(s.rstd_b));
@@ -482,13 +511,13 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       g1.A = km(b.S(s.X3), C, C / g);
       g1.B = km(b.W(DGSCT_P_WD), C / g, (long)(ds / g) * (C / g));
       outE(g1, b.S(s.Zp), E, ds, ds / g);
-      gemm(ctx, g1);
+      if (!(SK & 4096)) gemm(ctx, g1);
     }
     if (d.use_bn) {                                              // BN1: finalised inside the pass that applies it (BnFin)
-      if (d.training && !fuse89 && !gfuse) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
+      if (d.training && !fuse89 && !gfuse && !(SK & 32)) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
       const BnFin f1{b.S<float>(s.bnacc1), R, b.F(DGSCT_P_BN1_W), b.F(DGSCT_P_BN1_B), b.Fm(DGSCT_P_BN1_RM), b.Fm(DGSCT_P_BN1_RV),
                      d.bn_momentum, d.eps, d.training, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds};
-      affine_act_bn(ctx, b.S(s.Zp), b.S(s.Z), R, ds, f1, 1);
+      if (!(SK & 32)) affine_act_bn(ctx, b.S(s.Zp), b.S(s.Z), R, ds, f1, 1);
     } else {
       affine_act(ctx, b.S(s.Zp), b.S(s.Z), R, ds, nullptr, nullptr, 1);
     }
@@ -500,14 +529,14 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       g2.A = km(b.S(s.Z), ds, ds / g);
       g2.B = km(b.W(DGSCT_P_WU), ds / g, (long)(C / g) * (ds / g));
       outE(g2, b.S(s.Op), E, C, C / g);
-      gemm(ctx, g2);
+      if (!(SK & 4096)) gemm(ctx, g2);
     }
-    if (d.use_bn && stats2 && !vproj) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
+    if (d.use_bn && stats2 && !vproj && !(SK & 32)) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
   }
   // F11 ---- BN2 finalised + applied, ln_post / gate                     :668-671
   const BnFin f2{b.S<float>(s.bnacc2), R, b.F(DGSCT_P_BN2_W), b.F(DGSCT_P_BN2_B), b.Fm(DGSCT_P_BN2_RM), b.Fm(DGSCT_P_BN2_RV),
                  d.bn_momentum, d.eps, d.training, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C};
-  tail_fwd(ctx, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr,
+  if (!(SK & 512)) tail_fwd(ctx, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr,
            d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
            d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, d.eps, R, C, out, b.S<float>(s.mu_p),
            b.S<float>(s.rstd_p), residual,         // f2: out = residual + adapter(X, Y)
@@ -547,17 +576,33 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   const int cg = C / g, dg = ds / g;
   const float invN = 1.f / (float)N;
   const bool vproj = gproj_supported(ctx.mode, C, ds, g);
+  const int SK = C >= g_skip_minc.load(std::memory_order_relaxed) ? g_skip.load(std::memory_order_relaxed) : 0;   // what-if switches
+  // (weight-gradient products on the aux stream: every one of them goes through wgemm)
+  auto wgemm = [SK](const Ctx& c, const Gemm& gg) { if (!(SK & 1)) gemm(c, gg); };
 
   // B11 ---- ln_post / gate, BN2 sums
   void* dO = b.Wk(wb.dO);
-  tail_bwd(ctx, dOut, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr, bn2, bn2 + C,
+  if (!(SK & 512)) tail_bwd(ctx, dOut, b.S(s.Op), d.use_bn ? bn2 + 2 * C : nullptr, d.use_bn ? bn2 + 3 * C : nullptr, bn2, bn2 + C,
            d.ln_post ? b.F(DGSCT_P_LNP_W) : nullptr, d.ln_post ? b.F(DGSCT_P_LNP_B) : nullptr,
            d.use_gate ? b.F(DGSCT_P_GATE) : nullptr, d.gate_before_ln_post, b.S<float>(s.mu_p), b.S<float>(s.rstd_p), R, C,
            dO, G(DGSCT_P_LNP_W), G(DGSCT_P_LNP_B), G(DGSCT_P_GATE), d.use_bn ? G(DGSCT_P_BN2_B) : nullptr,
            d.eps, b.Wk<float>(wb.rowpart), row_part_floats(B, C));
   // B10 ---- BN2 backward, up projection
   const bool bnb = d.use_bn && vproj;                            // BN2 backward inside the narrow projection's pass (stages 0-1)
-  if (d.use_bn && !bnb) {
+  // late stages (round 5): dOp = BN2 backward of dO is formed while the dZ product stages its A operand (gemm_fx.hip) and written
+  // back in place for the dWu product -- no bn_bwd_apply pass over [rows, C]
+  Gemm gdz = mk((int)R, dg, cg, g);                              // dZ = dOp (x)_g Wu
+  GemmFx fdz;
+  bool fx_dz = false;
+  if (d.use_bn && !bnb && !vproj) {
+    gdz.A = km(dO, C, cg);
+    gdz.B = b.WBg(DGSCT_P_WU, dg, C, cg, (long)cg * dg);
+    outE(gdz, b.Wk(wb.dZ), E, ds, dg);
+    fdz.a_pro = APRO_BNBWD; fdz.a2 = b.S(s.Op); fdz.bn_mean = bn2; fdz.bn_rstd = bn2 + C; fdz.bn_sc = bn2 + 2 * C; fdz.bn_sh = bn2 + 3 * C;
+    fdz.bn_sums = G(DGSCT_P_BN2_B); fdz.bn_rows = R; fdz.bn_C = C; fdz.bn_relu = 0; fdz.bn_training = d.training; fdz.a_store = dO;
+    fx_dz = (gemmfx_mode(-1) & 1) && gemm_fx_supported(ctx, gdz, fdz);
+  }
+  if (d.use_bn && !bnb && !fx_dz && !(SK & 8)) {
     bn_bwd_apply(ctx, dO, b.S(s.Op), dO, R, C, bn2, bn2 + C, bn2 + 2 * C, bn2 + 3 * C, G(DGSCT_P_BN2_B), 0, 1, d.training);
   }
   {
@@ -566,18 +611,20 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g1.B = mn(b.S(s.Z), ds, dg);
     outF(g1, G(DGSCT_P_WU), dg, (long)cg * dg);
     atomic_out(g1);
-    defer([=, &side] { gemm(side, g1); });                       // released with dWd
+    defer([=, &side] { wgemm(side, g1); });                       // released with dWd
     if (bnb) {                                                   // dOp = BN2 backward of dO (in place), dZ = dOp (x)_g Wu
       gproj_narrow_bnb(ctx, dO, b.S(s.Op), dO, R, C, ds, g, b.F(DGSCT_P_WU), (long)cg * dg, 1, dg, b.Wk(wb.dZ), bn2, bn2 + C, bn2 + 2 * C,
                        bn2 + 3 * C, G(DGSCT_P_BN2_B), d.training);
     } else if (vproj) {                                          // dZ = dOp (x)_g Wu
       gproj_narrow(ctx, dO, R, C, ds, g, b.F(DGSCT_P_WU), (long)cg * dg, 1, dg, b.Wk(wb.dZ));
+    } else if (fx_dz) {
+      if (!(SK & 4096)) gemm_fx(ctx, gdz, fdz);
     } else {
       Gemm g2 = mk((int)R, dg, cg, g);                           // dZ = dOp (x)_g Wu
       g2.A = km(dO, C, cg);
       g2.B = mn(b.W(DGSCT_P_WU), dg, (long)cg * dg);
       outE(g2, b.Wk(wb.dZ), E, ds, dg);
-      gemm(ctx, g2);
+      if (!(SK & 4096)) gemm(ctx, g2);
     }
   }
   // B9 ---- relu, BN1 backward, down projection
@@ -587,6 +634,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   if (d.use_bn)
     bn_bwd_stats(ctx, dZ, b.S(s.Zp), R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, 1, G(DGSCT_P_BN1_B), b.Wk<float>(wb.rowpart),
                  row_part_floats(B, C));
+  bool t3_valid = false, t1_valid = false;                       // (fused engine) bias gradients of the two query layers as [BT, C] column sums
   Gemm gwd = mk(dg, cg, (int)R, g);                              // dWd = dZp^T (x)_g X3
   gwd.A = mn(dZ, ds, dg);
   gwd.B = mn(b.S(s.X3), C, cg);
@@ -606,34 +654,52 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                 bn1 + 3 * ds, d.use_bn ? G(DGSCT_P_BN1_B) : nullptr, d.use_bn, d.training, dX1, b.S(s.vq2), Xcb,
                 b.Wk<float>(wb.dch), b.Wk<float>(wb.u), b.Wk<float>(wb.dtg), G(DGSCT_P_LNB_W), G(DGSCT_P_LNB_B), G(DGSCT_P_BV2),
                 G(DGSCT_P_BS), b.Wk<float>(wb.rowtmp), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
-    defer([=, &side] { gemm(side, gwd); });
-    defer([=, &side] { gemm(side, gwv2); });
+    defer([=, &side] { wgemm(side, gwd); });
+    defer([=, &side] { wgemm(side, gwv2); });
     side_flush();
     // tmpBd = u * aq2 (d ws = sum_b tmpBd: with the bias gradients below, colsum_multi);  dpa2 = u * ws * (aq2 > 0)
     ew2(ctx, EwCall{EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1},
         EwCall{EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd});
   } else {
   if (xc_scratch) scale_cols(ctx, b.S(s.X1), Xcb, B, N, C, b.S<float>(s.ch), 1.f);   // (unfused test path of a fused shape: Xc is not saved)
-  if (d.use_bn) {
+  Gemm gdx3 = mk((int)R, cg, dg, g);                             // dX3 = dZp (x)_g Wd
+  GemmFx fdx3;
+  bool fx_dx3 = false;
+  if (d.use_bn && !vproj) {                                      // (round 5) dZp = relu' + BN1 backward of dZ formed in the product's staging
+    gdx3.A = km(dZ, ds, dg);
+    gdx3.B = b.WBg(DGSCT_P_WD, cg, ds, dg, (long)dg * cg);
+    outE(gdx3, b.Wk(wb.dX3), E, C, cg);
+    fdx3.a_pro = APRO_BNBWD; fdx3.a2 = b.S(s.Zp); fdx3.bn_mean = bn1; fdx3.bn_rstd = bn1 + ds; fdx3.bn_sc = bn1 + 2 * ds; fdx3.bn_sh = bn1 + 3 * ds;
+    fdx3.bn_sums = G(DGSCT_P_BN1_B); fdx3.bn_rows = R; fdx3.bn_C = ds; fdx3.bn_relu = 1; fdx3.bn_training = d.training; fdx3.a_store = b.Wk(wb.dZp);
+    fx_dx3 = (gemmfx_mode(-1) & 2) && gemm_fx_supported(ctx, gdx3, fdx3);
+  }
+  if (fx_dx3) {
+  } else if (SK & 8) {
+  } else if (d.use_bn) {
     bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds, G(DGSCT_P_BN1_B), 1, 1, d.training);
   } else {
     bn_bwd_apply(ctx, dZ, b.S(s.Zp), dZ, R, ds, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0);
   }
   {
-    defer([=, &side] { gemm(side, gwd); });
+    if (fx_dx3) {
+      if (!(SK & 4096)) gemm_fx(ctx, gdx3, fdx3);
+      gwd.A = mn(b.Wk(wb.dZp), ds, dg);                          // (dWd reads the cotangent the product wrote beside dZ)
+    }
+    defer([=, &side] { wgemm(side, gwd); });
     side_flush();
-    if (vproj) {                                                 // dX3 = dZp (x)_g Wd
+    if (fx_dx3) {
+    } else if (vproj) {                                                 // dX3 = dZp (x)_g Wd
       gproj_wide(ctx, dZ, R, C, ds, g, b.F(DGSCT_P_WD), (long)dg * cg, cg, 1, b.Wk(wb.dX3), nullptr);
     } else {
       Gemm g2 = mk((int)R, cg, dg, g);                           // dX3 = dZp (x)_g Wd
       g2.A = km(dZ, ds, dg);
       g2.B = mn(b.W(DGSCT_P_WD), cg, (long)dg * cg);
       outE(g2, b.Wk(wb.dX3), E, C, cg);
-      gemm(ctx, g2);
+      if (!(SK & 4096)) gemm(ctx, g2);
     }
   }
   // B8 ---- ln_before, modulation
-  modln_bwd(ctx, b.Wk(wb.dX3), b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), tg, d.alpha, d.beta, d.gamma,
+  if (!(SK & 256)) modln_bwd(ctx, b.Wk(wb.dX3), b.S(s.X1), b.S<float>(s.ch), b.S<float>(s.sg), tg, d.alpha, d.beta, d.gamma,
             d.ln_before ? b.F(DGSCT_P_LNB_W) : nullptr, b.S<float>(s.mu_b), b.S<float>(s.rstd_b), B, N, C, dX1,
             G(DGSCT_P_LNB_W), G(DGSCT_P_LNB_B), b.Wk<float>(wb.dch), b.Wk<float>(wb.dsg), b.Wk<float>(wb.dtg),
             b.Wk<float>(wb.rowpart), row_part_floats(B, C));
@@ -641,26 +707,72 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   {
     spatial_bwd(ctx, b.S<float>(s.sl), b.S<float>(s.sg), b.S<float>(s.map), b.Wk<float>(wb.dsg), dMap, B, N,
                 b.Wk<float>(wb.dsl), G(DGSCT_P_BS));
-    colsum_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd);  // u
+    // (round 5) dXc = dvq2 . Wv2 on the fused engine (gemm_fx.hip).  The channel-gate backward (dX1 += dXc (1 + ch), dch += sum_n dXc X1)
+    // runs in the product's epilogue wherever the engine takes the call: no dXc tensor, no xc_bwd pass.  The ReLU backward that makes
+    // dvq2 is folded into the staging of the A operand (vq2) only where few column tiles re-read (and re-transform) it -- C <= 256:
+    // measured inside the step (tools/call_overlap.py AB=gemmfx=..), the prologue wins 48 us per stage-1 pair, is neutral at C = 384 /
+    // 512 and loses 13 us per pair at C = 768 / 1024 (eight column tiles each redo the transform); "gemmfx" bit 16 forces it everywhere.
+    Gemm gxc = mk((int)R, C, dd);
+    gxc.B = b.WB(DGSCT_P_WV2, C, dd);
+    resid(gxc, dX1, E, C);
+    outE(gxc, dX1, E, C);
+    GemmFx fxc;
+    fxc.epi = EPI_XCBWD; fxc.rpf = N;
+    fxc.e_cs = b.S<float>(s.ch); fxc.e_x = b.S(s.X1); fxc.e_acc = b.Wk<float>(wb.dch); fxc.e_ld = C;
+    const int fxm = gemmfx_mode(-1);
+    int fx_xc = 0;                                               // 0: separate launches, 1: epilogue only, 2: prologue + epilogue
+    if (fxm & 4) {
+      gxc.A = km(b.S(s.vq2), dd);
+      if (gemm_fx_supported(ctx, gxc, fxc)) fx_xc = 1;
+      if ((C <= 256 || (fxm & 16)) && !(fxm & 32)) {            // (bit 32: never -- tests reach the epilogue-only variant at small widths)
+        GemmFx f2 = fxc;
+        f2.a_pro = APRO_MASKSCALE; f2.a_rs = b.Wk<float>(wb.dsl); f2.a_cs = b.S(s.aq2); f2.a_cs_dt = E; f2.a_cs_ld = dd; f2.a_cs2 = b.F(DGSCT_P_WS);
+        f2.a_scale = 1.f; f2.a_store = b.Wk(wb.dvq2);
+        if (gemm_fx_supported(ctx, gxc, f2)) { fx_xc = 2; fxc = f2; }
+      }
+    }
+    if (fx_xc == 2) {                                            // u, and w2 = sum_n dsl (vq2 > 0) for d bias(vq2), in the same pass over vq2
+      if (!(SK & 64)) colsum_batched_pos(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd,
+                                         b.Wk<float>(wb.w2), dd);
+    } else
+    if (!(SK & 64)) colsum_batched(ctx, b.S(s.vq2), dd, (long)N * dd, B, N, dd, b.Wk<float>(wb.dsl), N, 1.f, b.Wk<float>(wb.u), dd);  // u
     // tmpBd = u * aq2 (d ws = sum_b tmpBd: with the bias gradients below, colsum_multi);  dpa2 = u * ws * (aq2 > 0)
     ew2(ctx, EwCall{EW_MUL, b.Wk(wb.tmpBd), DT_F32, F32(b.Wk(wb.u)), Earg(b.S(s.aq2), E), NOARG, (long)B * dd, 0.f, 1},
         EwCall{EW_MULB_MASK, b.Wk(wb.dpa2), E, F32(b.Wk(wb.u)), F32(b.F(DGSCT_P_WS)), Earg(b.S(s.aq2), E), (long)B * dd, 0.f, dd});
+    if (fx_xc == 2) {
+      if (!(SK & 1024)) gemm_fx(ctx, gxc, fxc);
+      gwv2.A = mn(b.Wk(wb.dvq2), dd);
+      defer([=, &side, &b] {
+        wgemm(side, gwv2);
+        // d bias(vq2)[j] = sum_b w2[b][j] aq2[b][j] ws[j]
+        ew(side, EW_MUL3B, b.Wk(wb.t3), DT_F32, F32(b.Wk(wb.w2)), Earg(b.S(s.aq2), E), F32(b.F(DGSCT_P_WS)), (long)B * dd, 0.f, dd);
+      });
+      side_flush();
+    } else {
     // dvq2 (in place over vq2) = dsl[b,n] * aq2[b,j]*ws[j] * (vq2 > 0)
     {
       PartJob pj;                                                // d bias(vq2): second stage of the column sums off the chain
       Ctx cl = ctx; cl.late = aux_stream ? &pj : nullptr;
-      relu_bwd_scale(cl, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
+      if (!(SK & 2)) relu_bwd_scale(cl, b.S(s.vq2), b.S(s.vq2), B, N, dd, b.Wk<float>(wb.dsl), b.S(s.aq2), E, b.F(DGSCT_P_WS), 1.f,
                      G(DGSCT_P_BV2), b.Wk<float>(wb.rowpart_v2), row_part_floats(B, C));
       if (pj.n) defer([=, &side] { part_reduce_run(side.stream, pj); });
     }
+    if (fx_xc == 1) {                                            // dX1 += (dvq2 . Wv2) (1 + ch), dch += ...: the product's epilogue
+      if (!(SK & 1024)) gemm_fx(ctx, gxc, fxc);
+      defer([=, &side] { wgemm(side, gwv2); });
+      side_flush();
+    } else {
     Gemm g1 = mk((int)R, C, dd);                                 // dXc = dvq2 . Wv2
     g1.A = km(b.S(s.vq2), dd);
     g1.B = b.WB(DGSCT_P_WV2, C, dd);
     outE(g1, b.Wk(wb.dXc), E, C);
-    gemm(ctx, g1);
-    defer([=, &side] { gemm(side, gwv2); });
+    if (!(SK & 1024)) gemm(ctx, g1);
+    defer([=, &side] { wgemm(side, gwv2); });
     side_flush();
-    xc_bwd(ctx, b.Wk(wb.dXc), b.S(s.X1), dX1, B, N, C, b.S<float>(s.ch), b.Wk<float>(wb.dch));
+    if (!(SK & 4)) xc_bwd(ctx, b.Wk(wb.dXc), b.S(s.X1), dX1, B, N, C, b.S<float>(s.ch), b.Wk<float>(wb.dch));
+    }
+    }
+    t3_valid = fx_xc == 2;
   }
   }
   // B6 ---- channel-gate head
@@ -673,7 +785,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g1 = mk(C, dd, B);                                      // dWcatt = dpre^T . q
     g1.A = mn(b.Wk(wb.dpre_c), C); g1.B = mn(b.S(s.q), dd);
     outF(g1, G(DGSCT_P_WCATT), dd);
-    defer([=, &side] { gemm(side, g1); });
+    defer([=, &side] { wgemm(side, g1); });
     if (skf) {                                                   // dq = (dpre . Wcatt) * (q > 0), dpre = dch ch (1 - ch) made (and stored) on the way in
       SkFuse f; f.M = B; f.N = dd; f.K = C;
       f.a_mode = 2; f.A = b.Wk(wb.dch); f.lda = C; f.a_mul = b.S<float>(s.ch); f.ld_mul = C; f.a_store = b.Wk(wb.dpre_c); f.ld_store = C;
@@ -691,7 +803,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g3 = mk(dd, C, B);                                      // dWb = dq^T . m1
     g3.A = mn(b.Wk(wb.dq), dd); g3.B = mn(b.S(s.m1), C);
     outF(g3, G(DGSCT_P_WB), C);
-    defer([=, &side] { gemm(side, g3); });
+    defer([=, &side] { wgemm(side, g3); });
     if (skf) {                                                   // dm1 = dq . Wb -> dpa1 = dm1 mvq1 (aq1 > 0), coef = dm1 aq1 from the epilogue
       SkFuse f; f.M = B; f.N = C; f.K = dd;
       f.A = b.Wk(wb.dq); f.lda = dd; f.B = wbT.p; f.ldb = wbT.ld; f.b_kmajor = wbT.kmajor;
@@ -708,7 +820,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     }
   }
   // B5 ---- video query 1
-  bool vq1_in_kernel_dw = false;
+  bool vq1_in_kernel_dw = false, fx_x1 = false;
   {
     if (vq1_fused_supported(ctx.mode, N, C) && !fp8) {
       // the forward kept no vq1: ReLU decisions recomputed from X1, dvq1 (into vq1's region, for dWv1 below), d bias, dX1 += dvq1 . Wv1
@@ -723,10 +835,28 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
               vq1_in_kernel_dw ? b.Wk<float>(wb.vq1part) : nullptr);
       if (pj.n) defer([=, &side] { part_reduce_run(side.stream, pj); });
     } else {
+    // (round 5) dX1 += dvq1 . Wv1 with dvq1 = (vq1 > 0) * E(coef_b / N) formed in the product's staging (gemm_fx.hip); d bias(vq1) from
+    // the positive counts the forward left: sum_b E(coef_b / N) * cnt1_b
+    Gemm gx1 = mk((int)R, C, C);
+    gx1.A = km(b.S(s.vq1), C); gx1.B = b.WB(DGSCT_P_WV1, C, C);
+    resid(gx1, dX1, E, C);
+    outE(gx1, dX1, E, C);
+    GemmFx fx1;
+    fx1.a_pro = APRO_MASKSCALE; fx1.rpf = N; fx1.a_cs = b.Wk(wb.coef); fx1.a_cs_dt = DT_F32; fx1.a_cs_ld = C; fx1.a_scale = 1.f / (float)N;
+    fx1.a_store = b.Wk(wb.dvq1);
+    fx_x1 = (gemmfx_mode(-1) & 8) && (C <= 256 || (gemmfx_mode(-1) & 16)) && gemm_fx_supported(ctx, gx1, fx1);   // (as for dXc above)
+    if (fx_x1) {
+      if (!(SK & 1024)) gemm_fx(ctx, gx1, fx1);
+      defer([=, &side, &b] {                                     // t1 = E(coef / N) * cnt1: summed over the frames with the other bias gradients
+        EwArg rdt; rdt.dt = E;
+        ew(side, EW_RND_MUL, b.Wk(wb.t1), DT_F32, F32(b.Wk(wb.coef)), F32(b.S(s.cnt1)), rdt, (long)B * C, 1.f / (float)N, 1);
+      });
+      t1_valid = true;
+    } else {
     {
       PartJob pj;                                                // d bias(vq1), likewise
       Ctx cl = ctx; cl.late = aux_stream ? &pj : nullptr;
-      relu_bwd_scale(cl, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N,
+      if (!(SK & 2)) relu_bwd_scale(cl, b.S(s.vq1), b.S(s.vq1), B, N, C, nullptr, b.Wk(wb.coef), DT_F32, nullptr, 1.f / (float)N,
                      G(DGSCT_P_BV1), b.Wk<float>(wb.rowpart_v1), row_part_floats(B, C));
       if (pj.n) defer([=, &side] { part_reduce_run(side.stream, pj); });
     }
@@ -734,30 +864,34 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     g1.A = km(b.S(s.vq1), C); g1.B = b.WB(DGSCT_P_WV1, C, C);
     resid(g1, dX1, E, C);
     outE(g1, dX1, E, C);
-    gemm(ctx, g1);
+    if (!(SK & 1024)) gemm(ctx, g1);
+    }
     }
     Gemm g2 = mk(C, C, (int)R);                                  // dWv1 = dvq1^T . X1
-    g2.A = mn(b.S(s.vq1), C); g2.B = mn(b.S(s.X1), C);
+    g2.A = mn(fx_x1 ? b.Wk(wb.dvq1) : b.S(s.vq1), C); g2.B = mn(b.S(s.X1), C);
     outF(g2, G(DGSCT_P_WV1), C);
     atomic_out(g2);
-    if (!vq1_in_kernel_dw) defer([=, &side] { gemm(side, g2); });
+    if (!vq1_in_kernel_dw) defer([=, &side] { wgemm(side, g2); });
   }
   // B4 ---- audio queries
   {
     Gemm g1 = mk(C, C, B);                                       // dWa1 = dpa1^T . a
     g1.A = mn(b.Wk(wb.dpa1), C); g1.B = mn(b.S(s.aE), C);
     outF(g1, G(DGSCT_P_WA1), C);
-    defer([=, &side] { gemm(side, g1); });
+    defer([=, &side] { wgemm(side, g1); });
     Gemm g2 = mk(dd, C, B);                                      // dWa2 = dpa2^T . a
     g2.A = mn(b.Wk(wb.dpa2), dd); g2.B = mn(b.S(s.aE), C);
     outF(g2, G(DGSCT_P_WA2), C);
     defer([=, &side, &b] {
-      gemm(side, g2);
+      wgemm(side, g2);
       // the four bias gradients of the gate MLPs + d fc_affine_v_s_att.weight: column sums of [BT][C] matrices, one launch
-      const ColsumSeg segs[5] = {{b.Wk(wb.dpre_c), E, B, C, G(DGSCT_P_BCATT)}, {b.Wk(wb.dq), E, B, dd, G(DGSCT_P_BB)},
-                                 {b.Wk(wb.dpa1), E, B, C, G(DGSCT_P_BA1)}, {b.Wk(wb.dpa2), E, B, dd, G(DGSCT_P_BA2)},
-                                 {b.Wk(wb.tmpBd), DT_F32, B, dd, G(DGSCT_P_WS)}};
-      colsum_multi(side, segs, 5);
+      ColsumSeg segs[7] = {{b.Wk(wb.dpre_c), E, B, C, G(DGSCT_P_BCATT)}, {b.Wk(wb.dq), E, B, dd, G(DGSCT_P_BB)},
+                           {b.Wk(wb.dpa1), E, B, C, G(DGSCT_P_BA1)}, {b.Wk(wb.dpa2), E, B, dd, G(DGSCT_P_BA2)},
+                           {b.Wk(wb.tmpBd), DT_F32, B, dd, G(DGSCT_P_WS)}};
+      int nseg = 5;
+      if (t3_valid) segs[nseg++] = ColsumSeg{b.Wk(wb.t3), DT_F32, B, dd, G(DGSCT_P_BV2)};     // d bias(vq2), d bias(vq1) of the fused engine
+      if (t1_valid) segs[nseg++] = ColsumSeg{b.Wk(wb.t1), DT_F32, B, C, G(DGSCT_P_BV1)};
+      colsum_multi(side, segs, nseg);
     });
     side_flush();                                                // dWcatt, dWb, dWv1, dWa1, dWa2 and their biases
     const MatOp wa1T = b.WB(DGSCT_P_WA1, C, C), wa2T = b.WB(DGSCT_P_WA2, C, dd);
@@ -789,7 +923,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   }
   // B3 ---- X <- tokens attention: dX (output), dtok, d gate_av in one pass over X and dX1 (P2 recomputed)
   {
-    xattn_bwd(ctx, X, dX1, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX, skip_into_dx ? dOut : nullptr,
+    if (!(SK & 128)) xattn_bwd(ctx, X, dX1, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX, skip_into_dx ? dOut : nullptr,
               b.Wk<float>(wb.dtokF), G(DGSCT_P_GATE_AV),      // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
               s.tokpk >= 0 ? b.S(s.tokpk) : nullptr);
     if (d.remap == DGSCT_REMAP_CONV) {
@@ -803,7 +937,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B2 ---- tokens <- remapped tokens attention: dYp and d my_tokens in one pass over Yp (P1 recomputed from lse)
   void* dYp = b.Wk(wb.dYp);
   {
-    tokattn_bwd(ctx, b.S(s.Yp), b.F(DGSCT_P_TOKENS), b.S<float>(s.tok), b.S<float>(s.lse), b.Wk<float>(wb.dtokF),
+    if (!(SK & 128)) tokattn_bwd(ctx, b.S(s.Yp), b.F(DGSCT_P_TOKENS), b.S<float>(s.tok), b.S<float>(s.lse), b.Wk<float>(wb.dtokF),
                 b.Wk<float>(wb.da), invN, B, N, C, tk, dYp, b.Wk<float>(wb.dT0b), b.Wk<float>(wb.Dtok),
                 prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr, wb.dtokpk >= 0 ? b.Wk(wb.dtokpk) : nullptr);
     defer([=, &side, &b] {                                       // d my_tokens = sum_b (dtok + dS1 . Yp)
@@ -822,12 +956,12 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       g2.A = mn(dYp, C); g2.B = mn(b.S(s.T), Co);
       outF(g2, G(DGSCT_P_WC), Co);
       atomic_out(g2);
-      defer([=, &side] { gemm(side, g2); });
+      defer([=, &side] { wgemm(side, g2); });
       side_flush();
       Gemm g1 = mk((int)R, Co, C);                               // dT1 = dYp . Wc
       g1.A = km(dYp, C); g1.B = b.WB(DGSCT_P_WC, Co, C);
       outE(g1, b.Wk(wb.dT), E, Co);
-      gemm(ctx, g1);
+      if (!(SK & 2048)) gemm(ctx, g1);
       Gemm g3 = mk(No, Co, N, B);                                // dY[b] = Wn^T . dT1[b]
       g3.A = mn(b.W(DGSCT_P_WN), No);
       g3.B = mn(b.Wk(wb.dT), Co, (long)N * Co);
@@ -839,10 +973,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         g4.B = km(Y, Co, 0, (long)No * Co);
         outF(g4, G(DGSCT_P_WN), No);
         atomic_out(g4); g4.sole_writer = 1;
-        defer([=, &side] { gemm(side, g4); });
+        defer([=, &side] { wgemm(side, g4); });
         side_flush();
       }
-      gemm(ctx, g3);
+      if (!(SK & 2048)) gemm(ctx, g3);
     } else {
       if (conv) {
         Gemm g2 = mk(N, No, C);                                  // dWn = sum_b dYp[b] . T2[b]^T
@@ -851,27 +985,27 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         g2.B = mn(b.S(s.T), Nop, 0, (long)C * Nop);
         outF(g2, G(DGSCT_P_WN), No);
         atomic_out(g2); g2.sole_writer = 1;
-        defer([=, &side] { gemm(side, g2); });
+        defer([=, &side] { wgemm(side, g2); });
       }
       side_flush();
       Gemm g1 = mk(No, C, N, B);                                 // dT2[b] = Wn^T . dYp[b]     [No][C] token-major
       g1.A = mn(b.W(DGSCT_P_WN), No);                            //   (M = No, N = C: the 128x96 remap tile; the transposed
       g1.B = mn(dYp, C, (long)N * C);                            //    form M = C = 96 runs at half the rate)
       outE(g1, b.Wk(wb.dT), E, C, (long)No * C);
-      gemm(ctx, g1);
+      if (!(SK & 2048)) gemm(ctx, g1);
       Gemm g4 = mk(C, Co, No);                                   // dWc = sum_b dT2[b]^T . Y[b]
       g4.KB = B;
       g4.A = mn(b.Wk(wb.dT), C, 0, (long)No * C);
       g4.B = mn(Y, Co, 0, (long)No * Co);
       outF(g4, G(DGSCT_P_WC), Co);
       atomic_out(g4);
-      defer([=, &side] { gemm(side, g4); });
+      defer([=, &side] { wgemm(side, g4); });
       side_flush();
       Gemm g3 = mk(No, Co, C, B);                                // dY[b] = dT2[b] . Wc
       g3.A = km(b.Wk(wb.dT), C, (long)No * C);
       g3.B = b.WB(DGSCT_P_WC, Co, C);
       outE(g3, dY, E, Co, (long)No * Co);
-      gemm(ctx, g3);
+      if (!(SK & 2048)) gemm(ctx, g3);
     }
     // both bias-side reductions of dYp in one pass (they were rowdot -> sum_batch and colsum: two more reads of the cotangent)
     // (round 4: frame by frame -- contiguous rows -- with the per-frame row dots summed by a second small launch: 150 -> ~45 us

@@ -26,7 +26,7 @@ struct Plan {
   int64_t prep_w[DGSCT_P_COUNT], prep_wt[DGSCT_P_COUNT], wcols[DGSCT_P_COUNT], wnumel[DGSCT_P_COUNT], prep_rowb, prep_colb, prep_colb2, prep_t0pk, prep_bytes;
   // saved
   struct {
-    int64_t a, mvq1, bnacc1, bnacc2, zero_end;
+    int64_t a, mvq1, cnt1, bnacc1, bnacc2, zero_end;
     int64_t Yp, T, tok, tokpk, lse, aE, X1, aq1, aq2, vq1, m1, q, ch, Xc, vq2, sl, sg, map, tg, X3, mu_b, rstd_b, Zp, Z, Op,
         bn1, bn2, mu_p, rstd_p;
   } s;
@@ -35,8 +35,8 @@ struct Plan {
   // forward / backward scratch
   struct { int64_t tokscr, Xc; } wf;
   struct {
-    int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, dtokF, dT0b, zero_end;
-    int64_t dO, dZ, dX3, dX1, dXc, Xc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart, rowpart_v1, rowpart_v2, vq1part;
+    int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, dtokF, dT0b, w2, zero_end;
+    int64_t dO, dZ, dX3, dX1, dXc, Xc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart, rowpart_v1, rowpart_v2, vq1part, dvq1, dvq2, dZp, t1, t3;
   } wb;
   int64_t ws_fwd_bytes, ws_bwd_bytes;
   // gradients
@@ -53,5 +53,9 @@ struct Plan {
   bool validate();
   void layout();
 };
+
+// what-if timing switches of the schedule (plan.cpp; dgsct_test_tune "skip" / "skipminc"): set < 0 queries
+int plan_skip_mode(int set);
+int plan_skip_minc(int set);
 
 }  // namespace dgsct

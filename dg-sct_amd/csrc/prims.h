@@ -87,6 +87,32 @@ struct Gemm {
 };
 
 void gemm(const Ctx&, const Gemm&);
+
+// ---- producer / consumer fusion hooks of the tiled engine (gemm_fx.hip; round 5) ----------------------------------------------------
+// A GEMM of the adapter's BACKWARD chain with the elementwise launch in front of it folded into the staging of its A operand and the
+// one behind it into its epilogue (bf16, both operands K-major, E output).  `rpf` = token rows per frame: row m belongs to frame m / rpf.
+//   a_pro = APRO_MASKSCALE (relu_bwd_scale, net_trans.py:594 / 602 autograd):
+//       A'[m][k] = A[m][k] > 0 ? E( (a_rs ? a_rs[m] : 1) * a_scale * a_cs[frame][k] * (a_cs2 ? a_cs2[k] : 1) ) : 0
+//   a_pro = APRO_BNBWD (bn_bwd_apply, net_trans.py:636 / 643 autograd; batch = conv groups, channel c = b * K + k, x = a2 laid out like A):
+//       gg = bn_relu && !(x * sc[c] + sh[c] > 0) ? 0 : A;   A' = E( k1 gg - k2 - x k3 ),  k1 = sc,  k3 = sc rstd sums[C + c] / rows,
+//       k2 = sc sums[c] / rows - mean k3   (eval mode: k2 = k3 = 0)
+//   a_store (optional): A' is written once, laid out like A (may BE A when every A element feeds one output tile only: N <= the tile width)
+//   epi = EPI_XCBWD (xc_bwd, net_trans.py:598 autograd):   v = E(acc);  D = R + v * (1 + e_cs[frame][n]);  e_acc[frame][n] += sum_m v * e_x[m][n]
+//   (e_x: E [M][ldd] like D;  e_cs / e_acc: fp32 [frames][e_ld])
+enum APro : int { APRO_NONE = 0, APRO_MASKSCALE = 1, APRO_BNBWD = 2 };
+enum FxEpi : int { EPI_NONE = 0, EPI_XCBWD = 1 };
+struct GemmFx {
+  int a_pro = APRO_NONE, epi = EPI_NONE, rpf = 0;
+  const float* a_rs = nullptr; const void* a_cs = nullptr; int a_cs_dt = DT_F32; long a_cs_ld = 0; const float* a_cs2 = nullptr; float a_scale = 1.f;
+  const void* a2 = nullptr; const float* bn_mean = nullptr; const float* bn_rstd = nullptr; const float* bn_sc = nullptr; const float* bn_sh = nullptr;
+  const float* bn_sums = nullptr; long bn_rows = 0; int bn_C = 0, bn_relu = 0, bn_training = 1;
+  void* a_store = nullptr;
+  const float* e_cs = nullptr; const void* e_x = nullptr; float* e_acc = nullptr; long e_ld = 0;
+};
+// plain D = A' B^T (+ bias_n, + R) in E; g carries the operands / output as for gemm()
+bool gemm_fx_supported(const Ctx&, const Gemm&, const GemmFx&);
+void gemm_fx(const Ctx&, const Gemm&, const GemmFx&);
+int gemmfx_mode(int set);          // dgsct_test_tune "gemmfx": bit mask of the fused call sites (1 dZ, 2 dX3, 4 dXc, 8 dX1; 15 default, 0 = the separate launches); set < 0: query
 // A [BT, C] gate-MLP product with its neighbouring elementwise launches folded in (gemm_skinny.hip; bf16, M <= 256, both operands
 // K-major):   D = epi( act( sum_k A'[m][k] B[n][k] + sum_k2 A2[m][k2] B2[n][k2] + bias_n ) masked by (mask > 0) )
 //   a_mode 0: A' = A (bf16)          1: A' = bf16(A (bf16) * a_mul (fp32))          2: A' = bf16(A (fp32) * s (1 - s)), s = a_mul (fp32)
@@ -119,6 +145,11 @@ void softmax_bwd_rows(const Ctx&, const void* P, long ldp, const float* dP, long
 // out[b][c] += scale * sum_n roww[b*roww_bs + n] * x[b][n][c]     (roww == null -> 1).  x is E [B][N][ld]; out pre-zeroed.
 void colsum_batched(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const float* roww, long roww_bs,
                     float scale, float* out, long out_bs);
+// colsum_batched + the same sum over the POSITIVE entries only: out_pos[b][c] += sum_n roww * (x[b][n][c] > 0)   (pre-zeroed)
+// (with roww == null: the number of positive entries -- what a ReLU layer's bias gradient needs once its cotangent is a per-frame
+//  vector: sum_n (x > 0) * v[b][c] = v[b][c] * count)
+void colsum_batched_pos(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const float* roww, long roww_bs,
+                        float scale, float* out, long out_bs, float* out_pos, long out_pos_bs);
 // out[b][n] = sum_c x[b][n][c] * w[b*w_bs + c] * (w2 ? w2[c] : 1) + (bias ? *bias : 0).   w dtype wdt.
 void rowdot_batched(const Ctx&, const void* x, long ld, long bs, int B, int N, int C, const void* w, int wdt, long w_bs,
                     const float* w2, const float* bias, float* out);
@@ -324,6 +355,8 @@ enum EwOp : int {
   EW_OUTER_ACC = 5,    // o[i] += a[i / div] * b[i % div]       (rank-1 accumulate, fp32 o)
   EW_COPY = 6,         // o = a
   EW_MULB_MASK = 7,    // o[i] = a[i] * b[i % div] * (c[i] > 0)
+  EW_RND_MUL = 8,      // o[i] = round_c.dt(s * a[i]) * b[i]     (the value a ReLU backward wrote, times how often it wrote it; c.p unused)
+  EW_MUL3B = 9,        // o[i] = a[i] * b[i] * c[i % div]
 };
 struct EwArg { const void* p = nullptr; int dt = DT_F32; };
 void ew(const Ctx&, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n, float s, long div);

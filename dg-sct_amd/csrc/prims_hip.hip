@@ -1244,6 +1244,13 @@ __device__ __forceinline__ void ew_eval(const EwCall& p, long i) {
     case EW_SCALE: r = p.s * lde_rt(p.a.p, p.a.dt, i); break;
     case EW_ADD_BCAST: r = lde_rt(p.a.p, p.a.dt, i) + p.s * lde_rt(p.b.p, p.b.dt, i / p.div); break;
     case EW_MULB_MASK: r = lde_rt(p.c.p, p.c.dt, i) > 0.f ? lde_rt(p.a.p, p.a.dt, i) * lde_rt(p.b.p, p.b.dt, i % p.div) : 0.f; break;
+    case EW_RND_MUL: {
+      float t = p.s * lde_rt(p.a.p, p.a.dt, i);
+      if (p.c.dt == DT_BF16) t = bf2f(f2bf(t));
+      r = t * lde_rt(p.b.p, p.b.dt, i);
+      break;
+    }
+    case EW_MUL3B: r = lde_rt(p.a.p, p.a.dt, i) * lde_rt(p.b.p, p.b.dt, i) * lde_rt(p.c.p, p.c.dt, i % p.div); break;
     case EW_OUTER_ACC: r = lde_rt(p.o, p.odt, i) + lde_rt(p.a.p, p.a.dt, i / p.div) * lde_rt(p.b.p, p.b.dt, i % p.div); break;
     default: r = lde_rt(p.a.p, p.a.dt, i); break;
   }

@@ -187,6 +187,57 @@ void colsum_batched(const Ctx& ctx, const void* x, long ld, long bs, int B, int 
                g.rpp, g.rpc, out, out_bs);
 }
 
+// colsum_batched + a second sum over the POSITIVE entries: out_pos[b][c] += sum_n roww * (x > 0)     (prims.h: colsum_batched_pos)
+template <int DT, int VE>
+__global__ __launch_bounds__(256) void colsum_pos_k(const void* x, long ld, long bs, int N, int C, const float* roww,
+                                                    long roww_bs, float scale, int tpr, int rpp, int rpc, float* out,
+                                                    long out_bs, float* out_pos, long out_pos_bs) {
+  constexpr int UNR = UNR1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y;
+  STRIP_PROLOGUE(lmin_d(N, (long)(blockIdx.x + 1) * rpc), (long)blockIdx.x * rpc)
+  for (int vc0 = 0; vc0 < nvr; vc0 += tpr) {
+    const int vc = vc0 + tc;
+    const bool active = tr < rpp && vc < nvr;
+    float acc[2][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+      for (long n = r_begin + tr; n < r_end; n += (long)rpp * UNR) {
+        float t[UNR][VE], rw[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long nn = n + (long)u * rpp;
+          const long nc = nn < r_end ? nn : r_end - 1;            // unconditional, clamped
+          ldv<DT, VE>(x, (long)b * bs + nc * ld + vc * VE, t[u]);
+          rw[u] = roww ? roww[(long)b * roww_bs + nc] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) rw[u] = n + (long)u * rpp < r_end ? rw[u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int e = 0; e < VE; ++e) { acc[0][e] += rw[u] * t[u][e]; acc[1][e] += t[u][e] > 0.f ? rw[u] : 0.f; }
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[0][e] *= scale;
+    }
+    float* const dst[2] = {out + (long)b * out_bs, out_pos + (long)b * out_pos_bs};
+    flush_strip<2, VE>(acc, lds, C, vc * VE, active, dst, tr, rpp, vc0 * VE, imin_d(C, (vc0 + tpr) * VE));
+  }
+}
+void colsum_batched_pos(const Ctx& ctx, const void* x, long ld, long bs, int B, int N, int C, const float* roww, long roww_bs,
+                        float scale, float* out, long out_bs, float* out_pos, long out_pos_bs) {
+  int ve = col_ve(ctx, C);
+  if (ld % ve != 0 || bs % ve != 0) ve = 1;
+  int cap = 768;
+  COL_CAPACITY(cap, ctx, ve, colsum_pos_k, strip_lds(C, ve));
+  if (cap > 800) cap = 800;
+  ColGeom g = col_geom(UNR1, C, ve, N, B, cap, true);
+  COL_DISPATCH(ctx, ve, colsum_pos_k, dim3(g.chunks, B), strip_lds(C, ve), x, ld, bs, N, C, roww, roww_bs, scale, g.tpr,
+               g.rpp, g.rpc, out, out_bs, out_pos, out_pos_bs);
+}
+
 // ---- BatchNorm statistics ----------------------------------------------------------------------------
 // acc3[0..C) = shift (row 0), acc3[C..2C) += sum(x - shift), acc3[2C..3C) += sum((x - shift)^2)
 template <int DT, int VE>

@@ -44,6 +44,8 @@ void clear_async() {}
 int gemm_skinny_mode(int) { return 0; }
 int gemm_tall_mode(int) { return 0; }
 int gemm8_mode(int) { return 0; }                 // (the 8-wave GEMM kernel is a device-side choice: nothing to emulate)
+int gemm_noatomic_mode(int) { return 0; }
+int gemm8_wg_target(int) { return 0; }
 
 void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
 
@@ -237,6 +239,82 @@ void colsum_batched(const Ctx& ctx, const void* x, long ldx, long bs, int B, int
         s += (double)(roww ? roww[(long)b * roww_bs + n] : 1.f) * ld(x, ctx.mode, (long)b * bs + (long)n * ldx + c);
       out[(long)b * out_bs + c] += scale * (float)s;
     }
+}
+
+void colsum_batched_pos(const Ctx& ctx, const void* x, long ldx, long bs, int B, int N, int C, const float* roww, long roww_bs,
+                        float scale, float* out, long out_bs, float* out_pos, long out_pos_bs) {
+  colsum_batched(ctx, x, ldx, bs, B, N, C, roww, roww_bs, scale, out, out_bs);
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      double s = 0;
+      for (int n = 0; n < N; ++n)
+        if (ld(x, ctx.mode, (long)b * bs + (long)n * ldx + c) > 0.f) s += roww ? roww[(long)b * roww_bs + n] : 1.f;
+      out_pos[(long)b * out_pos_bs + c] += (float)s;
+    }
+}
+
+// ---- fused GEMM hooks (csrc/gemm_fx.hip): the same math in host loops, either element type, either B layout ------------------------
+static int g_gemmfx = 31;      // (all call sites, prologues at every width: the host loops have no tile economics)
+int gemmfx_mode(int set) { const int old = g_gemmfx; if (set >= 0) g_gemmfx = set & 63; return old; }
+bool gemm_fx_supported(const Ctx&, const Gemm& g, const GemmFx& fx) {
+  if (!g_gemmfx || !g.A.kmajor || g.KB != 1 || g.atomic) return false;
+  const bool frames = fx.a_pro == APRO_MASKSCALE || fx.epi == EPI_XCBWD;
+  if (frames && (fx.rpf <= 0 || g.batch != 1 || g.M % fx.rpf)) return false;
+  return true;
+}
+void gemm_fx(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
+  const int E = ctx.mode;
+  auto rnd = [E](float v) { return E == DT_BF16 ? bf2f(f2bf(v)) : v; };
+  std::vector<float> Ap((size_t)g.batch * g.M * g.K);
+  for (int b = 0; b < g.batch; ++b)
+    for (int m = 0; m < g.M; ++m)
+      for (int k = 0; k < g.K; ++k) {
+        const long ao = (long)b * g.A.bs + (long)m * g.A.ld + k;
+        float a = ld(g.A.p, E, ao);
+        if (fx.a_pro == APRO_MASKSCALE) {
+          const int f = m / fx.rpf;
+          float v = (fx.a_rs ? fx.a_rs[m] : 1.f) * fx.a_scale;
+          v *= ld(fx.a_cs, fx.a_cs_dt, (long)f * fx.a_cs_ld + k) * (fx.a_cs2 ? fx.a_cs2[k] : 1.f);
+          a = a > 0.f ? rnd(v) : 0.f;
+        } else if (fx.a_pro == APRO_BNBWD) {
+          const int c = b * g.K + k;
+          const float x = ld(fx.a2, E, ao), sc = fx.bn_sc[c];
+          float k2 = 0.f, k3 = 0.f;
+          if (fx.bn_training) {
+            const float inv = 1.f / (float)fx.bn_rows;
+            k3 = sc * fx.bn_rstd[c] * fx.bn_sums[fx.bn_C + c] * inv;
+            k2 = sc * fx.bn_sums[c] * inv - fx.bn_mean[c] * k3;
+          }
+          float gg = a;
+          if (fx.bn_relu && !(x * sc + fx.bn_sh[c] > 0.f)) gg = 0.f;
+          a = rnd(sc * gg - k2 - x * k3);
+        }
+        Ap[((size_t)b * g.M + m) * g.K + k] = a;
+      }
+  if (fx.a_store)
+    for (int b = 0; b < g.batch; ++b)
+      for (int m = 0; m < g.M; ++m)
+        for (int k = 0; k < g.K; ++k) st(fx.a_store, E, (long)b * g.A.bs + (long)m * g.A.ld + k, Ap[((size_t)b * g.M + m) * g.K + k]);
+  for (int b = 0; b < g.batch; ++b)
+    for (int m = 0; m < g.M; ++m)
+      for (int n = 0; n < g.N; ++n) {
+        double acc = 0;
+        for (int k = 0; k < g.K; ++k) {
+          const long bo = (long)b * g.B.bs + (g.B.kmajor ? (long)n * g.B.ld + k : (long)k * g.B.ld + n);
+          acc += (double)Ap[((size_t)b * g.M + m) * g.K + k] * (double)ld(g.B.p, E, bo);
+        }
+        float v = (float)acc + (g.bias_n ? g.bias_n[n] : 0.f);
+        const long o = (long)b * g.dbs + (long)m * g.ldd + n;
+        if (fx.epi == EPI_XCBWD) {
+          const int f = m / fx.rpf;
+          const float vr = rnd(v);
+          fx.e_acc[(long)f * fx.e_ld + n] += vr * ld(fx.e_x, E, o);
+          v = ld(g.R, g.rdt, (long)b * g.rbs + (long)m * g.ldr + n) + vr * (1.f + fx.e_cs[(long)f * fx.e_ld + n]);
+        } else if (g.R) {
+          v += g.beta * ld(g.R, g.rdt, (long)b * g.rbs + (long)m * g.ldr + n);
+        }
+        st(g.D, g.ddt, o, v);
+      }
 }
 
 void rowdot_batched(const Ctx& ctx, const void* x, long ldx, long bs, int B, int N, int C, const void* w, int wdt, long w_bs,
@@ -688,6 +766,8 @@ void ew(const Ctx&, int op, void* o, int odt, EwArg a, EwArg b, EwArg c, long n,
       case EW_ADD_BCAST: r = ld(a.p, a.dt, i) + s * ld(b.p, b.dt, i / div); break;
       case EW_OUTER_ACC: r = ld(o, odt, i) + ld(a.p, a.dt, i / div) * ld(b.p, b.dt, i % div); break;
       case EW_MULB_MASK: r = ld(c.p, c.dt, i) > 0.f ? ld(a.p, a.dt, i) * ld(b.p, b.dt, i % div) : 0.f; break;
+      case EW_RND_MUL: { float t = s * ld(a.p, a.dt, i); if (c.dt == DT_BF16) t = bf2f(f2bf(t)); r = t * ld(b.p, b.dt, i); break; }
+      case EW_MUL3B: r = ld(a.p, a.dt, i) * ld(b.p, b.dt, i) * ld(c.p, c.dt, i % div); break;
       default: r = ld(a.p, a.dt, i); break;
     }
     st(o, odt, i, r);

@@ -553,3 +553,53 @@ def test_weight_gradients_on_gemm_tall_equal_the_tiled_engine(shape):
     for name in ("up_sampler.weight", "down_sampler.weight", "fc_affine_video_1.weight", "fc_affine_video_2.weight", "fc.weight", "conv_adapter.weight"):
         if name in a:
             assert _l2(a[name], b[name]) < 2e-3, (name, _l2(a[name], b[name]))
+
+
+@pytest.mark.parametrize("shape,BT,masks", [((576, 256, 1024, 192), 10, (0, 15)), ((1024, 192, 576, 256), 10, (0, 15)),
+                                            ((144, 512, 256, 384), 20, (0, 15, 31)), ((256, 384, 144, 512), 20, (0, 15, 31)),
+                                            ((36, 1024, 64, 768), 20, (0, 15, 31)), ((64, 768, 36, 1024), 10, (0, 15, 4 + 32)),
+                                            ((144, 512, 256, 384), 160, (0, 15))])
+def test_fused_gemm_hooks_equal_the_launches_they_replace(shape, BT, masks):
+    """round 5, csrc/gemm_fx.hip: the backward products of the late-stage schedule with the elementwise launch in front of them folded
+    into the staging of their A operand (ReLU backward of vq2 / vq1: relu_bwd_scale; BatchNorm backward of dO / dZ: bn_bwd_apply) and
+    the channel-gate backward (xc_bwd) into the epilogue, against the separate launches (dgsct_test_tune "gemmfx" = 0) on the same
+    inputs.  Same operands and the same rounding points (the transformed operand and E(dXc) are rounded to bf16 exactly where the
+    separate launches stored them); what differs is the fp32 summation order of the per-frame / per-channel sums and the form of the two
+    query-layer bias gradients (counts x value instead of a column sum of the rounded tensor)."""
+    N, C, No, Co = shape
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS["ave"]})
+    p = O.random_params(cfg, "ave", seed=11, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(29)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    dMap = torch.randn(BT, N, generator=gen).to(DEV)
+    res = {}
+    old = lib.test_tune("gemmfx", -1)
+    assert old == 15
+    # ONE forward (it does not depend on the switch; two forwards differ in the last bits of their atomically summed batch statistics),
+    # every backward on its own copy of the saved activations (the separate launches overwrite vq1 / vq2 in place)
+    params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+    prep = ops.prepare(lib, spec, params, dtype, DEV)
+    out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+    torch.cuda.synchronize()
+    try:
+        for mode in masks:
+            lib.test_tune("gemmfx", mode)
+            dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved.clone(), dOut, dMap, None)
+            torch.cuda.synchronize()
+            res[mode] = (dX.float(), dY.float(), [g.clone() if g is not None else None for g in grads])
+    finally:
+        lib.test_tune("gemmfx", old)
+    ref = res[0]
+    for mode in masks[1:]:
+        a = res[mode]
+        for i, name in ((0, "dX"), (1, "dY")):
+            assert _l2(a[i], ref[i]) < 4e-3, (mode, name, _l2(a[i], ref[i]))
+        for name, ga, gb in zip(PARAM_NAMES, a[2], ref[2]):
+            if ga is None or gb.float().norm() == 0 or name in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias", "gate", "gate_av"):
+                continue
+            assert _l2(ga, gb) < 8e-3, (mode, name, _l2(ga, gb))

@@ -60,6 +60,30 @@ def test_schedule_without_the_gate_fusion_fp32(emu, name):
         assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
 
 
+@pytest.mark.parametrize("mask", [0, 31, 4 + 32, 1 + 2, 8 + 16])
+@pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "pretrain", "avs_s4", "avqa"])
+def test_schedule_with_the_fused_gemm_hooks_fp32(emu, name, mask):
+    """round 5 (csrc/gemm_fx.hip): the backward products of the unfused (late-stage) schedule take the elementwise launch in front of
+    them as a transform of their A operand (ReLU backward of vq1 / vq2; BatchNorm backward of dO / dZ) and the channel-gate backward as
+    an epilogue.  dgsct_test_tune("gemmfx", mask) picks the call sites (1 dZ, 2 dX3, 4 dXc, 8 dX1; 16: prologues at every width; 32: dXc
+    with its epilogue only); 0 = the separate launches.  DGSCT_NO_GPROJ=1 sends the tiny golden bottlenecks through the GEMM branch the
+    late stages use (the BatchNorm-backward sites live there); "gatefuse" = 0 selects the unfused gate chain."""
+    fx = load_golden(name)
+    old, oldg = emu.test_tune("gemmfx", mask), emu.test_tune("gatefuse", 0)
+    os.environ["DGSCT_NO_GPROJ"] = "1"
+    try:
+        r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
+    finally:
+        emu.test_tune("gemmfx", old)
+        emu.test_tune("gatefuse", oldg)
+        os.environ.pop("DGSCT_NO_GPROJ", None)
+    tol = 1e-4
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(r[k], fx[k]) < tol, k
+    for k, g in fx["grads"].items():
+        assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
+
+
 @pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "pretrain", "avqa"])
 def test_schedule_without_the_folded_gate_products_fp32(emu, name):
     """by default the schedule folds the [BT, C] elementwise launches of the gate-MLP chain into its skinny products (SkFuse:

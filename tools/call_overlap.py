@@ -60,6 +60,8 @@ def show(agg, wall, title):
     return
 
 
+if os.environ.get("SKIPMINC"):           # what-if switches ("skip", plan.cpp) only for adapters at least this wide
+    lib.test_tune("skipminc", int(os.environ["SKIPMINC"]))
 base, wall = measure()
 show(base, wall, "default")
 # A/B inside one process (two boxes differ by 2 %): each named switch off, then the default again
