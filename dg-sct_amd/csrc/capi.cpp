@@ -259,8 +259,10 @@ int dgsct_test_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm8")) return gemm8_mode(value);
   if (key && !strcmp(key, "skip")) return dgsct::plan_skip_mode(value);            // what-if timing switches (plan.cpp): results are garbage
   if (key && !strcmp(key, "gemmfx")) return gemmfx_mode(value);
+  if (key && !strcmp(key, "g8pipe")) return dgsct::gemm8_pipe_mode(value);
   if (key && !strcmp(key, "g8wg")) return dgsct::gemm8_wg_target(value);
   if (key && !strcmp(key, "noatomic")) return dgsct::gemm_noatomic_mode(value);
+  if (key && !strcmp(key, "skipmaxc")) return dgsct::plan_skip_maxc(value);
   if (key && !strcmp(key, "skipminc")) return dgsct::plan_skip_minc(value);
   if (key && !strcmp(key, "skinny")) return gemm_skinny_mode(value);
   if (key && !strcmp(key, "gemmtall")) return gemm_tall_mode(value);

@@ -187,7 +187,8 @@ __device__ __forceinline__ g8_bf16x8_t g8_frag_km(const char* lds, int row0, int
 
 template <int N> __device__ __forceinline__ void g8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool AK, bool BK, int BN, bool BATCHED, bool TWO>
+// PIPE (round 5): the k-loop software-pipelined ACROSS k-tiles -- ONE barrier and no exposed LDS latency per k-tile (see the loop)
+template <bool AK, bool BK, int BN, bool BATCHED, bool TWO, bool PIPE>
 __global__ __launch_bounds__(G8_NT, (G8_NW == 8 || G8_ROWS == 128) ? 2 : 1)
 void gemm8_kernel(const G8 p) {
   constexpr int BM = G8_ROWS, WGN = 2, WGM = G8_NW / WGN, TM = BM / (WGM * 32), TN = BN / 64;
@@ -252,6 +253,85 @@ void gemm8_kernel(const G8 p) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) kx[kk] = (unsigned)((((kk * 2 + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) * 16));
 
+  if constexpr (PIPE) {
+    // One k-tile = four 16-deep k-steps; fragment registers alternate between two sets.  Steady state of iteration `it` (tile `it` in
+    // buffer it & 1, its k-step 0 fragments already in set 0):
+    //     rd(1) | mma(0) | rd(2) | mma(1) | rd(3) | mma(2) | -- every read of tile `it` has returned --
+    //     s_waitcnt vmcnt(0) (this wave's pieces of tile it + 1: the only DMA group in flight) ; s_barrier
+    //         => tile it + 1 is visible to every wave AND every wave is done reading tile `it`: one barrier serves both hazards
+    //     DMA of tile it + 2 into buffer it & 1 ; rd(0) of tile it + 1 | mma(3)
+    // i.e. one barrier per k-tile instead of two, and the first fragment read of a tile flies under the last MFMA group of the tile
+    // before it instead of sitting exposed behind the barrier.
+    G8F<AK> fa[2][TM];
+    G8F<BK> fb[2][TN];
+    auto rdp = [&](auto kkc, unsigned boff) {
+      constexpr int KK = decltype(kkc)::value;
+      constexpr int S = KK & 1;
+      constexpr int PA = BM * 2, PB = BN * 2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (AK) g8_rd128<0>(baseA[i] + boff + kx[KK], fa[S][i]);
+        else g8_rdtr<KK * 16 * PA, KK * 16 * PA + 4 * PA>(baseA[i] + boff, fa[S][i]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (BK) g8_rd128<0>(baseB[j] + boff + kx[KK], fb[S][j]);
+        else g8_rdtr<KK * 16 * PB, KK * 16 * PB + 4 * PB>(baseB[j] + boff, fb[S][j]);
+      }
+    };
+    auto landedp = [&](int S) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < TM; ++i) g8_tie(fa[S][i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) g8_tie(fb[S][j]);
+    };
+    const bool prio = p.dbg & 16;                              // experiment: s_setprio 1 around every MFMA group
+    auto mmap = [&](int S) {
+      if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g8_val(fa[S][i]), g8_val(fb[S][j]), acc[i][j], 0, 0, 0);
+      if (prio) __builtin_amdgcn_s_setprio(0);
+    };
+    if (nk > 0) {
+      issue(kt_begin, 0);
+      if (nk > 1) { issue(kt_begin + 1, 1); g8_wait_vm<NDMA>(); } else g8_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      rdp(std::integral_constant<int, 0>{}, 0u);
+      landedp(0);
+      for (int it = 0; it < nk; ++it) {
+        const unsigned boff = (unsigned)((it & 1) * STAGE), bnext = (unsigned)(((it + 1) & 1) * STAGE);
+        rdp(std::integral_constant<int, 1>{}, boff);
+        __builtin_amdgcn_sched_barrier(0);
+        mmap(0);
+        __builtin_amdgcn_sched_barrier(0);
+        landedp(1);
+        rdp(std::integral_constant<int, 2>{}, boff);
+        __builtin_amdgcn_sched_barrier(0);
+        mmap(1);
+        __builtin_amdgcn_sched_barrier(0);
+        landedp(0);
+        rdp(std::integral_constant<int, 3>{}, boff);
+        __builtin_amdgcn_sched_barrier(0);
+        mmap(0);
+        __builtin_amdgcn_sched_barrier(0);
+        landedp(1);                                            // last read of tile `it` has returned
+        if (it + 1 < nk) {
+          g8_wait_vm<0>();                                     // tile it + 1 (the only group in flight) has landed
+          __builtin_amdgcn_s_barrier();
+          if (it + 2 < nk) issue(kt_begin + it + 2, it & 1);
+          rdp(std::integral_constant<int, 0>{}, bnext);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mmap(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < nk) landedp(0);
+      }
+    }
+  } else {
   const bool dbg_nodma = p.dbg & 1, dbg_nord = p.dbg & 2, dbg_nomma = p.dbg & 4, dbg_early = p.dbg & 8;
   if (nk > 0) issue(kt_begin, 0);
   if (nk > 1) issue(kt_begin + 1, 1);
@@ -342,6 +422,7 @@ void gemm8_kernel(const G8 p) {
     }
   }
 
+  }
   // ---- epilogue.  accumulator element r of tile (i, j): row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31
   const int ncol0 = n0 + wn * TN * 32;
   if (p.atomic || nk <= 0) {
@@ -415,20 +496,28 @@ void gemm8_kernel(const G8 p) {
 // k-loop); no caller of the adapter schedule has that shape -- gemm8_try leaves it to the tiled engine
 template <bool AK, bool BK, int BN> constexpr bool G8_TWO_OK = !(!AK && BK && BN == 256);
 
-template <bool AK, bool BK, int BN>
+template <bool AK, bool BK, int BN, bool PIPE>
 static void g8_launch_lay(const G8& k, bool batched, bool two, dim3 grid, hipStream_t s) {
-  if (batched)  hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, true, false>), grid, dim3(G8_NT), 0, s, k);
+  if (batched)  hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, true, false, PIPE>), grid, dim3(G8_NT), 0, s, k);
   else if (two) {
-    if constexpr (G8_TWO_OK<AK, BK, BN>) hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, false, true>), grid, dim3(G8_NT), 0, s, k);
+    if constexpr (G8_TWO_OK<AK, BK, BN>) hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, false, true, PIPE>), grid, dim3(G8_NT), 0, s, k);
   }
-  else          hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, false, false>), grid, dim3(G8_NT), 0, s, k);
+  else          hipLaunchKernelGGL((gemm8_kernel<AK, BK, BN, false, false, PIPE>), grid, dim3(G8_NT), 0, s, k);
 }
+template <int BN, bool PIPE>
+static void g8_launch_p(const G8& k, int ak, int bk, bool batched, bool two, dim3 grid, hipStream_t s) {
+  if (ak && bk)       g8_launch_lay<true, true, BN, PIPE>(k, batched, two, grid, s);
+  else if (ak && !bk) g8_launch_lay<true, false, BN, PIPE>(k, batched, two, grid, s);
+  else if (!ak && bk) g8_launch_lay<false, true, BN, PIPE>(k, batched, two, grid, s);
+  else                g8_launch_lay<false, false, BN, PIPE>(k, batched, two, grid, s);
+}
+// "g8pipe" (dgsct_test_tune / DGSCT_G8PIPE): 1 = the cross-tile pipelined k-loop (default), 0 = the round-3 loop (two barriers per k-tile)
+static std::atomic<int> g_g8pipe{getenv("DGSCT_G8PIPE") ? atoi(getenv("DGSCT_G8PIPE")) : 1};
+int gemm8_pipe_mode(int set) { const int old = g_g8pipe.load(); if (set >= 0) g_g8pipe.store(set ? 1 : 0); return old; }
 template <int BN>
 static void g8_launch(const G8& k, int ak, int bk, bool batched, bool two, dim3 grid, hipStream_t s) {
-  if (ak && bk)       g8_launch_lay<true, true, BN>(k, batched, two, grid, s);
-  else if (ak && !bk) g8_launch_lay<true, false, BN>(k, batched, two, grid, s);
-  else if (!ak && bk) g8_launch_lay<false, true, BN>(k, batched, two, grid, s);
-  else                g8_launch_lay<false, false, BN>(k, batched, two, grid, s);
+  if (g_g8pipe.load(std::memory_order_relaxed)) g8_launch_p<BN, true>(k, ak, bk, batched, two, grid, s);
+  else g8_launch_p<BN, false>(k, ak, bk, batched, two, grid, s);
 }
 
 static inline bool g8_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

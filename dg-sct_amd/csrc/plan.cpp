@@ -76,10 +76,12 @@ bool Plan::validate() {
 //   1 weight-gradient GEMMs on the aux stream    2 relu_bwd_scale    4 xc_bwd    8 bn_bwd_apply    16 scale_cols + rowdot (forward)
 //   32 bn_stats + affine_act    64 colsum of vq1 / u    128 the four attention kernels    256 modln fwd / bwd    512 tail fwd / bwd
 //   1024 the [rows, C] x [C, C] chain GEMMs (vq1, vq2, dXc, dX1 +=)    2048 the remap GEMMs    4096 the bottleneck GEMMs
+//   8192 the backward's final join with the aux stream    16384 / 32768 / 65536 / 131072: tokattn_fwd / xattn_fwd / xattn_bwd / tokattn_bwd alone
 // "skipminc": only for adapters at least that wide (default 0).
-static std::atomic<int> g_skip{0}, g_skip_minc{0};
+static std::atomic<int> g_skip{0}, g_skip_minc{0}, g_skip_maxc{1 << 30};
 int plan_skip_mode(int set) { const int old = g_skip.load(); if (set >= 0) g_skip.store(set); return old; }
 int plan_skip_minc(int set) { const int old = g_skip_minc.load(); if (set >= 0) g_skip_minc.store(set); return old; }
+int plan_skip_maxc(int set) { const int old = g_skip_maxc.load(); if (set >= 0) g_skip_maxc.store(set ? set : (1 << 30)); return old; }
 
 static bool wt_enabled() {
   static const bool off = getenv("DGSCT_NO_WT") != nullptr;      // A/B switch: no transposed weight copies
@@ -367,7 +369,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   Ctx side = ctx;
   if (aux_stream) { side.stream = aux_stream; side.aux = nullptr; }
   const float invN = 1.f / (float)N;
-  const int SK = C >= g_skip_minc.load(std::memory_order_relaxed) ? g_skip.load(std::memory_order_relaxed) : 0;   // what-if switches
+  const int SK = (C >= g_skip_minc.load(std::memory_order_relaxed) && C <= g_skip_maxc.load(std::memory_order_relaxed)) ? g_skip.load(std::memory_order_relaxed) : 0;   // what-if switches
   zero(ctx, b.S(0), (size_t)s.zero_end);
 
   // F1 ---- cross-modal remap                                            net_trans.py:553-555
@@ -404,7 +406,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   }
   // F2 ---- latent tokens attend to the remapped tokens (one pass over Yp)   :572-580, :592
   void* tokpk = s.tokpk >= 0 ? b.S(s.tokpk) : nullptr;
-  if (!(SK & 128)) tokattn_fwd(ctx, Yp, b.F(DGSCT_P_TOKENS), B, N, C, tk, b.S<float>(s.tok), b.S<float>(s.lse), b.S<float>(s.a), b.S(s.aE),
+  if (!(SK & (128 | 16384))) tokattn_fwd(ctx, Yp, b.F(DGSCT_P_TOKENS), B, N, C, tk, b.S<float>(s.tok), b.S<float>(s.lse), b.S<float>(s.a), b.S(s.aE),
               b.Wk<float>(wf.tokscr), tokpk, prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr);
   {
     stream_fork(ctx);                                            // a = mean_N(Yp) is complete on the main stream
@@ -418,7 +420,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     gemm(side, g2);
   }
   // F3 ---- X attends to the latent tokens (one pass over X)             :583-589
-  if (!(SK & 128)) xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1), tokpk);
+  if (!(SK & (128 | 32768))) xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1), tokpk);
   // F4-F6 ---- channel gate                                              :593-598
   {
     if (vq1_fused_supported(ctx.mode, N, C) && !fp8) {
@@ -576,7 +578,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   const int cg = C / g, dg = ds / g;
   const float invN = 1.f / (float)N;
   const bool vproj = gproj_supported(ctx.mode, C, ds, g);
-  const int SK = C >= g_skip_minc.load(std::memory_order_relaxed) ? g_skip.load(std::memory_order_relaxed) : 0;   // what-if switches
+  const int SK = (C >= g_skip_minc.load(std::memory_order_relaxed) && C <= g_skip_maxc.load(std::memory_order_relaxed)) ? g_skip.load(std::memory_order_relaxed) : 0;   // what-if switches
   // (weight-gradient products on the aux stream: every one of them goes through wgemm)
   auto wgemm = [SK](const Ctx& c, const Gemm& gg) { if (!(SK & 1)) gemm(c, gg); };
 
@@ -923,7 +925,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   }
   // B3 ---- X <- tokens attention: dX (output), dtok, d gate_av in one pass over X and dX1 (P2 recomputed)
   {
-    if (!(SK & 128)) xattn_bwd(ctx, X, dX1, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX, skip_into_dx ? dOut : nullptr,
+    if (!(SK & (128 | 65536))) xattn_bwd(ctx, X, dX1, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX, skip_into_dx ? dOut : nullptr,
               b.Wk<float>(wb.dtokF), G(DGSCT_P_GATE_AV),      // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
               s.tokpk >= 0 ? b.S(s.tokpk) : nullptr);
     if (d.remap == DGSCT_REMAP_CONV) {
@@ -937,7 +939,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B2 ---- tokens <- remapped tokens attention: dYp and d my_tokens in one pass over Yp (P1 recomputed from lse)
   void* dYp = b.Wk(wb.dYp);
   {
-    if (!(SK & 128)) tokattn_bwd(ctx, b.S(s.Yp), b.F(DGSCT_P_TOKENS), b.S<float>(s.tok), b.S<float>(s.lse), b.Wk<float>(wb.dtokF),
+    if (!(SK & (128 | 131072))) tokattn_bwd(ctx, b.S(s.Yp), b.F(DGSCT_P_TOKENS), b.S<float>(s.tok), b.S<float>(s.lse), b.Wk<float>(wb.dtokF),
                 b.Wk<float>(wb.da), invN, B, N, C, tk, dYp, b.Wk<float>(wb.dT0b), b.Wk<float>(wb.Dtok),
                 prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr, wb.dtokpk >= 0 ? b.Wk(wb.dtokpk) : nullptr);
     defer([=, &side, &b] {                                       // d my_tokens = sum_b (dtok + dS1 . Yp)
@@ -1018,7 +1020,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                            b.Wk<float>(wb.rowpart), row_part_floats(B, C));
   }
   side_flush();
-  stream_join(ctx);
+  if (!(SK & 8192)) stream_join(ctx);                            // (what-if 8192: no final join -- what waiting for the weight gradients costs the chain)
   if (d.remap == DGSCT_REMAP_CONV)   // + d rowsum(Wc)[c] broadcast over co (after the join: dWc is accumulated on aux)
     ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
   check_async("dgsct_adapter_backward");

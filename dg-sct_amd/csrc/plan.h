@@ -57,5 +57,6 @@ struct Plan {
 // what-if timing switches of the schedule (plan.cpp; dgsct_test_tune "skip" / "skipminc"): set < 0 queries
 int plan_skip_mode(int set);
 int plan_skip_minc(int set);
+int plan_skip_maxc(int set);
 
 }  // namespace dgsct

@@ -46,6 +46,7 @@ int gemm_tall_mode(int) { return 0; }
 int gemm8_mode(int) { return 0; }                 // (the 8-wave GEMM kernel is a device-side choice: nothing to emulate)
 int gemm_noatomic_mode(int) { return 0; }
 int gemm8_wg_target(int) { return 0; }
+int gemm8_pipe_mode(int) { return 0; }
 
 void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
 

@@ -62,6 +62,8 @@ def show(agg, wall, title):
 
 if os.environ.get("SKIPMINC"):           # what-if switches ("skip", plan.cpp) only for adapters at least this wide
     lib.test_tune("skipminc", int(os.environ["SKIPMINC"]))
+if os.environ.get("SKIPMAXC"):
+    lib.test_tune("skipmaxc", int(os.environ["SKIPMAXC"]))
 base, wall = measure()
 show(base, wall, "default")
 # A/B inside one process (two boxes differ by 2 %): each named switch off, then the default again

@@ -58,7 +58,8 @@ def check(name, lines):
         return errs + ["no loop found"]
     label = lines[hdr].split(":")[0]
     # the loop may be entered through a preheader block placed before it: take every backward branch to blocks at/above hdr
-    end = max((i for i, l in enumerate(lines) if re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b", l)), default=None)
+    # (the latch may be an unconditional s_branch: the round-5 pipelined loop ends in `if (it + 1 < nk) landed(0)` + a plain jump back)
+    end = max((i for i, l in enumerate(lines) if re.search(r"s_(c)?branch\w*\s+" + re.escape(label) + r"\b", l)), default=None)
     if end is None or end < hdr:
         cands = [i for i, l in enumerate(lines) if i > hdr and re.search(r"s_cbranch\w*\s+\.LBB\d+_\d+", l)
                  and any(lines[j].startswith(l.split()[-1] + ":") for j in range(0, i))]
