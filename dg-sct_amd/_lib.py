@@ -139,9 +139,10 @@ class Lib:
                                                     saved, ws, stream, aux_stream), "dgsct_adapter_forward")
 
     def backward(self, desc, ptrs, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream=None,
-                 skip_into_dx=False):
+                 skip_into_dx=False, no_join=False):
+        flags = (1 if skip_into_dx else 0) | (2 if no_join else 0)       # DGSCT_BWD_SKIP_INTO_DX | DGSCT_BWD_NO_JOIN
         self._check(self.c.dgsct_adapter_backward_ex(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, saved, dOut, dMap, dTmap,
-                                                     dX, dY, grads, ws, stream, aux_stream, int(bool(skip_into_dx))),
+                                                     dX, dY, grads, ws, stream, aux_stream, flags),
                     "dgsct_adapter_backward")
 
     def saved_regions(self, desc):

@@ -97,7 +97,8 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
   Plan p(*desc);
   if (!p.ok) return 2;
   void* rec = call_prof_begin(stream, 1, desc->N, desc->C);
-  const int rc = p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream, skip_into_dx != 0);
+  const int rc = p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream, (skip_into_dx & DGSCT_BWD_SKIP_INTO_DX) != 0,
+                            (skip_into_dx & DGSCT_BWD_NO_JOIN) != 0);
   call_prof_end(rec);
   return rc;
 }

@@ -550,7 +550,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
 // ------------------------------------------------------------------------------------------------
 int Plan::backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved_c,
                    const void* dOut, const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws,
-                   void* stream, void* aux_stream, bool skip_into_dx) const {
+                   void* stream, void* aux_stream, bool skip_into_dx, bool no_join) const {
   Bound b(*this, params, prep, const_cast<void*>(saved_c), ws, stream);
   b.ctx.aux = aux_stream;
   const Ctx& ctx = b.ctx;
@@ -1020,9 +1020,15 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
                            b.Wk<float>(wb.rowpart), row_part_floats(B, C));
   }
   side_flush();
-  if (!(SK & 8192)) stream_join(ctx);                            // (what-if 8192: no final join -- what waiting for the weight gradients costs the chain)
-  if (d.remap == DGSCT_REMAP_CONV)   // + d rowsum(Wc)[c] broadcast over co (after the join: dWc is accumulated on aux)
-    ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
+  // d rowsum(Wc)[c] is broadcast over co into dWc, which the aux stream accumulates: after the join -- or, when the caller takes over the
+  // ordering (DGSCT_BWD_NO_JOIN: it orders whatever reads `grads`, reuses `ws` or frees the inputs after the aux stream itself, so the
+  // chain of the NEXT call never waits for this call's weight gradients), on the aux stream behind them
+  const bool deferred = no_join && aux_stream;
+  if (!deferred && !(SK & 8192)) stream_join(ctx);
+  if (d.remap == DGSCT_REMAP_CONV) {
+    if (deferred) { stream_fork(ctx); ew(side, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co); }
+    else ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
+  }
   check_async("dgsct_adapter_backward");
   return has_error() ? 1 : 0;
 }

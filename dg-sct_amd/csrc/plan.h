@@ -47,7 +47,7 @@ struct Plan {
               void* saved, void* ws, void* stream, const void* residual = nullptr, void* aux_stream = nullptr) const;
   int backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved, const void* dOut,
                const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws, void* stream,
-               void* aux_stream = nullptr, bool skip_into_dx = false) const;
+               void* aux_stream = nullptr, bool skip_into_dx = false, bool no_join = false) const;
 
  private:
   bool validate();

@@ -139,6 +139,11 @@ class GradAllReducer:
                         dist.all_reduce(t, op=op, group=self.group)
                 self._work.append(cm)
 
+        if tensors[0].is_cuda:
+            # the flat gradient buffers are completed on the adapters' weight-gradient (aux) streams, whose join is deferred
+            # (ops.DEFER_AUX_JOIN): order this stream -- and the producing streams -- behind them before anything reads a gradient
+            from . import ops as _ops
+            _ops.drain_aux(tensors[0].device)
         if tensors[0].is_cuda and self.overlap and os.environ.get("DGSCT_DP_COMM_STREAM", "0") != "1":
             # Launch from the stream that produced the bucket's last gradient: ProcessGroupNCCL orders its own collective
             # stream behind an event on the CURRENT stream, so no extra stream is needed -- the current stream only has to

@@ -129,8 +129,8 @@ def _aux_stream(lib: Lib, t: torch.Tensor, stream: int) -> Optional[int]:
     return s.cuda_stream
 
 
-def _workspace(device: torch.device, stream: int, nbytes: int) -> torch.Tensor:
-    key = (device.type, device.index, stream)
+def _workspace(device: torch.device, stream: int, nbytes: int, slot: int = 0) -> torch.Tensor:
+    key = (device.type, device.index, stream, slot)
     with _WS_LOCK:
         buf = _WS.get(key)
         if buf is None or buf.numel() < nbytes:
@@ -140,8 +140,53 @@ def _workspace(device: torch.device, stream: int, nbytes: int) -> torch.Tensor:
 
 
 def release_workspaces():
+    drain_aux()
     with _WS_LOCK:
         _WS.clear()
+
+
+# ---- deferred join of the weight-gradient (aux) stream (round 5) -------------------------------------------------------------
+# dgsct_adapter_backward_ex(DGSCT_BWD_NO_JOIN) returns with its weight gradients still running on the aux stream: the chain of the
+# NEXT backward call on the same stream starts at once instead of waiting for them (0.9 ms of the 50 ms AVE step, most of it the
+# remap weight gradient of stage 0).  What that leaves to the caller is done here:
+#   * two workspaces per stream, used alternately: call k + 1 never overwrites what call k's aux kernels still read;
+#   * an event recorded on the aux stream behind call k is waited for by the main stream at the END of call k + 1 (it has long
+#     completed by then); only then are call k's buffers (saved activations, inputs, its workspace) let go;
+#   * the gradients of the LAST calls are ordered by drain_aux(): queued as an autograd end-of-backward callback (the stream that
+#     called backward() waits for every pending aux event), and called by the data-parallel reducer before it launches a collective.
+# Only the flat-parameter path defers (autograd adopts the gradient buffer without reading it); DGSCT_DEFER_AUX=0 switches it off.
+DEFER_AUX_JOIN = os.environ.get("DGSCT_DEFER_AUX", "1") != "0"
+_PENDING: Dict[Tuple, Tuple] = {}          # (device index, stream) -> (event on aux, tensors kept alive)
+_SLOT: Dict[Tuple, int] = {}
+_CB = threading.local()
+
+
+def drain_aux(device: Optional[torch.device] = None):
+    """Order the CURRENT stream (and each producing stream) after every weight-gradient stream that still has work in flight."""
+    with _WS_LOCK:
+        items = [(k, v) for k, v in _PENDING.items() if device is None or k[0] == (device.index if device.index is not None else torch.cuda.current_device())]
+        for k, _ in items:
+            del _PENDING[k]
+    for (dev, stream), (ev, keep) in items:
+        torch.cuda.current_stream(dev).wait_event(ev)
+        torch.cuda.ExternalStream(stream, device=torch.device("cuda", dev)).wait_event(ev) if stream else None
+        del keep
+
+
+def _queue_drain():
+    """once per backward pass: drain when the autograd engine has run its last node (on the thread that called backward())"""
+    if getattr(_CB, "queued", False):
+        return
+
+    def cb():
+        _CB.queued = False
+        drain_aux()
+
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(cb)
+        _CB.queued = True
+    except RuntimeError:                   # not inside a backward pass (raw calls): the caller drains
+        pass
 
 
 def _dev_guard(t: torch.Tensor):
@@ -228,7 +273,9 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
 
 
 def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y, saved, dOut, dMap, dTmap, flat_out=False,
-                 skip_into_dx=False):
+                 skip_into_dx=False, defer_join=False):
+    """defer_join: the call returns without joining its weight-gradient stream (see DEFER_AUX_JOIN above); `grads` is complete only
+    after drain_aux() -- dX / dY are ordered on the current stream as always."""
     _mark_stream_use(X, Y, saved, dOut, dMap, dTmap, prep)
     sz = _sizes(lib, d)
     dev = X.device
@@ -236,14 +283,31 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     dY = torch.empty_like(Y)
     grads = torch.empty(int(sz.grad_floats), dtype=torch.float32, device=dev)
     stream = _stream_of(X)
-    ws = _workspace(dev, stream, int(sz.ws_bwd_bytes))
+    aux = _aux_stream(lib, X, stream)
+    defer = bool(defer_join and DEFER_AUX_JOIN and aux is not None)
+    key = (dev.index, stream)
+    slot = 0
+    if defer:
+        slot = _SLOT[key] = 1 - _SLOT.get(key, 1)
+    ws = _workspace(dev, stream, int(sz.ws_bwd_bytes), slot)
     if _POISON:
         _poison(dX, dY, grads, ws)
     with _dev_guard(X):
         lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
                      dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
-                     dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, _aux_stream(lib, X, stream),
-                     skip_into_dx)
+                     dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, aux, skip_into_dx, defer)
+        if defer:
+            ev = torch.cuda.Event()
+            ev.record(_AUX[key])                                       # behind everything this call put on its aux stream
+            with _WS_LOCK:
+                prev = _PENDING.get(key)
+                # (NOT `grads`: autograd adopts the flat gradient only while nothing else references it -- a second reference makes
+                #  AccumulateGrad CLONE it on the calling stream, i.e. read it before the aux stream has finished writing)
+                _PENDING[key] = (ev, (saved, X, Y, dOut, dMap, dTmap, prep, ws))
+            if prev is not None:
+                torch.cuda.current_stream(dev).wait_event(prev[0])     # the call before this one: long done; its buffers go now
+                del prev
+            _queue_drain()
     if flat_out:
         return dX, dY, grads
     lay = grad_layout(lib, d)
@@ -346,7 +410,7 @@ class _AdapterFlatFn(torch.autograd.Function):
         dMap = dMap.contiguous().float() if dMap is not None else None
         dTm = dTmap.contiguous().float() if (spec.temporal and dTmap is not None and dTmap.numel()) else None
         dX, dY, gflat = raw_backward(ctx.lib, spec, ctx.desc, ctx.plist, ctx.prep, X, Y, ctx.saved_buf, dOut, dMap, dTm,
-                                     flat_out=True, skip_into_dx=ctx.skip)
+                                     flat_out=True, skip_into_dx=ctx.skip, defer_join=True)
         ctx.saved_buf = None
         return None, None, None, None, None, None, dOut if ctx.has_res else None, dX, dY, gflat
 

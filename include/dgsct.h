@@ -148,8 +148,16 @@ int dgsct_adapter_backward(const dgsct_adapter_desc* desc, float* const* params,
 /* Same, with an optional second stream: weight / bias gradients (which feed nothing downstream) are issued on
  * `aux_stream` and overlap the data-gradient chain; the call forks from and joins back into `stream`, so the caller sees
  * ordinary single-stream semantics.  aux_stream == NULL is dgsct_adapter_backward.
- * skip_into_dx != 0: the forward was `out = X + adapter(X, Y)` (residual aliased X), so dX also receives dOut
- * (dX = dOut + d adapter / dX) -- saves the caller's gradient-accumulation pass over [BT][N][C]. */
+ * `skip_into_dx` is a flag word (0 / 1 keep their round-1 meaning):
+ *   DGSCT_BWD_SKIP_INTO_DX (1): the forward was `out = X + adapter(X, Y)` (residual aliased X), so dX also receives dOut
+ *     (dX = dOut + d adapter / dX) -- saves the caller's gradient-accumulation pass over [BT][N][C];
+ *   DGSCT_BWD_NO_JOIN (2, round 5; ignored without an aux stream): the call does NOT join the aux stream back into `stream`.  dX
+ *     and dY are complete in `stream` order as always; `grads` is complete, and `ws`, `saved`, X, Y, dOut may be reused / freed, only
+ *     once everything this call enqueued on `aux_stream` has run -- the CALLER orders that (an event recorded on aux_stream after the
+ *     call, waited for before the next use).  The chain of the caller's next call on `stream` then never waits for this call's
+ *     weight gradients (0.9 ms of the 50 ms AVE step); dg-sct_amd/ops.py does it with two alternating workspaces per stream. */
+#define DGSCT_BWD_SKIP_INTO_DX 1
+#define DGSCT_BWD_NO_JOIN 2
 int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* params, const void* prep,
                               const void* X, const void* Y, const void* saved,
                               const void* dOut, const float* dMap, const float* dTmap,

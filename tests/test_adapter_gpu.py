@@ -561,3 +561,36 @@ def test_module_dropin_matches_oracle():
     assert int(m.bn1.num_batches_tracked) == 1
     assert fp32_err(m.bn2.running_mean, po["bn2.running_mean"]) < TOL_F32
     assert fp32_err(m.bn2.running_var, po["bn2.running_var"]) < TOL_F32
+
+
+def test_deferred_aux_join_gives_the_joined_results():
+    """round 5 (ops.DEFER_AUX_JOIN, DGSCT_BWD_NO_JOIN): backward calls that return with their weight gradients still running on the aux
+    stream -- three calls in a row on one stream (alternating workspaces, each call letting go of the buffers of the one before), then
+    drain_aux() -- against the same calls with the join inside; fp32, so only the atomic summation order differs."""
+    N, C, No, Co, BT = 144, 64, 96, 48, 8
+    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=8, r=8, g=2)
+    p = O.random_params(cfg, "ave", seed=5)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    params = param_table(p, spec, DEV)
+    gen = torch.Generator().manual_seed(3)
+    res = {}
+    for defer in (False, True):
+        outs = []
+        prep = ops.prepare(lib, spec, params, torch.float32, DEV)
+        for rep in range(3):
+            g2 = torch.Generator().manual_seed(10 + rep)
+            X = torch.randn(BT, N, C, generator=g2).to(DEV).contiguous()
+            Y = torch.randn(BT, No, Co, generator=g2).to(DEV).contiguous()
+            dOut = torch.randn(BT, N, C, generator=g2).to(DEV).contiguous()
+            dMap = torch.randn(BT, N, generator=g2).to(DEV)
+            out, amap, _, saved, d = ops.raw_forward(lib, spec, [t.clone() if t is not None else None for t in params], prep, X, Y, True)
+            dX, dY, gflat = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, None, flat_out=True, defer_join=defer)
+            del saved, X, Y, dOut, dMap                    # (the deferred path keeps what the aux stream still reads alive itself)
+            outs.append((dX, dY, gflat))
+        ops.drain_aux()
+        torch.cuda.synchronize()
+        res[defer] = [(a.clone(), b.clone(), c.clone()) for a, b, c in outs]
+    for (a0, b0, c0), (a1, b1, c1) in zip(res[False], res[True]):
+        assert fp32_err(a1, a0) < 1e-4 and fp32_err(b1, b0) < 1e-4
+        assert fp32_err(c1, c0) < 1e-3, fp32_err(c1, c0)
