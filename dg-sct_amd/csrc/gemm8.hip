@@ -530,9 +530,12 @@ int gemm8_mode(int set) {
   return old;
 }
 
-// experiment knob ("g8wg"): late-stage weight gradients (few output tiles, very deep contraction) on this kernel with only as many
-// split-K slabs as give ~`target` workgroups (one per CU): fewer CUs for longer instead of every CU for a short, atomics-heavy burst
-static std::atomic<int> g_g8wg{getenv("DGSCT_G8WG") ? atoi(getenv("DGSCT_G8WG")) : 0};
+// "g8wg" (dgsct_test_tune / DGSCT_G8WG; 0 = off): late-stage weight gradients (few 256 x 256 output tiles, a 23 040 .. 40 960-row
+// contraction) on this kernel with only as many split-K slabs as give ~`target` workgroups: a FEW CUs for longer instead of every CU
+// for a short burst that ends in 16-40-way atomics.  Round 4 measured the opposite choice (60 splits: 36.7 -> 61 us, kept off).  With
+// the aux join deferred (round 5) only the CU-time and the L2 traffic of these products count, not their latency: in-process A/B
+// (tools/call_overlap.py AB=g8wg=..): 32 -> -0.4 .. -0.7 ms per step, 64 -> -0.25, 96 -> +0.15, 16 -> noise.  Default 32.
+static std::atomic<int> g_g8wg{getenv("DGSCT_G8WG") ? atoi(getenv("DGSCT_G8WG")) : 32};
 int gemm8_wg_target(int set) { const int old = g_g8wg.load(); if (set >= 0) g_g8wg.store(set); return old; }
 
 bool gemm8_try(const Ctx& ctx, const Gemm& g) {
