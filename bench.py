@@ -485,6 +485,16 @@ def main():
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None
         step_block = dict(frac_of_mfma_peak=round(alg / (ms_per_step * 1e-3) / 1e12 / peak, 4), alg_gb_per_step=round(alg_bytes_per_step(stages, BT) / 1e9, 2))
+        try:        # what the 48 forward calls of a step keep for their backward (dgsct_query: `saved`) and the scratch of one call
+            from dgsct_amd import ops as _o
+            sv = wsb = 0
+            for m in stack.modules():
+                if hasattr(m, "spec") and hasattr(m.spec, "desc"):
+                    sz = lib.query(m.spec.desc(BT, dtype, True))
+                    sv += int(sz.saved_bytes); wsb = max(wsb, int(sz.ws_bwd_bytes))
+            step_block.update(saved_gb_per_step=round(sv / 1e9, 2), largest_bwd_workspace_gb=round(wsb / 1e9, 2))
+        except Exception:
+            pass
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
         tsrc = None

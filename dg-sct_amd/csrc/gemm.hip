@@ -866,7 +866,8 @@ static void launch_cfg(const GemmK& k, int ak, int bk, dim3 grid, hipStream_t s,
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // what-if switch (TIMING ONLY, results wrong): split-K partial tiles leave as plain stores instead of fp32 atomics -- what the atomics cost
-static std::atomic<int> g_noatomic{0};
+static std::atomic<int> g_noatomic{0}, g_cfgx{0};
+int gemm_cfgx_mode(int set) { const int old = g_cfgx.load(); if (set >= 0) g_cfgx.store(set); return old; }
 int gemm_noatomic_mode(int set) { const int old = g_noatomic.load(); if (set >= 0) g_noatomic.store(set); return old; }
 
 template <int MODE>
@@ -945,6 +946,9 @@ static void gemm_mode(const Ctx& ctx, const Gemm& g) {
     const bool fills = w0 >= 192 && (last == 0 || last >= 576 || w0 >= 6144);
     cfg = (kflat > 256 && g.M >= 128 && g.N >= 128 && fills && !g.atomic) ? 0 : 4;
   }
+  // experiment ("cfgx" bit 1): the per-frame batched products of the late stages with a short contraction (dY[b] = Wn^T dT[b],
+  // T1[b] = Wn Y[b]: K = 36 .. 256) on 128 x 128 tiles instead of 64 x 64
+  if ((g_cfgx.load(std::memory_order_relaxed) & 1) && !g.atomic && g.batch >= 16 && g.M >= 128 && g.N >= 128 && kflat <= 256 && cfg == 4) cfg = 0;
   if (const char* e = getenv("DGSCT_GEMM_CFG")) { const int c = atoi(e); if (c >= 0 && c <= 5) cfg = c; }   // tuning hook
   if (rowwise) {
     if (g.M > 32 || g.R || g.atomic || g.splitk > 1 || g.bias_m || g.bias_n) {

@@ -30,6 +30,7 @@ int gemm_tall_mode(int set);        // 0: off, 1: on (default; DGSCT_NO_GEMM_TAL
 
 int gemm8_pipe_mode(int set);      // k-loop variant of gemm8 (1: pipelined across k-tiles, default; 0: two barriers per k-tile)
 int gemm8_wg_target(int set);      // experiment: workgroup target of late-stage weight gradients on gemm8 (0 = off)
+int gemm_cfgx_mode(int set);       // tile-configuration experiments of the tiled engine (bit mask)
 int gemm_noatomic_mode(int set);   // what-if (timing only): split-K partials as plain stores
 
 }  // namespace dgsct

@@ -45,6 +45,7 @@ int gemm_skinny_mode(int) { return 0; }
 int gemm_tall_mode(int) { return 0; }
 int gemm8_mode(int) { return 0; }                 // (the 8-wave GEMM kernel is a device-side choice: nothing to emulate)
 int gemm_noatomic_mode(int) { return 0; }
+int gemm_cfgx_mode(int) { return 0; }
 int gemm8_wg_target(int) { return 0; }
 int gemm8_pipe_mode(int) { return 0; }
 

@@ -5,7 +5,10 @@ otherwise drain the LDS-DMA queue in front of every ds_read_b64_tr_b16).  The co
 of those asm statements arrive later, so three properties are checked on what it actually emitted, per kernel:
   1. no scratch traffic (a spill reload is a VMEM load: `s_waitcnt vmcnt(0)` in the loop, and copies of in-flight data);
   2. inside the k-loop every `s_waitcnt vmcnt` sits in an inline-asm block (ours, counted) -- none made by the compiler;
-  3. between an asm `ds_read*` and the next asm `s_waitcnt lgkmcnt(0)` no instruction names the registers being loaded.
+  3. between an asm `ds_read*` and the next asm `s_waitcnt lgkmcnt(0)` no instruction names the registers being loaded;
+  4. (round 5, the kernels with the cross-tile pipelined k-loop: last template argument `true`) the interleave itself: the loop has ONE
+     s_barrier; behind it come the LDS-DMA of the tile after next and the first fragment reads of the NEXT tile, and only then the last
+     MFMA group of the current tile -- i.e. that read flies under MFMAs instead of sitting exposed behind the barrier.
 usage: python tools/check_gemm8_isa.py  -> exit 0 / 1, prints one line per kernel."""
 import os
 import re
@@ -64,6 +67,18 @@ def check(name, lines):
         cands = [i for i, l in enumerate(lines) if i > hdr and re.search(r"s_cbranch\w*\s+\.LBB\d+_\d+", l)
                  and any(lines[j].startswith(l.split()[-1] + ":") for j in range(0, i))]
         end = max(cands) if cands else len(lines) - 1
+    if name.endswith("ELb1EEEvNS_2G8E"):                       # PIPE variant: the interleave (item 4 of the header)
+        body = [(i, lines[i].strip()) for i in range(hdr, end + 1)]
+        bars = [i for i, l in body if l.startswith("s_barrier")]
+        if len(bars) != 1:
+            errs.append(f"pipelined k-loop: expected exactly one s_barrier, found {len(bars)}")
+        else:
+            after = [(i, l) for i, l in body if i > bars[0]]
+            dma = [i for i, l in after if l.startswith("global_load_lds")]
+            rd = [i for i, l in after if l.startswith("ds_read")]
+            mf = [i for i, l in after if l.startswith("v_mfma")]
+            if not dma or not rd or not mf or not (min(rd) < min(mf)) or not (min(dma) < min(mf)):
+                errs.append("pipelined k-loop: behind the barrier the DMA issue and the next tile's first fragment reads must precede the last MFMA group")
     in_asm = False
     pending = {}            # register -> line of the asm ds_read that loads it
     for i in range(hdr, end + 1):

@@ -23,7 +23,7 @@ def main(path, top=40, gemm_json=None, steps=None):
     # family roll-up
     fam = {}
     for name, n, tot, mn, mx in rows:
-        k = "gemm_kernel<*>" if ("gemm_kernel" in name or "gemm8_kernel" in name) else ("torch/other" if "dgsct" not in name else re.sub(r"<.*", "", short(name)))
+        k = "gemm_kernel<*>" if ("gemm_kernel" in name or "gemm8_kernel" in name or "gemm_fx_kernel" in name) else ("torch/other" if "dgsct" not in name else re.sub(r"<.*", "", short(name)))
         a = fam.setdefault(k, [0, 0])
         a[0] += n; a[1] += tot
     if gemm_json and steps:
@@ -35,7 +35,7 @@ def main(path, top=40, gemm_json=None, steps=None):
                    "kernel_ms_per_step_all": round(total / 1e6 / steps, 2), "dispatches_per_step": round(sum(r[1] for r in rows) / steps, 1),
                    "steps_traced": steps,
                    "source": "rocprofv3 --kernel-trace of `python bench.py --steps 5 --warmup 2 --no-roofline --no-cpu-baseline` "
-                             "(7 steps under the timed two-stream schedule); gemm = gemm_kernel<*> + gemm8_kernel<*>"}, open(gemm_json, "w"))
+                             "(7 steps under the timed two-stream schedule); gemm = gemm_kernel<*> + gemm8_kernel<*> + gemm_fx_kernel<*>"}, open(gemm_json, "w"))
     print("# by family")
     for k, (n, tot) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         print(f"{n:7d} {tot/1e6:10.3f} {tot/n/1e3:9.2f} {'':8} {'':9} {100*tot/total:6.2f}  {k}")
