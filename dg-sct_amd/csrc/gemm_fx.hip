@@ -37,7 +37,7 @@ struct FxK {
   const char* A; long lda, a_bs;
   const char* B; long ldb, b_bs;
   char* D; long ldd, dbs;
-  const float* bias_n;
+  const float* bias_n; int act;
   const char* R; long ldr, rbs;
   // prologue
   int rpf, nframes, nb, kpad; unsigned rinv;          // frame = umulhi(m, rinv); nb = frame buckets a tile can touch; kpad = K rounded up to 64
@@ -47,6 +47,7 @@ struct FxK {
   char* a_store;
   // epilogue
   const float* e_cs; const char* e_x; float* e_acc; long e_ld;
+  float* e_acc2; float e_scale;          // COLSTATS: sum of squares; COLSUM: positive counts, scale of the sums
 };
 
 __device__ __forceinline__ int fx_frame(int m, unsigned rinv) { return (int)__umulhi((unsigned)m, rinv); }
@@ -74,7 +75,9 @@ void gemm_fx_kernel(const FxK p) {
   char* ldsB = smem + A_BYTES;
   float* tab = reinterpret_cast<float*>(smem + MAIN_BYTES);                   // prologue table
   const int tab_floats = PRO == APRO_MASKSCALE ? p.nb * p.kpad : (PRO == APRO_BNBWD ? 5 * p.kpad : 0);
-  float* chacc = tab + tab_floats;                                            // EPI_XCBWD: [nb][BN] per-frame column sums
+  float* chacc = tab + tab_floats;                                            // epilogue column sums: [nb][NQ][BN] (NQ = 2 but for EPI_XCBWD)
+  constexpr int NQ = (EPI == EPI_COLSTATS || EPI == EPI_COLSUM) ? 2 : 1;
+  constexpr bool COLRED = EPI != EPI_NONE;                                    // the epilogue ends in a column reduction
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,7 +96,7 @@ void gemm_fx_kernel(const FxK p) {
     else { tn = __builtin_amdgcn_readfirstlane(t / p.tiles_m); tm = __builtin_amdgcn_readfirstlane(t - tn * p.tiles_m); }
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int f0 = (PRO == APRO_MASKSCALE || EPI == EPI_XCBWD) ? fx_frame(m0, p.rinv) : 0;
+  const int f0 = (PRO == APRO_MASKSCALE || EPI == EPI_XCBWD || EPI == EPI_COLSUM) ? fx_frame(m0, p.rinv) : 0;
   const char* Ab = p.A + (long)b * p.a_bs * 2;
   const char* A2b = PRO == APRO_BNBWD ? p.a2 + (long)b * p.a_bs * 2 : nullptr;
   const char* Bb = p.B + (long)b * p.b_bs * 2;
@@ -141,8 +144,8 @@ void gemm_fx_kernel(const FxK p) {
       tab[k] = k1; tab[p.kpad + k] = k2; tab[2 * p.kpad + k] = k3; tab[3 * p.kpad + k] = a; tab[4 * p.kpad + k] = sh;
     }
   }
-  if constexpr (EPI == EPI_XCBWD) {
-    for (int idx = tid; idx < p.nb * BN; idx += 256) chacc[idx] = 0.f;
+  if constexpr (COLRED) {
+    for (int idx = tid; idx < p.nb * NQ * BN; idx += 256) chacc[idx] = 0.f;
   }
   // (the first __syncthreads of the k-loop orders these LDS writes before their first use)
 
@@ -299,7 +302,9 @@ void gemm_fx_kernel(const FxK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        stg[row * SP + j * 32 + (lane & 31)] = acc[i][j][r] + bn;
+        float av = acc[i][j][r] + bn;
+        if (p.act == ACT_RELU) av = fmaxf(av, 0.f);
+        stg[row * SP + j * 32 + (lane & 31)] = av;
       }
     }
     __syncthreads();
@@ -336,35 +341,60 @@ void gemm_fx_kernel(const FxK p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
       }
-      if (ok) *reinterpret_cast<uint4*>(Db + ((long)m * p.ldd + n) * 2) = fx_pack(v);
+      const uint4 packed = fx_pack(v);
+      if (ok) *reinterpret_cast<uint4*>(Db + ((long)m * p.ldd + n) * 2) = packed;
+      if constexpr (EPI == EPI_COLSTATS || EPI == EPI_COLSUM) {          // the values AS STORED back into the staging block (0 for rows / columns outside)
+        float vr[8];
+        fx_unpack(packed, vr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vr[e] = ok ? vr[e] : 0.f;
+        *reinterpret_cast<float4*>(stg + row * SP + cc * 8) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+        *reinterpret_cast<float4*>(stg + row * SP + cc * 8 + 4) = make_float4(vr[4], vr[5], vr[6], vr[7]);
+      }
     }
-    if constexpr (EPI == EPI_XCBWD) {
+    if constexpr (COLRED) {
       __syncthreads();
-      // column sums of the products over this block's rows, split at the (single: rpf >= 32) frame boundary inside the block
+      // column reduction over this block's rows, split at the (single: rpf >= 32) frame boundary inside the block.
+      //   XCBWD: sum of the products;  COLSUM: sum and number of positive entries (per frame);  COLSTATS: sum and sum of squares (no frames)
       constexpr int NCOL = TN * 32, LPC = 64 / NCOL, RPL = 32 / LPC;       // lanes per column, rows per lane
       const int col = lane % NCOL, half = lane / NCOL;
-      const int fb = fx_frame(mrow0 < p.M ? mrow0 : p.M - 1, p.rinv);
-      const int nb1 = (fb + 1) * p.rpf - mrow0;                           // rows of the block that belong to frame fb
-      float s0 = 0.f, s1 = 0.f;
+      int nb1 = 32, bk = 0;
+      if constexpr (EPI != EPI_COLSTATS) {
+        const int fb = fx_frame(mrow0 < p.M ? mrow0 : p.M - 1, p.rinv);
+        nb1 = (fb + 1) * p.rpf - mrow0;                                   // rows of the block that belong to frame fb
+        bk = fb - f0;
+      }
+      float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
       for (int rr = 0; rr < RPL; ++rr) {
         const int row = half * RPL + rr;
         const float x = stg[row * SP + col];
-        if (row < nb1) s0 += x; else s1 += x;
+        const float y = EPI == EPI_COLSTATS ? x * x : (x > 0.f ? 1.f : 0.f);
+        if (row < nb1) { s0 += x; q0 += y; } else { s1 += x; q1 += y; }
       }
-      const int bk = fb - f0;
-      float* dst = chacc + bk * BN + wn * NCOL + col;
+      float* dst = chacc + (bk * NQ) * BN + wn * NCOL + col;
       atomicAdd(dst, s0);
-      if (nb1 < 32 && bk + 1 < p.nb) atomicAdd(dst + BN, s1);
+      if (NQ == 2) atomicAdd(dst + BN, q0);
+      if (nb1 < 32 && bk + 1 < p.nb) {
+        atomicAdd(dst + NQ * BN, s1);
+        if (NQ == 2) atomicAdd(dst + NQ * BN + BN, q1);
+      }
     }
   }
-  if constexpr (EPI == EPI_XCBWD) {
+  if constexpr (COLRED) {
     __syncthreads();
-    for (int idx = tid; idx < p.nb * BN; idx += 256) {
-      const int f = idx / BN, cn = idx - f * BN;
+    for (int idx = tid; idx < p.nb * NQ * BN; idx += 256) {
+      const int f = idx / (NQ * BN), rem = idx - f * (NQ * BN), q = rem / BN, cn = rem - q * BN;
       const int fr = f0 + f, n = n0 + cn;
-      const float s = chacc[idx];
-      if (fr < p.nframes && n < p.N && s != 0.f) unsafeAtomicAdd(p.e_acc + (long)fr * p.e_ld + n, s);
+      const float sv = chacc[idx];
+      if (n >= p.N || sv == 0.f) continue;
+      if constexpr (EPI == EPI_COLSTATS) {                                // channel of column n in group b: b * N + n
+        unsafeAtomicAdd((q ? p.e_acc2 : p.e_acc) + (long)b * p.N + n, sv);
+      } else {
+        if (fr >= p.nframes) continue;
+        if (q == 0) unsafeAtomicAdd(p.e_acc + (long)fr * p.e_ld + n, EPI == EPI_COLSUM ? sv * p.e_scale : sv);
+        else unsafeAtomicAdd(p.e_acc2 + (long)fr * p.e_ld + n, sv);
+      }
     }
   }
 }
@@ -383,6 +413,8 @@ void fx_launch_cfg(const FxK& k, int pro, int epi, dim3 grid, size_t shmem, hipS
   else if (pro == APRO_MASKSCALE) fx_launch_one<WGM, WGN, TM, TN, APRO_MASKSCALE, EPI_NONE>(k, grid, shmem, s);
   else if (pro == APRO_BNBWD) fx_launch_one<WGM, WGN, TM, TN, APRO_BNBWD, EPI_NONE>(k, grid, shmem, s);
   else if (epi == EPI_XCBWD) fx_launch_one<WGM, WGN, TM, TN, APRO_NONE, EPI_XCBWD>(k, grid, shmem, s);
+  else if (epi == EPI_COLSTATS) fx_launch_one<WGM, WGN, TM, TN, APRO_NONE, EPI_COLSTATS>(k, grid, shmem, s);
+  else if (epi == EPI_COLSUM) fx_launch_one<WGM, WGN, TM, TN, APRO_NONE, EPI_COLSUM>(k, grid, shmem, s);
   else fx_launch_one<WGM, WGN, TM, TN, APRO_NONE, EPI_NONE>(k, grid, shmem, s);
 }
 
@@ -408,6 +440,7 @@ size_t fx_shmem(int cfg, const Gemm& g, const GemmFx& fx, int* nb_out, int* kpad
   if (fx.a_pro == APRO_MASKSCALE) extra += (size_t)nb * kpad * 4;
   if (fx.a_pro == APRO_BNBWD) extra += (size_t)5 * kpad * 4;
   if (fx.epi == EPI_XCBWD) extra += (size_t)nb * BN * 4;
+  if (fx.epi == EPI_COLSTATS || fx.epi == EPI_COLSUM) extra += (size_t)nb * 2 * BN * 4;
   if (nb_out) *nb_out = nb;
   if (kpad_out) *kpad_out = kpad;
   return (opnd > stg ? opnd : stg) + extra;
@@ -420,23 +453,24 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 int gemmfx_mode(int set) {
   // bit mask of the call sites (plan.cpp): 1 dZ (BN2 backward), 2 dX3 (ReLU + BN1 backward), 4 dXc (ReLU backward + channel-gate backward),
   // 8 dX1 += dvq1 Wv1 (ReLU backward); 15 = all (default); 16: the A-operand prologues of sites 4 / 8 at every width (default: C <= 256);
-  // 32: site 4 never with its prologue (tests)
-  if (g_fx_mode.load(std::memory_order_relaxed) < 0) g_fx_mode.store(getenv("DGSCT_NO_GEMMFX") ? 0 : 15, std::memory_order_relaxed);
+  // 32: site 4 never with its prologue (tests); FORWARD sites: 64 vq1 product + per-frame column sums / positive counts, 128 the two
+  // bottleneck products + their BatchNorm sums; default = 15 + 64 + 128
+  if (g_fx_mode.load(std::memory_order_relaxed) < 0) g_fx_mode.store(getenv("DGSCT_NO_GEMMFX") ? 0 : 15 + 64 + 128, std::memory_order_relaxed);
   const int old = g_fx_mode.load(std::memory_order_relaxed);
-  if (set >= 0) g_fx_mode.store(set & 63, std::memory_order_relaxed);
+  if (set >= 0) g_fx_mode.store(set & 255, std::memory_order_relaxed);
   return old;
 }
 
 bool gemm_fx_supported(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
   if (!gemmfx_mode(-1) || ctx.mode != DT_BF16) return false;
   if (!g.A.kmajor || !g.B.kmajor || g.KB != 1 || g.atomic || g.splitk > 1 || g.ddt != DT_BF16) return false;
-  if (g.act != ACT_NONE || g.mask || g.R2 || g.bias_m || g.r1_m || g.r1_n || g.alpha_ptr || g.alpha != 1.f || g.sm_scale || g.sm_dot) return false;
+  if ((g.act != ACT_NONE && g.act != ACT_RELU) || g.mask || g.R2 || g.bias_m || g.r1_m || g.r1_n || g.alpha_ptr || g.alpha != 1.f || g.sm_scale || g.sm_dot) return false;
   if (g.bias_n_bs != 0 || (g.R && (g.rdt != DT_BF16 || g.beta != 1.f))) return false;
   if (g.M < 8 || g.N < 8 || g.K < 8 || g.K % 8 || g.N % 8) return false;
   if (!al16(g.A.p) || !al16(g.B.p) || !al16(g.D) || g.A.ld % 8 || g.B.ld % 8 || g.ldd % 8 || g.A.bs % 8 || g.B.bs % 8 || g.dbs % 8) return false;
   if (g.R && (!al16(g.R) || g.ldr % 8 || g.rbs % 8)) return false;
   if (g.A.kbs || g.B.kbs) return false;
-  const bool frames = fx.a_pro == APRO_MASKSCALE || fx.epi == EPI_XCBWD;
+  const bool frames = fx.a_pro == APRO_MASKSCALE || fx.epi == EPI_XCBWD || fx.epi == EPI_COLSUM;
   if (frames) {
     if (fx.rpf < 32 || g.batch != 1 || g.M % fx.rpf) return false;          // a 32-row block touches <= 2 frames; whole frames
     if ((unsigned long long)g.M * (unsigned long long)fx.rpf >= 0x100000000ULL) return false;    // frame split by multiply-high
@@ -451,6 +485,8 @@ bool gemm_fx_supported(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
     if (fx.a_store && !al16(fx.a_store)) return false;
     if (fx.a_store == g.A.p && g.N > FX_BN[fx_cfg(g)]) return false;                // in place only when ONE n-tile reads every A element
   }
+  if (fx.epi == EPI_COLSTATS && (!fx.e_acc || !fx.e_acc2 || fx.a_pro != APRO_NONE || g.R)) return false;
+  if (fx.epi == EPI_COLSUM && (!fx.e_acc || !fx.e_acc2 || fx.e_ld < g.N || fx.a_pro != APRO_NONE || g.R)) return false;
   if (fx.epi == EPI_XCBWD) {
     if (!g.R || g.ldr != g.ldd || g.rbs != g.dbs || !fx.e_cs || !fx.e_x || !fx.e_acc || !al16(fx.e_x) || !al16(fx.e_cs) || fx.e_ld % 4 || fx.e_ld < g.N) return false;
   }
@@ -471,7 +507,7 @@ void gemm_fx(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
   k.A = (const char*)g.A.p; k.lda = g.A.ld; k.a_bs = g.A.bs;
   k.B = (const char*)g.B.p; k.ldb = g.B.ld; k.b_bs = g.B.bs;
   k.D = (char*)g.D; k.ldd = g.ldd; k.dbs = g.dbs;
-  k.bias_n = g.bias_n;
+  k.bias_n = g.bias_n; k.act = g.act;
   k.R = (const char*)g.R; k.ldr = g.ldr; k.rbs = g.rbs;
   k.rpf = fx.rpf > 0 ? fx.rpf : g.M;
   k.nframes = fx.rpf > 0 ? g.M / fx.rpf : 1;
@@ -483,7 +519,7 @@ void gemm_fx(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
   k.a2 = (const char*)fx.a2; k.bn_mean = fx.bn_mean; k.bn_rstd = fx.bn_rstd; k.bn_sc = fx.bn_sc; k.bn_sh = fx.bn_sh; k.bn_sums = fx.bn_sums;
   k.bn_inv = fx.bn_rows > 0 ? 1.f / (float)fx.bn_rows : 0.f; k.bn_C = fx.bn_C; k.bn_relu = fx.bn_relu; k.bn_training = fx.bn_training;
   k.a_store = (char*)fx.a_store;
-  k.e_cs = fx.e_cs; k.e_x = (const char*)fx.e_x; k.e_acc = fx.e_acc; k.e_ld = fx.e_ld;
+  k.e_cs = fx.e_cs; k.e_x = (const char*)fx.e_x; k.e_acc = fx.e_acc; k.e_ld = fx.e_ld; k.e_acc2 = fx.e_acc2; k.e_scale = fx.e_scale;
   const dim3 grid((unsigned)(k.tiles_m * k.tiles_n * g.batch));
   hipStream_t s = (hipStream_t)ctx.stream;
   GemmProfShape shp{g.M, g.N, g.K, 1, g.batch, 1, 20 + cfg, 1, 1, 0, 1, 0.0};

@@ -429,13 +429,19 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       vq1sum_fwd(ctx, b.S(s.X1), b.W(DGSCT_P_WV1), b.F(DGSCT_P_BV1), B, N, C, invN, b.S<float>(s.mvq1),
                  vq1fuse_mode(-1) == 2 ? b.S(s.vq1) : nullptr);
     } else {
+      bool vq1_summed = false;
       Gemm g3 = mk((int)R, C, C);                                // vq1 = relu(X1 Wv1^T + b)
       g3.A = km(b.S(s.X1), C); g3.B = km(b.W(DGSCT_P_WV1), C); g3.bias_n = b.F(DGSCT_P_BV1); g3.act = ACT_RELU;
       outE(g3, b.S(s.vq1), E, C);
       if (fp8) gemm_fp8(ctx, (int)R, C, C, b.S(s.X1), C, b.prep + prep_w8[1], (const float*)(b.prep + prep_w8scale) + 1, b.F(DGSCT_P_BV1), 1, b.S(s.vq1), C);
-      else if (!(SK & 1024)) gemm(ctx, g3);
+      else {
+        // (round 5) the per-frame column sums (mean_N vq1) and positive counts in the product's epilogue: no second pass over vq1
+        GemmFx fv; fv.epi = EPI_COLSUM; fv.rpf = N; fv.e_acc = b.S<float>(s.mvq1); fv.e_acc2 = b.S<float>(s.cnt1); fv.e_ld = C; fv.e_scale = invN;
+        if ((gemmfx_mode(-1) & 64) && gemm_fx_supported(ctx, g3, fv)) { if (!(SK & 1024)) gemm_fx(ctx, g3, fv); vq1_summed = true; }
+        else if (!(SK & 1024)) gemm(ctx, g3);
+      }
       // mean_N vq1, and the number of positive entries per (frame, channel) for the backward (same pass over vq1)
-      if (!(SK & 64)) colsum_batched_pos(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C, b.S<float>(s.cnt1), C);
+      if (!vq1_summed && !(SK & 64)) colsum_batched_pos(ctx, b.S(s.vq1), C, (long)N * C, B, N, C, nullptr, 0, invN, b.S<float>(s.mvq1), C, b.S<float>(s.cnt1), C);
     }
     stream_join(ctx);                                            // aq1 / aq2 / a from the aux stream
     if (skinny_fused_supported(ctx, B, dd, C, 0)) {              // q = relu(m1 Wb^T + b), m1 = aq1 * mean_N vq1 made (and stored) on the way in
@@ -505,6 +511,7 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     // dimensions -> vector-unit row kernels (prims_proj.hip) instead of 80 %-padded MFMA tiles
     const bool vproj = gproj_supported(ctx.mode, C, ds, g);
     const long cgl = C / g, dgl = ds / g;
+    bool stats1_done = false, stats2_done = false;
     if (fuse89 || gfuse) {
     } else if (vproj) {
       gproj_narrow(ctx, b.S(s.X3), R, C, ds, g, b.F(DGSCT_P_WD), dgl * cgl, cgl, 1, b.S(s.Zp));     // Zp = X3 (x)_g Wd
@@ -513,10 +520,14 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       g1.A = km(b.S(s.X3), C, C / g);
       g1.B = km(b.W(DGSCT_P_WD), C / g, (long)(ds / g) * (C / g));
       outE(g1, b.S(s.Zp), E, ds, ds / g);
-      if (!(SK & 4096)) gemm(ctx, g1);
+      GemmFx f1s; f1s.epi = EPI_COLSTATS; f1s.e_acc = b.S<float>(s.bnacc1) + ds; f1s.e_acc2 = b.S<float>(s.bnacc1) + 2 * ds;
+      if (d.use_bn && d.training && (gemmfx_mode(-1) & 128) && gemm_fx_supported(ctx, g1, f1s)) {       // BN1 sums in the epilogue
+        if (!(SK & 4096)) gemm_fx(ctx, g1, f1s);
+        stats1_done = true;
+      } else if (!(SK & 4096)) gemm(ctx, g1);
     }
     if (d.use_bn) {                                              // BN1: finalised inside the pass that applies it (BnFin)
-      if (d.training && !fuse89 && !gfuse && !(SK & 32)) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
+      if (d.training && !fuse89 && !gfuse && !stats1_done && !(SK & 32)) bn_stats(ctx, b.S(s.Zp), R, ds, b.S<float>(s.bnacc1));
       const BnFin f1{b.S<float>(s.bnacc1), R, b.F(DGSCT_P_BN1_W), b.F(DGSCT_P_BN1_B), b.Fm(DGSCT_P_BN1_RM), b.Fm(DGSCT_P_BN1_RV),
                      d.bn_momentum, d.eps, d.training, bn1, bn1 + ds, bn1 + 2 * ds, bn1 + 3 * ds};
       if (!(SK & 32)) affine_act_bn(ctx, b.S(s.Zp), b.S(s.Z), R, ds, f1, 1);
@@ -531,9 +542,13 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
       g2.A = km(b.S(s.Z), ds, ds / g);
       g2.B = km(b.W(DGSCT_P_WU), ds / g, (long)(C / g) * (ds / g));
       outE(g2, b.S(s.Op), E, C, C / g);
-      if (!(SK & 4096)) gemm(ctx, g2);
+      GemmFx f2s; f2s.epi = EPI_COLSTATS; f2s.e_acc = b.S<float>(s.bnacc2) + C; f2s.e_acc2 = b.S<float>(s.bnacc2) + 2 * C;
+      if (stats2 && (gemmfx_mode(-1) & 128) && gemm_fx_supported(ctx, g2, f2s)) {                       // BN2 sums in the epilogue
+        if (!(SK & 4096)) gemm_fx(ctx, g2, f2s);
+        stats2_done = true;
+      } else if (!(SK & 4096)) gemm(ctx, g2);
     }
-    if (d.use_bn && stats2 && !vproj && !(SK & 32)) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
+    if (d.use_bn && stats2 && !vproj && !stats2_done && !(SK & 32)) bn_stats(ctx, b.S(s.Op), R, C, b.S<float>(s.bnacc2));
   }
   // F11 ---- BN2 finalised + applied, ln_post / gate                     :668-671
   const BnFin f2{b.S<float>(s.bnacc2), R, b.F(DGSCT_P_BN2_W), b.F(DGSCT_P_BN2_B), b.Fm(DGSCT_P_BN2_RM), b.Fm(DGSCT_P_BN2_RV),

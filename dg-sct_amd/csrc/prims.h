@@ -99,8 +99,12 @@ void gemm(const Ctx&, const Gemm&);
 //   a_store (optional): A' is written once, laid out like A (may BE A when every A element feeds one output tile only: N <= the tile width)
 //   epi = EPI_XCBWD (xc_bwd, net_trans.py:598 autograd):   v = E(acc);  D = R + v * (1 + e_cs[frame][n]);  e_acc[frame][n] += sum_m v * e_x[m][n]
 //   (e_x: E [M][ldd] like D;  e_cs / e_acc: fp32 [frames][e_ld])
+//   epi = EPI_COLSTATS (bn_stats of the output, net_trans.py:636 / 643):  v = E(act(acc + bias));  D = v;  channel c = b * N + n (b: batch = group):
+//       e_acc[c] += sum_m v,  e_acc2[c] += sum_m v^2     (the BatchNorm sums with shift 0: bn_stats' accumulators [shift | sum | sum of squares])
+//   epi = EPI_COLSUM (colsum_batched_pos of the output, net_trans.py:594-595):  v = E(act(acc + bias));  D = v;
+//       e_acc[frame][n] += e_scale * sum_m v,  e_acc2[frame][n] += #{m: v > 0}
 enum APro : int { APRO_NONE = 0, APRO_MASKSCALE = 1, APRO_BNBWD = 2 };
-enum FxEpi : int { EPI_NONE = 0, EPI_XCBWD = 1 };
+enum FxEpi : int { EPI_NONE = 0, EPI_XCBWD = 1, EPI_COLSTATS = 2, EPI_COLSUM = 3 };
 struct GemmFx {
   int a_pro = APRO_NONE, epi = EPI_NONE, rpf = 0;
   const float* a_rs = nullptr; const void* a_cs = nullptr; int a_cs_dt = DT_F32; long a_cs_ld = 0; const float* a_cs2 = nullptr; float a_scale = 1.f;
@@ -108,6 +112,7 @@ struct GemmFx {
   const float* bn_sums = nullptr; long bn_rows = 0; int bn_C = 0, bn_relu = 0, bn_training = 1;
   void* a_store = nullptr;
   const float* e_cs = nullptr; const void* e_x = nullptr; float* e_acc = nullptr; long e_ld = 0;
+  float* e_acc2 = nullptr; float e_scale = 1.f;
 };
 // plain D = A' B^T (+ bias_n, + R) in E; g carries the operands / output as for gemm()
 bool gemm_fx_supported(const Ctx&, const Gemm&, const GemmFx&);

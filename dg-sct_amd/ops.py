@@ -158,34 +158,33 @@ def release_workspaces():
 DEFER_AUX_JOIN = os.environ.get("DGSCT_DEFER_AUX", "1") != "0"
 _PENDING: Dict[Tuple, Tuple] = {}          # (device index, stream) -> (event on aux, tensors kept alive)
 _SLOT: Dict[Tuple, int] = {}
-_CB = threading.local()
 
 
 def drain_aux(device: Optional[torch.device] = None):
-    """Order the CURRENT stream (and each producing stream) after every weight-gradient stream that still has work in flight."""
+    """Order the CURRENT stream -- and each stream whose backward calls deferred their join -- after every weight-gradient stream that
+    still has work in flight.  Cheap when nothing is pending."""
+    if not _PENDING:
+        return
+    want = None if device is None else (device.index if device.index is not None else torch.cuda.current_device())
     with _WS_LOCK:
-        items = [(k, v) for k, v in _PENDING.items() if device is None or k[0] == (device.index if device.index is not None else torch.cuda.current_device())]
+        items = [(k, v) for k, v in _PENDING.items() if want is None or k[0] == want]
         for k, _ in items:
             del _PENDING[k]
     for (dev, stream), (ev, keep) in items:
         torch.cuda.current_stream(dev).wait_event(ev)
-        torch.cuda.ExternalStream(stream, device=torch.device("cuda", dev)).wait_event(ev) if stream else None
+        prod = torch.cuda.ExternalStream(stream, device=torch.device("cuda", dev)) if stream else torch.cuda.default_stream(dev)
+        prod.wait_event(ev)
         del keep
 
 
 def _queue_drain():
-    """once per backward pass: drain when the autograd engine has run its last node (on the thread that called backward())"""
-    if getattr(_CB, "queued", False):
-        return
-
-    def cb():
-        _CB.queued = False
-        drain_aux()
-
+    """drain_aux() when the autograd engine has run the last node of this backward pass.  Queued by EVERY deferring call: backward nodes
+    run on the engine's per-device worker threads and the callbacks on whichever thread finishes the graph task, so a once-per-pass
+    flag cannot live in thread-local storage; a drain that finds nothing pending costs a dictionary lookup.  The engine runs final
+    callbacks on the stream that was current around the user's backward() call, which is the stream that reads the gradients next."""
     try:
-        torch.autograd.Variable._execution_engine.queue_callback(cb)
-        _CB.queued = True
-    except RuntimeError:                   # not inside a backward pass (raw calls): the caller drains
+        torch.autograd.Variable._execution_engine.queue_callback(drain_aux)
+    except RuntimeError:                   # not inside a backward pass (raw calls from tests / tools): the caller drains
         pass
 
 

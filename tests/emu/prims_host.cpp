@@ -256,11 +256,11 @@ void colsum_batched_pos(const Ctx& ctx, const void* x, long ldx, long bs, int B,
 }
 
 // ---- fused GEMM hooks (csrc/gemm_fx.hip): the same math in host loops, either element type, either B layout ------------------------
-static int g_gemmfx = 31;      // (all call sites, prologues at every width: the host loops have no tile economics)
-int gemmfx_mode(int set) { const int old = g_gemmfx; if (set >= 0) g_gemmfx = set & 63; return old; }
+static int g_gemmfx = 31 + 64 + 128;      // (all call sites, prologues at every width: the host loops have no tile economics)
+int gemmfx_mode(int set) { const int old = g_gemmfx; if (set >= 0) g_gemmfx = set & 255; return old; }
 bool gemm_fx_supported(const Ctx&, const Gemm& g, const GemmFx& fx) {
   if (!g_gemmfx || !g.A.kmajor || g.KB != 1 || g.atomic) return false;
-  const bool frames = fx.a_pro == APRO_MASKSCALE || fx.epi == EPI_XCBWD;
+  const bool frames = fx.a_pro == APRO_MASKSCALE || fx.epi == EPI_XCBWD || fx.epi == EPI_COLSUM;
   if (frames && (fx.rpf <= 0 || g.batch != 1 || g.M % fx.rpf)) return false;
   return true;
 }
@@ -306,7 +306,18 @@ void gemm_fx(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
           acc += (double)Ap[((size_t)b * g.M + m) * g.K + k] * (double)ld(g.B.p, E, bo);
         }
         float v = (float)acc + (g.bias_n ? g.bias_n[n] : 0.f);
+        if (g.act == ACT_RELU) v = std::max(v, 0.f);
         const long o = (long)b * g.dbs + (long)m * g.ldd + n;
+        if (fx.epi == EPI_COLSTATS) {
+          const float vr = rnd(v);
+          fx.e_acc[(long)b * g.N + n] += vr;
+          fx.e_acc2[(long)b * g.N + n] += vr * vr;
+        } else if (fx.epi == EPI_COLSUM) {
+          const int f = m / fx.rpf;
+          const float vr = rnd(v);
+          fx.e_acc[(long)f * fx.e_ld + n] += fx.e_scale * vr;
+          if (vr > 0.f) fx.e_acc2[(long)f * fx.e_ld + n] += 1.f;
+        }
         if (fx.epi == EPI_XCBWD) {
           const int f = m / fx.rpf;
           const float vr = rnd(v);

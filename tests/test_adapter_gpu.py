@@ -504,6 +504,10 @@ def test_stack_on_gpu_matches_reference_fixture(flat):
         bad += [(f"map{i}", fp32_err(maps[i], fx["maps"][i])) for i in (0, 1) if not fp32_err(maps[i], fx["maps"][i]) < TOL_F32]
         torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
                                 [g.to(DEV) for pr in fx["cots"] for g in pr] + [fx["mcots"][0].to(DEV), fx["mcots"][1].to(DEV)])
+        # the flat path defers the join of the weight-gradient streams (ops.DEFER_AUX_JOIN): by the time backward() returns, the
+        # end-of-backward callback must have ordered this stream behind every one of them -- in EVERY pass (a once-per-pass flag
+        # kept in thread-local storage drained the first pass only: backward nodes run on the engine's worker threads)
+        assert not ops._PENDING, (rep, list(ops._PENDING))
         torch.cuda.synchronize()
         for i, ((fv, fa), (gv, ga)) in enumerate(zip(feats, fx["dfeats"])):
             bad += [(f"dfeat{i}{m}", fp32_err(a.grad, b)) for m, a, b in (("v", fv, gv), ("a", fa, ga)) if not fp32_err(a.grad, b) < TOL_F32]

@@ -579,7 +579,7 @@ def test_fused_gemm_hooks_equal_the_launches_they_replace(shape, BT, masks):
     dMap = torch.randn(BT, N, generator=gen).to(DEV)
     res = {}
     old = lib.test_tune("gemmfx", -1)
-    assert old == 15
+    assert old == 15 + 64 + 128                # (64 / 128: the forward sites, exercised by the test below)
     # ONE forward (it does not depend on the switch; two forwards differ in the last bits of their atomically summed batch statistics),
     # every backward on its own copy of the saved activations (the separate launches overwrite vq1 / vq2 in place)
     params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
@@ -603,3 +603,44 @@ def test_fused_gemm_hooks_equal_the_launches_they_replace(shape, BT, masks):
             if ga is None or gb.float().norm() == 0 or name in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias", "gate", "gate_av"):
                 continue
             assert _l2(ga, gb) < 8e-3, (mode, name, _l2(ga, gb))
+
+
+@pytest.mark.parametrize("shape,BT", [((576, 256, 1024, 192), 10), ((144, 512, 256, 384), 20), ((256, 384, 144, 512), 20), ((36, 1024, 64, 768), 20),
+                                      ((64, 768, 36, 1024), 10), ((144, 512, 256, 384), 160)])
+def test_forward_gemm_epilogues_equal_the_reductions_they_replace(shape, BT):
+    """round 5, csrc/gemm_fx.hip forward sites: vq1 = relu(X1 Wv1^T + b) with its per-frame column sums (mean_N vq1) and positive
+    counts in the product's epilogue ("gemmfx" bit 64: no colsum pass), and the two bottleneck products with their BatchNorm sums in
+    the epilogue (bit 128: no bn_stats passes; sums of the values as stored, shift 0 instead of row 0) -- against the separate
+    reductions on the same inputs: the per-frame means, the counts (exact), the BatchNorm statistics and the outputs."""
+    N, C, No, Co = shape
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS["ave"]})
+    p = O.random_params(cfg, "ave", seed=13, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(31)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    res = {}
+    old = lib.test_tune("gemmfx", -1)
+    try:
+        for mode in (15, 15 + 64 + 128):
+            lib.test_tune("gemmfx", mode)
+            params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+            prep = ops.prepare(lib, spec, params, dtype, DEV)
+            out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+            torch.cuda.synchronize()
+            regs = lib.saved_regions(d)
+            grab = lambda nm, n: saved[regs[nm][0]:regs[nm][0] + 4 * n].view(torch.float32).clone()
+            ds = C // 8
+            res[mode] = dict(out=out.float(), map=amap.clone(), mvq1=grab("mvq1", BT * C), cnt1=grab("cnt1", BT * C), bn1=grab("bn1", 4 * ds),
+                             bn2=grab("bn2", 4 * C), rm2=params[PARAM_NAMES.index("bn2.running_mean")].clone(),
+                             rv1=params[PARAM_NAMES.index("bn1.running_var")].clone())
+    finally:
+        lib.test_tune("gemmfx", old)
+    a, b = res[15], res[15 + 64 + 128]
+    assert torch.equal(a["cnt1"], b["cnt1"])                                       # same product bits, same ReLU decisions: exact counts
+    assert _l2(b["mvq1"], a["mvq1"]) < 1e-5, _l2(b["mvq1"], a["mvq1"])            # fp32 sums of the same bf16 values, another order
+    for k in ("bn1", "bn2", "rm2", "rv1"):
+        assert _l2(b[k], a[k]) < 2e-4, (k, _l2(b[k], a[k]))                      # (mean | rstd | scale | shift) from sums with another shift
+    assert _l2(b["out"], a["out"]) < 4e-3 and _l2(b["map"], a["map"]) < 1e-3, (_l2(b["out"], a["out"]), _l2(b["map"], a["map"]))
