@@ -297,6 +297,7 @@ void gemm_fx(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
     for (int b = 0; b < g.batch; ++b)
       for (int m = 0; m < g.M; ++m)
         for (int k = 0; k < g.K; ++k) st(fx.a_store, E, (long)b * g.A.bs + (long)m * g.A.ld + k, Ap[((size_t)b * g.M + m) * g.K + k]);
+  std::vector<double> cs1(fx.epi == EPI_COLSTATS ? (size_t)g.batch * g.N : 0, 0.0), cs2(cs1.size(), 0.0);
   for (int b = 0; b < g.batch; ++b)
     for (int m = 0; m < g.M; ++m)
       for (int n = 0; n < g.N; ++n) {
@@ -309,9 +310,9 @@ void gemm_fx(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
         if (g.act == ACT_RELU) v = std::max(v, 0.f);
         const long o = (long)b * g.dbs + (long)m * g.ldd + n;
         if (fx.epi == EPI_COLSTATS) {
-          const float vr = rnd(v);
-          fx.e_acc[(long)b * g.N + n] += vr;
-          fx.e_acc2[(long)b * g.N + n] += vr * vr;
+          const double vr = rnd(v);                       // (double partial sums: the host loops are the ideal evaluation of the schedule)
+          cs1[(size_t)b * g.N + n] += vr;
+          cs2[(size_t)b * g.N + n] += vr * vr;
         } else if (fx.epi == EPI_COLSUM) {
           const int f = m / fx.rpf;
           const float vr = rnd(v);
@@ -328,6 +329,7 @@ void gemm_fx(const Ctx& ctx, const Gemm& g, const GemmFx& fx) {
         }
         st(g.D, g.ddt, o, v);
       }
+  for (size_t i = 0; i < cs1.size(); ++i) { fx.e_acc[i] += (float)cs1[i]; fx.e_acc2[i] += (float)cs2[i]; }
 }
 
 void rowdot_batched(const Ctx& ctx, const void* x, long ldx, long bs, int B, int N, int C, const void* w, int wdt, long w_bs,
