@@ -388,6 +388,7 @@ class _AdapterFlatFn(torch.autograd.Function):
         ctx.lib, ctx.spec, ctx.desc, ctx.prep, ctx.plist = lib, spec, d, prep, plist
         ctx.skip, ctx.has_res = bool(skip), res is not None
         ctx.saved_buf = saved
+        ctx.flat = flat
         ctx.save_for_backward(X, Y)
         ctx.set_materialize_grads(False)
         if tmap is None:
@@ -400,6 +401,13 @@ class _AdapterFlatFn(torch.autograd.Function):
             raise RuntimeError("dg-sct_amd: backward through an adapter call twice is not supported "
                                "(the saved-activation buffer is consumed in place)")
         X, Y = ctx.saved_tensors
+        # The join of the weight-gradient stream is deferred only when autograd will ADOPT the returned buffer untouched: the
+        # parameter has no gradient yet (else AccumulateGrad adds the new one into it on this stream, right now) and no tensor
+        # hook wants to see it.  Gradient accumulation over several backward passes therefore joins from the second pass on.
+        flat = ctx.flat
+        can_defer = (isinstance(flat, torch.Tensor) and flat.is_leaf and flat.grad is None and not getattr(flat, "_backward_hooks", None))
+        # (a DataParallel replica's flat tensor is NOT a leaf: its gradient is consumed by the broadcast's backward at once)
+        ctx.flat = None
         spec = ctx.spec
         if dOut is None:
             dOut = torch.zeros_like(X)
@@ -409,7 +417,7 @@ class _AdapterFlatFn(torch.autograd.Function):
         dMap = dMap.contiguous().float() if dMap is not None else None
         dTm = dTmap.contiguous().float() if (spec.temporal and dTmap is not None and dTmap.numel()) else None
         dX, dY, gflat = raw_backward(ctx.lib, spec, ctx.desc, ctx.plist, ctx.prep, X, Y, ctx.saved_buf, dOut, dMap, dTm,
-                                     flat_out=True, skip_into_dx=ctx.skip, defer_join=True)
+                                     flat_out=True, skip_into_dx=ctx.skip, defer_join=can_defer)
         ctx.saved_buf = None
         return None, None, None, None, None, None, dOut if ctx.has_res else None, dX, dY, gflat
 

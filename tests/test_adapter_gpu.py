@@ -598,3 +598,32 @@ def test_deferred_aux_join_gives_the_joined_results():
     for (a0, b0, c0), (a1, b1, c1) in zip(res[False], res[True]):
         assert fp32_err(a1, a0) < 1e-4 and fp32_err(b1, b0) < 1e-4
         assert fp32_err(c1, c0) < 1e-3, fp32_err(c1, c0)
+
+
+def test_flat_gradients_accumulate_over_two_backward_passes():
+    """the deferred join (ops.DEFER_AUX_JOIN) must not reach gradient ACCUMULATION: from the second backward pass on, AccumulateGrad
+    adds the new flat gradient into the existing one on the calling stream right after the call, so the call has to join its
+    weight-gradient stream itself (ops._AdapterFlatFn: defers only while `flat.grad is None`).  Two passes without zero_grad on the
+    same inputs must give exactly twice the gradients of one."""
+    from dgsct_amd import AdapterStack
+    from dgsct_amd.stack import default_opt
+    fx = load_golden("stack_2stage")
+    grads = {}
+    for passes in (1, 2):
+        st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4), concurrent=True)
+        st.load_state_dict(fx["state0"])
+        st = st.to(DEV)
+        st.flatten_parameters()
+        st.train()
+        for _ in range(passes):
+            st.load_state_dict(fx["state0"])                      # same weights and BN buffers for every pass (keeps .grad)
+            feats = [(a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for a, b in fx["feats"]]
+            outs, maps = st(feats)
+            torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
+                                    [g.to(DEV) for pr in fx["cots"] for g in pr] + [fx["mcots"][0].to(DEV), fx["mcots"][1].to(DEV)])
+            assert not ops._PENDING
+        torch.cuda.synchronize()
+        grads[passes] = {n: m.flat_param.grad.clone() for n, m in st.named_modules() if hasattr(m, "flat_param")}
+    assert grads[1]
+    for n, g1 in grads[1].items():
+        assert fp32_err(grads[2][n], 2 * g1) < 1e-3, (n, fp32_err(grads[2][n], 2 * g1))
