@@ -29,7 +29,7 @@ import dgsct_amd  # noqa: E402
 from dgsct_amd import AdapterStack, GradAllReducer, ave_stage_shapes  # noqa: E402
 from dgsct_amd._lib import default_lib  # noqa: E402
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16_fp8": 2500.0}   # (fp8 products are priced at the bf16 peak: most of the path is bf16)      # dense, MI355X_MICROARCH.md
 
 
 def alg_flops_per_frame(stages, tk=32, r=8, g=2):
@@ -54,10 +54,10 @@ def alg_bytes_per_step(stages, BT, es=2):
     return tot
 
 
-def build_stack(backbone, dtype, device, concurrent=True):
+def build_stack(backbone, dtype, device, concurrent=True, fp8=False):
     torch.manual_seed(0)
     stages = ave_stage_shapes(backbone)
-    stack = AdapterStack(stages, compute_dtype=dtype, concurrent=concurrent).to(device)
+    stack = AdapterStack(stages, compute_dtype=dtype, concurrent=concurrent, fp8_projections=fp8).to(device)
     with torch.no_grad():              # BEFORE flattening: afterwards the per-name tensors are views, not parameters
         for n, p in stack.named_parameters():
             if n.endswith("gate") or n.endswith("gate_av"):
@@ -259,7 +259,9 @@ def main():
                     help="weak: --batch clips on EVERY GPU (the driver's default); strong: --batch is the GLOBAL batch (BASELINE's fixed "
                          "B=16), split over the ranks (must divide)")
     ap.add_argument("--backbone", default="swinv2_base", choices=["swinv2_base", "swinv2_large"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16_fp8"],
+                    help="bf16_fp8: bf16 storage with e4m3 MFMA operands for the three weight-stationary forward projections (BASELINE configs[4]); "
+                         "the backward products stay bf16 (a straight-through estimate, tests/test_fp8.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optim", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--no-roofline", action="store_true")
@@ -287,7 +289,8 @@ def main():
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
         from dgsct_amd import init_process_group
         init_process_group(device)       # "nccl" IS RCCL on ROCm (one process per GPU, bound to its device)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+    fp8 = args.dtype == "bf16_fp8"
     T = 10
     per_gpu_batch = args.batch
     if args.scaling == "strong":
@@ -296,7 +299,7 @@ def main():
         per_gpu_batch = args.batch // world                 # clips of the fixed global batch that land on this rank
     BT = per_gpu_batch * T
 
-    stages, stack = build_stack(args.backbone, dtype, device, concurrent=not args.serial)
+    stages, stack = build_stack(args.backbone, dtype, device, concurrent=not args.serial, fp8=fp8)
     stack.train()
     params = [p for p in stack.parameters() if p.requires_grad]
     if dp:
@@ -569,7 +572,7 @@ def main():
         line = dict(
             metric="adapter_fwd_bwd_clips_per_sec", value=round(clips_per_s, 2), unit="clips/s", n_gpus=world,
             steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling=args.scaling,
-            vs_baseline=None, dtype="bf16" if dtype == torch.bfloat16 else "f32", data="synthetic",
+            vs_baseline=None, dtype=("bf16_fp8" if fp8 else "bf16") if dtype == torch.bfloat16 else "f32", data="synthetic",
             config=dict(workload=f"AVE fine-tune adapter stack (BASELINE configs[1]): {args.backbone} + HTS-AT token/width "
                                  f"shapes, 48 DG-SCT adapters, B={per_gpu_batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on",
                         global_batch=per_gpu_batch * world, frames_per_clip=T, parallelism=f"dp{world}",

@@ -43,7 +43,8 @@ class AdapterStack(nn.Module):
     """4 x L adapters (audio/visual x p1/p2) in the reference's ModuleLists, plus the layer loop."""
 
     def __init__(self, stages: Sequence[Dict[str, int]], opt: Optional[SimpleNamespace] = None, flavour: str = "ave",
-                 compute_dtype: Optional[torch.dtype] = None, lib=None, concurrent: bool = True, fuse_residual: bool = True):
+                 compute_dtype: Optional[torch.dtype] = None, lib=None, concurrent: bool = True, fuse_residual: bool = True,
+                 fp8_projections: bool = False):
         super().__init__()
         self.concurrent = concurrent
         self.fuse_residual = fuse_residual        # `f = f + adapter(...)` inside the adapter's last kernel (8f row f2)
@@ -55,6 +56,8 @@ class AdapterStack(nn.Module):
             for _ in range(s["layers"]):
                 hidden.append(s["Cv"]); hidden_a.append(s["Ca"]); conv.append(s["Nv"]); conv_a.append(s["Na"])
         kw = dict(flavour=flavour, compute_dtype=compute_dtype, lib=lib)
+        if fp8_projections:                       # BASELINE configs[4]: e4m3 MFMA operands for fc / fc_affine_video_1 / fc_affine_video_2 (forward)
+            kw["fp8_projections"] = True
         if flavour in ("ave", "avvp", "pretrain"):
             kw["num_tk"] = o.num_tokens
 

@@ -138,8 +138,17 @@ def _groupmm_bwd(dy: Tensor, x: Tensor, w: Tensor, g: int):
 
 
 # ----------------------------------------------------------------------------- forward
+def _q8(x: Tensor, per_tensor: bool) -> Tensor:
+    """OCP e4m3 quantisation of one MFMA operand as the fp8 projections do it (csrc/gemm_fp8.hip; BASELINE configs[4]): weights with a
+    per-tensor scale max|w| / 448, activations converted directly (saturating at +-448).  Returns the DE-quantised fp32 values."""
+    if per_tensor:
+        sc = 448.0 / x.abs().max().clamp_min(1e-30)
+        return (x * sc).clamp(-448, 448).to(torch.float8_e4m3fn).float() / sc
+    return x.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
 def forward(p: Dict[str, Tensor], X: Tensor, Y: Tensor, cfg: AdapterConfig, training: bool = True,
-            update_running: bool = True) -> Tuple[Tensor, Tensor, Optional[Tensor], Dict[str, Tensor]]:
+            update_running: bool = True, fp8: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor], Dict[str, Tensor]]:
     """p: parameter/buffer dict keyed by the reference state_dict names (conv weights squeezed to
     2-D views is NOT required: 4-D [out,in,1,1] tensors are accepted).  Returns
     (out [BT,N,C], map [BT,N], tmap [BT] | None, saved-intermediates)."""
@@ -163,7 +172,10 @@ def forward(p: Dict[str, Tensor], X: Tensor, Y: Tensor, cfg: AdapterConfig, trai
     if order == "A":
         T1 = torch.einsum("mn,bnk->bmk", Wn, Y)                       # [B,N,Co]
         s["T1"] = T1
-        Yp = T1 @ Wc.t()
+        # (fp8: the three weight-stationary forward projections with e4m3 operands -- fc in this association, fc_affine_video_1 / 2;
+        #  the saved intermediates then carry that perturbation and backward() differentiates the UN-quantised graph at them, which is
+        #  what the device does: its backward products use the bf16 weights and activations)
+        Yp = (_q8(T1.bfloat16().float(), False) @ _q8(Wc, True).t()) if fp8 else T1 @ Wc.t()
     else:
         T2t = torch.einsum("ck,bnk->bcn", Wc, Y)                      # [B,C,No]  (= (Y Wc^T)^T)
         s["T2t"] = T2t
@@ -186,7 +198,10 @@ def forward(p: Dict[str, Tensor], X: Tensor, Y: Tensor, cfg: AdapterConfig, trai
     # F4-F6 channel gate ---------------------------------------------------------------- :593-598
     aq1 = F.relu(F.linear(a, p["fc_affine_audio_1.weight"], p["fc_affine_audio_1.bias"]))
     aq2 = F.relu(F.linear(a, p["fc_affine_audio_2.weight"], p["fc_affine_audio_2.bias"]))
-    vq1 = F.relu(F.linear(X1, p["fc_affine_video_1.weight"], p["fc_affine_video_1.bias"]))
+    if fp8:
+        vq1 = F.relu(_q8(X1.bfloat16().float(), False) @ _q8(p["fc_affine_video_1.weight"], True).t() + p["fc_affine_video_1.bias"])
+    else:
+        vq1 = F.relu(F.linear(X1, p["fc_affine_video_1.weight"], p["fc_affine_video_1.bias"]))
     mvq1 = vq1.mean(1)                                                # [B,C]
     m1 = aq1 * mvq1
     q = F.relu(F.linear(m1, p["fc_affine_bottleneck.weight"], p["fc_affine_bottleneck.bias"]))
@@ -194,7 +209,10 @@ def forward(p: Dict[str, Tensor], X: Tensor, Y: Tensor, cfg: AdapterConfig, trai
     s.update(aq1=aq1, aq2=aq2, vq1=vq1, mvq1=mvq1, m1=m1, q=q, ch=ch)
     # F7 spatial gate + map ------------------------------------------------------------- :601-608
     Xc = X1 * (1 + ch[:, None, :])
-    vq2 = F.relu(F.linear(Xc, p["fc_affine_video_2.weight"], p["fc_affine_video_2.bias"]))
+    if fp8:
+        vq2 = F.relu(_q8(Xc.bfloat16().float(), False) @ _q8(p["fc_affine_video_2.weight"], True).t() + p["fc_affine_video_2.bias"])
+    else:
+        vq2 = F.relu(F.linear(Xc, p["fc_affine_video_2.weight"], p["fc_affine_video_2.bias"]))
     ws, bs = p["fc_affine_v_s_att.weight"].reshape(-1), p["fc_affine_v_s_att.bias"]
     sl = (vq2 * (aq2 * ws)[:, None, :]).sum(-1) + bs                  # [B,N]
     sg = torch.sigmoid(sl)
@@ -574,11 +592,17 @@ def forward_autograd(p: Dict[str, Tensor], X: Tensor, Y: Tensor, cfg: AdapterCon
     X1 = X + p["gate_av"] * torch.bmm(torch.softmax(torch.bmm(X, tok.transpose(1, 2)), -1), tok)
     a = Yp.mean(1)
     aq1 = F.relu(F.linear(a, p["fc_affine_audio_1.weight"], p["fc_affine_audio_1.bias"])).unsqueeze(1)
-    vq1 = F.relu(F.linear(X1, p["fc_affine_video_1.weight"], p["fc_affine_video_1.bias"]))
+    if fp8:
+        vq1 = F.relu(_q8(X1.bfloat16().float(), False) @ _q8(p["fc_affine_video_1.weight"], True).t() + p["fc_affine_video_1.bias"])
+    else:
+        vq1 = F.relu(F.linear(X1, p["fc_affine_video_1.weight"], p["fc_affine_video_1.bias"]))
     q = F.relu(F.linear((aq1 * vq1).mean(1), p["fc_affine_bottleneck.weight"], p["fc_affine_bottleneck.bias"]))
     ch = torch.sigmoid(F.linear(q, p["fc_affine_v_c_att.weight"], p["fc_affine_v_c_att.bias"])).unsqueeze(1)
     Xc = X1 * (ch + 1)
-    vq2 = F.relu(F.linear(Xc, p["fc_affine_video_2.weight"], p["fc_affine_video_2.bias"]))
+    if fp8:
+        vq2 = F.relu(_q8(Xc.bfloat16().float(), False) @ _q8(p["fc_affine_video_2.weight"], True).t() + p["fc_affine_video_2.bias"])
+    else:
+        vq2 = F.relu(F.linear(Xc, p["fc_affine_video_2.weight"], p["fc_affine_video_2.bias"]))
     aq2 = F.relu(F.linear(a, p["fc_affine_audio_2.weight"], p["fc_affine_audio_2.bias"])).unsqueeze(1)
     sl = F.linear(vq2 * aq2, p["fc_affine_v_s_att.weight"], p["fc_affine_v_s_att.bias"])     # [B,N,1]
     amap = torch.softmax(torch.tanh(sl).transpose(1, 2), -1).squeeze(1)

@@ -122,3 +122,60 @@ def test_fp8_fixture_is_current():
     fx = torch.load(os.path.join(ROOT, "tests", "golden", "fp8_emu_ave_64x96.pt"))
     b = _case(Lib(build_emu()), torch.device("cpu"), *FP8_FIXTURE_SHAPE, flavour="ave")
     assert _l2(b["out"], fx["out"]) < 1e-6 and _l2(b["map"], fx["map"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,flavour,over", [((144, 768, 256, 384), "avqa", dict(use_gate=True)), ((256, 384, 144, 768), "avqa", dict(use_gate=False)),
+                                                ((36, 1536, 64, 768), "avqa", dict(use_gate=True)), ((2304, 192, 4096, 96), "avqa", dict(use_gate=True)),
+                                                ((144, 512, 256, 384), "ave", {}), ((576, 256, 1024, 192), "ave", {})])
+def test_fp8_backward_against_the_fp8_aware_oracle(shape, flavour, over):
+    """round 5 (g-1): the GRADIENTS of the fp8 path, not only their finiteness.  The device's backward differentiates the un-quantised
+    graph at the activations the e4m3 forward produced (bf16 operands in every backward product: a straight-through estimate).  The
+    oracle does exactly that when its forward quantises the operands of the same three projections (`O.forward(fp8=True)`: per-tensor
+    scale for the weights, saturating direct conversion for the activations, as csrc/gemm_fp8.hip) and its backward is fed the device's
+    ReLU decisions: what is left is the bf16 arithmetic of the backward, and the bounds are the bf16 ones of
+    tests/test_bf16_masked_gpu.py for dX (2 %) and 2.5 x its C-linear line for dY / the weight gradients (see below)."""
+    from helpers import device_relu_masks
+    from test_bf16_masked_gpu import bounds, RESIDUES
+    from dgsct_amd._lib import PARAM_NAMES
+    N, C, No, Co = shape
+    BT = 10
+    dev = torch.device("cuda:0")
+    lib = default_lib()
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour], **over})
+    p = O.random_params(cfg, flavour, seed=2, scale=0.577)
+    gen = torch.Generator().manual_seed(7)
+    rb = lambda t: t.bfloat16().float()
+    X, Y, dOut = rb(torch.randn(BT, N, C, generator=gen)), rb(torch.randn(BT, No, Co, generator=gen)), rb(torch.randn(BT, N, C, generator=gen))
+    dMap = torch.randn(BT, N, generator=gen)
+    spec = dataclasses.replace(spec_of(cfg), fp8=True)
+    params = param_table(p, spec, dev)
+    dt = torch.bfloat16
+    prep = ops.prepare(lib, spec, params, dt, dev)
+    Xd, Yd = X.to(dev, dt).contiguous(), Y.to(dev, dt).contiguous()
+    out, amap, _, saved, d = ops.raw_forward(lib, spec, params, prep, Xd, Yd, True)
+    torch.cuda.synchronize()
+    masks = device_relu_masks(lib, d, saved, spec, BT, dt)
+    dX, dY, grads = ops.raw_backward(lib, spec, d, params, prep, Xd, Yd, saved, dOut.to(dev, dt).contiguous(), dMap.to(dev), None)
+    torch.cuda.synchronize()
+    po = {k: v.clone() for k, v in p.items()}
+    out_o, map_o, _, s = O.forward(po, X, Y, cfg, training=True, fp8=True)
+    dX_o, dY_o, g_o = O.backward(po, s, cfg, dOut, dMap, None, training=True, masks=masks)
+    # forward against the fp8-AWARE oracle: bf16 storage error only (against the fp32 oracle the fp8 operands cost 1-3 %, tested above)
+    assert _l2(out, out_o) < 1.5e-2 and _l2(amap, map_o) < 5e-3, (_l2(out, out_o), _l2(amap, map_o))
+    bd = bounds(C, flavour, BT)
+    # Behind the un-scaled softmaxes the fp8 path is entitled to more than the bf16 one: device and oracle quantise T1 / X1 / Xc values that
+    # differ in their last bf16 bit, and a value near an e4m3 rounding boundary then takes the other code (a 6 % step for that element)
+    # -- measured 2.1-2.2 x the bf16 line at C <= 512, 1.0-1.5 x above; dX keeps the bf16 bound.
+    bd = dict(bd, dY=2.5 * bd["dY"], W=2.5 * bd["W"], V=2.5 * bd["V"])
+    bad = [(k, v, bd[k]) for k, v in (("dX", _l2(dX, dX_o)), ("dY", _l2(dY, dY_o))) if v > bd[k]]
+    for i, g in enumerate(grads):
+        name = PARAM_NAMES[i]
+        if g is None or name not in g_o or name in RESIDUES or g_o[name].float().norm() == 0:
+            continue
+        mat = g_o[name].dim() >= 2 and min(g_o[name].shape[:2]) > 1
+        e = _l2(g.reshape(-1), g_o[name].reshape(-1))
+        if e > (bd["W"] if mat else bd["V"]):
+            bad.append((name, e, bd["W"] if mat else bd["V"]))
+    print("FP8-MASKED", shape, flavour, {"out": round(_l2(out, out_o), 4), "dX": round(_l2(dX, dX_o), 4), "dY": round(_l2(dY, dY_o), 4)})
+    assert not bad, bad
