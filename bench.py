@@ -262,6 +262,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16_fp8"],
                     help="bf16_fp8: bf16 storage with e4m3 MFMA operands for the three weight-stationary forward projections (BASELINE configs[4]); "
                          "the backward products stay bf16 (a straight-through estimate, tests/test_fp8.py)")
+    ap.add_argument("--blocks", action="store_true", help="harness B (SURVEY.md 8d / row f4): the frozen Swin-V2 half-blocks and HTS-AT blocks "
+                    "(dgsct_amd/backbone.py, random-init, frozen, PyTorch-ROCm ops) inside the layer loop -- NOT the graded workload; the line "
+                    "says so in config.workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optim", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--no-roofline", action="store_true")
@@ -325,11 +328,15 @@ def main():
     phase_ev = []                          # (start, end-of-forward, end-of-backward) events of the timed steps (--phases)
     from dgsct_amd.train import StackTrainer
     trainer = StackTrainer(stack, opt, reducer)      # the step logic the gloo world-2 test drives (tests/test_host_cpu.py)
+    if args.blocks:
+        from dgsct_amd import FrozenBlocks
+        fb = FrozenBlocks(stages, dtype=dtype).to(device)
+        trainer.block_kwargs = dict(vis_block=fb.vis_block, aud_block=fb.aud_block)
 
     def fwd_bwd():
         if args.phases:
             e0 = torch.cuda.Event(enable_timing=True); e0.record()
-            outs, maps = stack(feats)
+            outs, maps = stack(feats, **getattr(trainer, "block_kwargs", {}))
             e1 = torch.cuda.Event(enable_timing=True); e1.record()
             torch.autograd.backward([t for pair in outs for t in pair] + [maps[0], maps[1]],
                                     [g for pair in cots for g in pair] + [mcots[0], mcots[1]])
@@ -574,7 +581,9 @@ def main():
             steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling=args.scaling,
             vs_baseline=None, dtype=("bf16_fp8" if fp8 else "bf16") if dtype == torch.bfloat16 else "f32", data="synthetic",
             config=dict(workload=f"AVE fine-tune adapter stack (BASELINE configs[1]): {args.backbone} + HTS-AT token/width "
-                                 f"shapes, 48 DG-SCT adapters, B={per_gpu_batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on",
+                                 f"shapes, 48 DG-SCT adapters, B={per_gpu_batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on" +
+                                 (" + HARNESS B: the 12 frozen Swin-V2 blocks / HTS-AT blocks beside the adapter positions in the loop (not the graded workload)"
+                                  if args.blocks else ""),
                         global_batch=per_gpu_batch * world, frames_per_clip=T, parallelism=f"dp{world}",
                         step="fwd+bwd" + ("+allreduce" if dp else "") + ("" if args.no_optim else "+adam"),
                         streams=1 if args.serial else 2, hip_graph=use_graph, host_enqueue_ms_per_step=round(host_s / args.steps * 1e3, 2),

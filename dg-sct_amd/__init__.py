@@ -9,3 +9,4 @@ from .adapter import VisualAdapter, bicubic_matrix                 # noqa: F401
 from .stack import AdapterStack, ave_stage_shapes                  # noqa: F401
 from .dp import GradAllReducer, init_process_group                 # noqa: F401
 from .temporal import TemporalAttention, TemporalAttentionAVS, TemporalAttentionAVVP, frame_scale   # noqa: F401
+from .backbone import FrozenBlocks, HTSATBlock, SwinV2Block         # noqa: F401

@@ -91,7 +91,7 @@ class StackTrainer:
         self.it = 0
 
     def fwd_bwd(self, feats, cots=None, mcots=None, loss_fn=None):
-        outs, maps = self.stack(feats)
+        outs, maps = self.stack(feats, **getattr(self, "block_kwargs", {}))      # (vis_block= / aud_block=: frozen backbone blocks, backbone.py)
         if loss_fn is not None:
             loss_fn(outs, maps).backward()
         else:
