@@ -357,6 +357,10 @@ struct XB2Args {
   unsigned short* dX; const unsigned short* R2; float* dtok; float* dgate;
 };
 static bool xattn_bwd3_launch(const Ctx& ctx, XB2Args a, int B);
+// KEEPX (round 5; C <= 128, one slab per row block: the stage-0 shapes): the X slab and the dX1 slab are requested TOGETHER up front and
+// the X slab stays in registers for the second half -- one exposed global round trip per row block instead of three (X, then dX1, then
+// the L2-hot re-read of X).
+template <bool KEEPX>
 __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * (IMG2 + 2 * 32 * PP2)];
   __shared__ float dgs[4];
@@ -379,7 +383,20 @@ __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
   f32x16 aS, aU;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { aS[r] = 0.f; aU[r] = 0.f; }
-  Slab s;
+  Slab s, sx;
+  if constexpr (KEEPX) {
+    const int kc = (p.C < CS2 ? p.C : CS2) / 16;
+    slab_load(sx, Xg, C, rows, 0, p.C, lane);
+    slab_load(s, Gg, C, rows, 0, p.C, lane);
+    wave_sync();
+    slab_store_lds(sx, img, rows, 0, p.C, lane);
+    wave_sync();
+    logits_slab<true>(aS, hiF, loF, 0, kc, img, lane);
+    wave_sync();
+    slab_store_lds(s, img, rows, 0, p.C, lane);
+    wave_sync();
+    logits_slab<true>(aU, hiF, loF, 0, kc, img, lane);
+  } else {
   slab_load(s, Xg, C, rows, 0, p.C, lane);
   for (int si = 0; si < 2 * nsl; ++si) {                         // X slabs (logits), then dX1 slabs (U = dX1 . tok^T)
     const bool second = si >= nsl;
@@ -391,6 +408,7 @@ __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
     else if (nsl > 1) slab_load(s, Gg, C, rows, 0, p.C, lane);
     if (!second) logits_slab<true>(aS, hiF, loF, c0, kc, img, lane);
     else logits_slab<true>(aU, hiF, loF, c0, kc, img, lane);
+  }
   }
   softmax_regs(aS, p.tk, lane);
   float dot = 0.f;
@@ -415,7 +433,7 @@ __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
   for (int si = 0; si < nsl; ++si) {
     const int c0 = si * CS2, nt = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 32;
     if (nsl > 1) { wave_sync(); slab_store_lds(s, img, rows, c0, p.C, lane); }
-    slab_load(s, Xg, C, rows, c0, p.C, lane);                     // X slab for the second half of this iteration (L2-hot re-read)
+    if constexpr (!KEEPX) slab_load(s, Xg, C, rows, c0, p.C, lane);   // X slab for the second half of this iteration (L2-hot re-read)
     __syncthreads();                                              // dX1 slab images + P / dS images of all 4 waves visible
     f32x16 a1, a2;
 #pragma unroll
@@ -442,7 +460,8 @@ __global__ __launch_bounds__(256) void xattn_bwd2_k(const XB2Args p) {
     wave_sync();
     if (active) slab_copy_out(img, p.dX + ((long)b * p.N + n0) * C, p.R2 ? p.R2 + ((long)b * p.N + n0) * C : nullptr, C, rows, c0, p.C, lane);
     wave_sync();
-    slab_store_lds(s, img, active ? rows : 0, c0, p.C, lane);     // X slab
+    if constexpr (KEEPX) slab_store_lds(sx, img, active ? rows : 0, c0, p.C, lane);     // X slab (still in registers)
+    else slab_store_lds(s, img, active ? rows : 0, c0, p.C, lane);
     if (si + 1 < nsl) slab_load(s, Gg, C, rows, c0 + CS2, p.C, lane);
     __syncthreads();
     if (wave < nt) {
@@ -461,7 +480,9 @@ void xattn_bwd2(const Ctx& ctx, const void* X, const void* dX1, const void* tokp
   XB2Args a{(const unsigned short*)X, (const unsigned short*)dX1, (const unsigned short*)tokpk, gate_av, N, C, tk, wpf,
             (unsigned short*)dX, (const unsigned short*)R2, dtok, dgate};
   if (xattn_bwd3_launch(ctx, a, B)) return;
-  hipLaunchKernelGGL(xattn_bwd2_k, dim3(B * wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
+  static const bool nokeep = getenv("DGSCT_ATTN_NOKEEPX") != nullptr;
+  if (C <= CS2 && !nokeep) hipLaunchKernelGGL(xattn_bwd2_k<true>, dim3(B * wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
+  else hipLaunchKernelGGL(xattn_bwd2_k<false>, dim3(B * wpf), dim3(256), 0, (hipStream_t)ctx.stream, a);
 }
 
 // ---- tokattn_bwd ----------------------------------------------------------------------------------------------------
