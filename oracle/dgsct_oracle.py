@@ -592,17 +592,11 @@ def forward_autograd(p: Dict[str, Tensor], X: Tensor, Y: Tensor, cfg: AdapterCon
     X1 = X + p["gate_av"] * torch.bmm(torch.softmax(torch.bmm(X, tok.transpose(1, 2)), -1), tok)
     a = Yp.mean(1)
     aq1 = F.relu(F.linear(a, p["fc_affine_audio_1.weight"], p["fc_affine_audio_1.bias"])).unsqueeze(1)
-    if fp8:
-        vq1 = F.relu(_q8(X1.bfloat16().float(), False) @ _q8(p["fc_affine_video_1.weight"], True).t() + p["fc_affine_video_1.bias"])
-    else:
-        vq1 = F.relu(F.linear(X1, p["fc_affine_video_1.weight"], p["fc_affine_video_1.bias"]))
+    vq1 = F.relu(F.linear(X1, p["fc_affine_video_1.weight"], p["fc_affine_video_1.bias"]))
     q = F.relu(F.linear((aq1 * vq1).mean(1), p["fc_affine_bottleneck.weight"], p["fc_affine_bottleneck.bias"]))
     ch = torch.sigmoid(F.linear(q, p["fc_affine_v_c_att.weight"], p["fc_affine_v_c_att.bias"])).unsqueeze(1)
     Xc = X1 * (ch + 1)
-    if fp8:
-        vq2 = F.relu(_q8(Xc.bfloat16().float(), False) @ _q8(p["fc_affine_video_2.weight"], True).t() + p["fc_affine_video_2.bias"])
-    else:
-        vq2 = F.relu(F.linear(Xc, p["fc_affine_video_2.weight"], p["fc_affine_video_2.bias"]))
+    vq2 = F.relu(F.linear(Xc, p["fc_affine_video_2.weight"], p["fc_affine_video_2.bias"]))
     aq2 = F.relu(F.linear(a, p["fc_affine_audio_2.weight"], p["fc_affine_audio_2.bias"])).unsqueeze(1)
     sl = F.linear(vq2 * aq2, p["fc_affine_v_s_att.weight"], p["fc_affine_v_s_att.bias"])     # [B,N,1]
     amap = torch.softmax(torch.tanh(sl).transpose(1, 2), -1).squeeze(1)

@@ -523,3 +523,28 @@ def test_training_steps_under_dp_match_single_process(accum_itr, accum_mode):
     assert [g["lr"] for g in groups] == [5e-4, 5e-4, 5e-4, 5e-4, 5e-6, 5e-4, 5e-4]
     a, b = shard_clips(11, 0, 2, seed=43, epoch=3), shard_clips(11, 1, 2, seed=43, epoch=3)
     assert len(a) == len(b) == 6 and set(a) | set(b) == set(range(11))
+
+
+@pytest.mark.parametrize("flavour,over", [("ave", {}), ("avqa", dict(tk=2, g=4)), ("avs_s4", {}), ("pretrain", {})])
+def test_cpu_baseline_port_matches_the_explicit_oracle(flavour, over):
+    """`oracle.forward_autograd` -- the op-for-op ATen port that bench.py's `cpu_baseline` leg times -- against the explicit
+    forward / hand-derived backward the parity tests use (round 5: an edit of the explicit forward once leaked into the port and
+    broke the default bench line on the GPU box; nothing on the CPU side ran it)."""
+    from oracle import dgsct_oracle as O
+    cfg = O.AdapterConfig(**{**dict(N=16, C=32, No=36, Co=16, tk=4, r=8, g=2), **O.FLAVOURS[flavour], **over})
+    p = O.random_params(cfg, flavour, seed=1)
+    if cfg.remap == "bicubic":
+        p["_bicubic"] = O.bicubic_matrix(cfg.No, cfg.N)
+    gen = torch.Generator().manual_seed(2)
+    BT = 2 * max(cfg.T, 1)
+    X, Y = torch.randn(BT, cfg.N, cfg.C, generator=gen), torch.randn(BT, cfg.No, cfg.Co, generator=gen)
+    dOut, dMap = torch.randn(BT, cfg.N, cfg.C, generator=gen), torch.randn(BT, cfg.N, generator=gen)
+    out_o, map_o, _, s = O.forward({k: v.clone() for k, v in p.items()}, X, Y, cfg, training=True)
+    dX_o, dY_o, _ = O.backward({k: v.clone() for k, v in p.items()}, s, cfg, dOut, dMap, None, training=True)
+    pa = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.startswith("_") else v.clone())
+          for k, v in p.items()}
+    Xa, Ya = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+    out, amap, _ = O.forward_autograd(pa, Xa, Ya, cfg, training=True)
+    torch.autograd.backward([out, amap], [dOut.reshape(out.shape), dMap.reshape(amap.shape)])
+    assert rel_err(out.reshape(out_o.shape), out_o) < 1e-4 and rel_err(amap.reshape(map_o.shape), map_o) < 1e-4
+    assert rel_err(Xa.grad, dX_o) < 1e-4 and rel_err(Ya.grad, dY_o) < 1e-4
