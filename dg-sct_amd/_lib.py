@@ -64,10 +64,18 @@ class AttnArgs(C.Structure):
 
 
 EXPORTS = ["dgsct_test_gemm_fp8", "dgsct_temporal_gate_forward", "dgsct_temporal_gate_backward", "dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
-           "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_test_tune", "dgsct_frame_scale_forward", "dgsct_frame_scale_backward", "dgsct_prof_enable", "dgsct_prof_collect",
+           "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_adapter_backward_ex2", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_test_tune", "dgsct_frame_scale_forward", "dgsct_frame_scale_backward", "dgsct_prof_enable", "dgsct_prof_collect",
            "dgsct_stream_create", "dgsct_stream_destroy", "dgsct_map_pool_forward", "dgsct_map_pool_backward"]
 
 _PP = C.POINTER(C.c_void_p)
+
+
+class BwdOpts(C.Structure):
+    """dgsct_bwd_opts (include/dgsct.h)"""
+    _fields_ = [("flags", C.c_int32), ("dy_residual", C.c_void_p), ("dx_ready_event", C.c_void_p), ("dy_wait_event", C.c_void_p)]
+
+
+BWD_SKIP_INTO_DX, BWD_NO_JOIN, BWD_HOLD_DY, BWD_ONLY_DY = 1, 2, 4, 8
 
 
 class Lib:
@@ -94,6 +102,7 @@ class Lib:
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p]
         c.dgsct_adapter_backward_ex.argtypes = c.dgsct_adapter_backward.argtypes + [C.c_void_p, C.c_int]
+        c.dgsct_adapter_backward_ex2.argtypes = c.dgsct_adapter_backward.argtypes + [C.c_void_p, C.POINTER(BwdOpts)]
         fa = list(c.dgsct_adapter_forward.argtypes)
         c.dgsct_adapter_forward_ex.argtypes = fa[:5] + [C.c_void_p] + fa[5:] + [C.c_void_p]
         c.dgsct_saved_region.argtypes = [C.POINTER(AdapterDesc), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
@@ -144,6 +153,22 @@ class Lib:
         self._check(self.c.dgsct_adapter_backward_ex(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, saved, dOut, dMap, dTmap,
                                                      dX, dY, grads, ws, stream, aux_stream, flags),
                     "dgsct_adapter_backward")
+
+    def backward_hold_dy(self, desc, ptrs, prep, X, Y, saved, dOut, dMap, dTmap, dX, grads, ws, stream, aux_stream=None,
+                         skip_into_dx=False, no_join=False, dx_ready_event=None):
+        """everything of the backward except the product that writes dY (DGSCT_BWD_HOLD_DY); `dx_ready_event` (raw hipEvent_t) is
+        recorded on `stream` once dX is complete"""
+        o = BwdOpts((BWD_SKIP_INTO_DX if skip_into_dx else 0) | (BWD_NO_JOIN if no_join else 0) | BWD_HOLD_DY, None, dx_ready_event, None)
+        self._check(self.c.dgsct_adapter_backward_ex2(C.byref(desc), C.cast(ptrs, _PP), prep, X, Y, saved, dOut, dMap, dTmap,
+                                                      dX, None, grads, ws, stream, aux_stream, C.byref(o)),
+                    "dgsct_adapter_backward_ex2 (HOLD_DY)")
+
+    def backward_only_dy(self, desc, ptrs, prep, dY, ws, stream, dy_residual=None, dy_wait_event=None):
+        """the held-back product: dY = dy_residual + d adapter / dY, behind `dy_wait_event` (DGSCT_BWD_ONLY_DY)"""
+        o = BwdOpts(BWD_ONLY_DY, dy_residual, None, dy_wait_event)
+        self._check(self.c.dgsct_adapter_backward_ex2(C.byref(desc), C.cast(ptrs, _PP), prep, None, None, None, None, None, None,
+                                                      None, dY, None, ws, stream, None, C.byref(o)),
+                    "dgsct_adapter_backward_ex2 (ONLY_DY)")
 
     def saved_regions(self, desc):
         out = {}

@@ -308,6 +308,26 @@ class VisualAdapter(nn.Module):
         e.g. writes through raw pointers)."""
         self._prep_cache = None
 
+    def _compute_dtype_for(self, in_dtype):
+        return self.compute_dtype or (torch.bfloat16 if in_dtype == torch.bfloat16 else torch.float32)
+
+    def _token_call(self, cd, device):
+        """What one library call of this module needs besides the maps: (lib, spec, training, prep, params, flat parameter or None).
+        Counts the call for BatchNorm's num_batches_tracked (training mode), as forward() always did."""
+        lib = self._lib or _lib.default_lib()
+        params = [ops.check_param(n, p, device) for n, p in zip(PARAM_NAMES, self._param_list())]
+        prep = self._prepared(lib, params, cd, device)
+        training = self.training
+        flat = self.flat_param if "_flat_views" in self.__dict__ else None
+        if training and self.use_bn:
+            pend = self.__dict__.get("_count_later")
+            if pend is not None:                         # AdapterStack: one _foreach_add_ per step instead of 96 one-element kernels
+                pend.append(self.bn1.num_batches_tracked); pend.append(self.bn2.num_batches_tracked)
+            else:
+                self.bn1.num_batches_tracked += 1
+                self.bn2.num_batches_tracked += 1
+        return lib, self.spec, training, prep, params, flat
+
     def forward(self, x, vis_token=None, caption=None, is_temporal=False, residual=None, skip=False):
         """x [BT,C,N,1], vis_token [BT,Co,No,1] (views of token-major maps) ->
         (output [BT,C,N,1], spatial_att_maps [BT,1,N][, temporal_att_maps [BT/T,T,1,1]]).
@@ -320,28 +340,17 @@ class VisualAdapter(nn.Module):
         if not x.is_cuda and self._lib is None:      # (tests inject the host-emulated library to check this plumbing)
             raise RuntimeError("dg-sct_amd.VisualAdapter runs on MI355X through libdgsct.so; there is no CPU path "
                                "(move the module and its inputs to a ROCm device)")
-        lib = self._lib or _lib.default_lib()
         X = x.squeeze(-1).permute(0, 2, 1)           # [BT,N,C]: contiguous when x is the reference's permuted view
         Y = vis_token.squeeze(-1).permute(0, 2, 1)
         in_dtype = x.dtype
-        cd = self.compute_dtype or (torch.bfloat16 if in_dtype == torch.bfloat16 else torch.float32)
+        cd = self._compute_dtype_for(in_dtype)
         X = X.to(cd).contiguous()
         Y = Y.to(cd).contiguous()
-        params = [ops.check_param(n, p, X.device) for n, p in zip(PARAM_NAMES, self._param_list())]
-        prep = self._prepared(lib, params, cd, X.device)
-        training = self.training
-        flat = self.flat_param if "_flat_views" in self.__dict__ else None
+        lib, spec, training, prep, params, flat = self._token_call(cd, X.device)
         res = None
         if residual is not None:
             res = residual.squeeze(-1).permute(0, 2, 1).to(cd).contiguous()
-        out, amap, tmap = ops.adapter_apply(lib, self.spec, training, prep, X, Y, params, flat, residual=res, skip=skip)
-        if training and self.use_bn:
-            pend = self.__dict__.get("_count_later")
-            if pend is not None:                         # AdapterStack: one _foreach_add_ per step instead of 96 one-element kernels
-                pend.append(self.bn1.num_batches_tracked); pend.append(self.bn2.num_batches_tracked)
-            else:
-                self.bn1.num_batches_tracked += 1
-                self.bn2.num_batches_tracked += 1
+        out, amap, tmap = ops.adapter_apply(lib, spec, training, prep, X, Y, params, flat, residual=res, skip=skip)
         if out.dtype != in_dtype:
             out = out.to(in_dtype)
         output = out.permute(0, 2, 1).unsqueeze(-1)

@@ -103,6 +103,33 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
   return rc;
 }
 
+int dgsct_adapter_backward_ex2(const dgsct_adapter_desc* desc, float* const* params, const void* prep, const void* X,
+                               const void* Y, const void* saved, const void* dOut, const float* dMap, const float* dTmap,
+                               void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream,
+                               const dgsct_bwd_opts* opts) {
+  begin_call();
+  if (!opts) { set_error("dgsct_adapter_backward_ex2: NULL options"); return 2; }
+  const int fl = opts->flags;
+  if ((fl & DGSCT_BWD_HOLD_DY) && (fl & DGSCT_BWD_ONLY_DY)) { set_error("dgsct_adapter_backward_ex2: HOLD_DY and ONLY_DY are the two parts of one call"); return 2; }
+  BwdPair pr;
+  pr.phase = (fl & DGSCT_BWD_HOLD_DY) ? 1 : (fl & DGSCT_BWD_ONLY_DY) ? 2 : 0;
+  pr.dy_residual = opts->dy_residual; pr.dx_event = opts->dx_ready_event; pr.dy_wait = opts->dy_wait_event;
+  if (pr.phase == 1 && pr.dy_residual) { set_error("dgsct_adapter_backward_ex2: dy_residual belongs to the part that writes dY"); return 2; }
+  if (pr.phase == 2) {
+    if (!desc || !params || !prep || !dY || !ws) { set_error("dgsct_adapter_backward_ex2 (ONLY_DY): NULL argument"); return 2; }
+  } else if (!desc || !params || !prep || !X || !Y || !saved || !dOut || !dX || !grads || !ws || (pr.phase == 0 && !dY)) {
+    set_error("dgsct_adapter_backward_ex2: NULL argument");
+    return 2;
+  }
+  Plan p(*desc);
+  if (!p.ok) return 2;
+  void* rec = pr.phase == 2 ? nullptr : call_prof_begin(stream, 1, desc->N, desc->C);
+  const int rc = p.backward(params, prep, X, Y, saved, dOut, dMap, dTmap, dX, dY, grads, ws, stream, aux_stream, (fl & DGSCT_BWD_SKIP_INTO_DX) != 0,
+                            (fl & DGSCT_BWD_NO_JOIN) != 0, &pr);
+  if (rec) call_prof_end(rec);
+  return rc;
+}
+
 int dgsct_saved_region(const dgsct_adapter_desc* desc, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes) {
   begin_host_call();
   if (!desc) return 2;

@@ -72,6 +72,7 @@ struct G8 {
   const char* B; long ldb, b_bs, b_kbs;
   char* D; int ddt; long ldd, dbs; int atomic;
   const float* r1_m; const float* r1_n; const float* bias_n;
+  const char* R;                          // bf16 residual laid out like D (ldd, dbs), added in the row pass (plain stores only); NULL: none
   int gm;                                 // m-tiles per group of the work list (tile order, see the kernel)
   int dbg;                                // DGSCT_GEMM8_DBG (timing experiments only, results are garbage): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMA
 };
@@ -481,6 +482,12 @@ void gemm8_kernel(const G8 p) {
       const float4 b = *reinterpret_cast<const float4*>(stg + row * SP + cc * 8 + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
       const long od = (long)m * p.ldd + cb;
+      if (p.R) {                                              // (pair backward: d f = dX(other call) + this product)
+        float rv[8];
+        ldv<DT_BF16, 8>(p.R, od, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
       if (p.ddt == DT_F32) {
         stv<DT_F32, 4>(p.D, od, *reinterpret_cast<const float(*)[4]>(v));
         stv<DT_F32, 4>(p.D, od + 4, *reinterpret_cast<const float(*)[4]>(v + 4));
@@ -542,7 +549,8 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
   // DGSCT_GEMM8=0 switches the kernel off (A/B runs against the tiled engine); =2 also takes shapes below the size gates
   const int mode = gemm8_mode(-1);
   if (!mode || ctx.mode != DT_BF16) return false;
-  if (g.act != ACT_NONE || g.mask || g.R || g.R2 || g.bias_m || g.alpha_ptr || g.alpha != 1.f || g.sm_scale || g.sm_dot) return false;
+  if (g.R && (g.atomic || g.R2 || g.ddt != DT_BF16 || g.rdt != DT_BF16 || g.ldr != g.ldd || g.rbs != g.dbs || g.beta != 1.f || !g8_al16(g.R))) return false;
+  if (g.act != ACT_NONE || g.mask || g.R2 || g.bias_m || g.alpha_ptr || g.alpha != 1.f || g.sm_scale || g.sm_dot) return false;
   if (g.m_mod > 0 || g.bias_n_bs != 0) return false;
   if ((g.r1_m == nullptr) != (g.r1_n == nullptr)) return false;
   const long kflat = (long)g.K * g.KB;
@@ -632,6 +640,7 @@ split_done:
   k.B = (const char*)g.B.p; k.ldb = g.B.ld; k.b_bs = g.B.bs; k.b_kbs = g.B.kbs;
   k.D = (char*)g.D; k.ddt = g.ddt; k.ldd = g.ldd; k.dbs = g.dbs; k.atomic = plain ? 0 : g.atomic;
   k.r1_m = g.r1_m; k.r1_n = g.r1_n; k.bias_n = g.bias_n;
+  k.R = (const char*)g.R;
   static const int gm_env = getenv("DGSCT_GEMM8_GM") ? atoi(getenv("DGSCT_GEMM8_GM")) : 4;
   k.gm = gm_env < 1 ? 1 : (gm_env > tiles_m ? tiles_m : gm_env);
   static const int dbg_env = getenv("DGSCT_GEMM8_DBG") ? atoi(getenv("DGSCT_GEMM8_DBG")) : 0;

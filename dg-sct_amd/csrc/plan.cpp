@@ -565,10 +565,42 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
 // ------------------------------------------------------------------------------------------------
 int Plan::backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved_c,
                    const void* dOut, const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws,
-                   void* stream, void* aux_stream, bool skip_into_dx, bool no_join) const {
+                   void* stream, void* aux_stream, bool skip_into_dx, bool no_join, const BwdPair* pair) const {
   Bound b(*this, params, prep, const_cast<void*>(saved_c), ws, stream);
   b.ctx.aux = aux_stream;
   const Ctx& ctx = b.ctx;
+  // The product that writes dY is the last link of the data-gradient chain and reads only the workspace (dT) and the prepared weights.
+  // A caller that runs the two adapters of a position (net_trans.py:891-892) side by side wants d f_own = dX(own) + dY(other): it holds
+  // this product back (phase 1), and issues it afterwards (phase 2) with the OTHER call's dX as the epilogue's residual -- behind an
+  // event that call recorded right after its dX.  The gradient-accumulation pass over [BT][N][C] per adapter call disappears.
+  const int phase = pair ? pair->phase : 0;
+  // (DGSCT_BWD_NO_JOIN) the caller orders `grads` / `ws` behind the aux stream itself: this call's chain ends with dY, so everything
+  // that only feeds parameter gradients -- also the three bias-side reductions that used to balance the tail of a joined call -- goes
+  // to the aux stream
+  const bool deferred = no_join && aux_stream;
+  static const bool bias_on_main = getenv("DGSCT_BIAS_ON_MAIN") && atoi(getenv("DGSCT_BIAS_ON_MAIN"));     // (A/B switch)
+  const bool bias_aux = deferred && !bias_on_main;
+  auto dy_product = [&]() {
+    Gemm g3;
+    if (orderA) {
+      g3 = mk(No, Co, N, B);                                     // dY[b] = Wn^T . dT1[b]
+      g3.A = mn(b.W(DGSCT_P_WN), No);
+      g3.B = mn(b.Wk(wb.dT), Co, (long)N * Co);
+    } else {
+      g3 = mk(No, Co, C, B);                                     // dY[b] = dT2[b] . Wc
+      g3.A = km(b.Wk(wb.dT), C, (long)No * C);
+      g3.B = b.WB(DGSCT_P_WC, Co, C);
+    }
+    outE(g3, dY, E, Co, (long)No * Co);
+    if (pair && pair->dy_residual) resid(g3, pair->dy_residual, E, Co, (long)No * Co);
+    if (pair && pair->dy_wait) event_wait(ctx, pair->dy_wait);
+    gemm(ctx, g3);
+  };
+  if (phase == 2) {
+    dy_product();
+    check_async("dgsct_adapter_backward (dY product)");
+    return has_error() ? 1 : 0;
+  }
   // Weight / bias gradients feed nothing downstream: they go to the aux stream (when given) and overlap the data-gradient
   // chain.  A fork makes aux wait for everything enqueued so far (the operands); the final join orders it all
   // before the caller's next use of `grads` / `ws`.
@@ -943,12 +975,20 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     if (!(SK & (128 | 65536))) xattn_bwd(ctx, X, dX1, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX, skip_into_dx ? dOut : nullptr,
               b.Wk<float>(wb.dtokF), G(DGSCT_P_GATE_AV),      // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
               s.tokpk >= 0 ? b.S(s.tokpk) : nullptr);
+    if (pair && pair->dx_event) event_record(ctx, pair->dx_event);      // dX is complete
     if (d.remap == DGSCT_REMAP_CONV) {
       // d fc.bias = sum_{b,n} dYp[b,n,:].  Softmax rows sum to 1 and dS1 rows sum to 0, so this equals
       // sum_b (sum_t dtok[b,t,:] + da[b,:]) exactly -- computed from these two small fp32 tensors instead of
       // re-reducing the big bf16-rounded dYp (a cancellation-heavy sum: 30 % relative error in bf16 otherwise).
-      const ColsumSeg segs[2] = {{b.Wk(wb.dtokF), DT_F32, B * tk, C, G(DGSCT_P_BC)}, {b.Wk(wb.da), DT_F32, B, C, G(DGSCT_P_BC)}};
-      colsum_multi(ctx, segs, 2);
+      if (bias_aux) {
+        defer([=, &side, &b] {
+          const ColsumSeg segs[2] = {{b.Wk(wb.dtokF), DT_F32, B * tk, C, G(DGSCT_P_BC)}, {b.Wk(wb.da), DT_F32, B, C, G(DGSCT_P_BC)}};
+          colsum_multi(side, segs, 2);
+        });
+      } else {
+        const ColsumSeg segs[2] = {{b.Wk(wb.dtokF), DT_F32, B * tk, C, G(DGSCT_P_BC)}, {b.Wk(wb.da), DT_F32, B, C, G(DGSCT_P_BC)}};
+        colsum_multi(ctx, segs, 2);
+      }
     }
   }
   // B2 ---- tokens <- remapped tokens attention: dYp and d my_tokens in one pass over Yp (P1 recomputed from lse)
@@ -979,10 +1019,6 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       g1.A = km(dYp, C); g1.B = b.WB(DGSCT_P_WC, Co, C);
       outE(g1, b.Wk(wb.dT), E, Co);
       if (!(SK & 2048)) gemm(ctx, g1);
-      Gemm g3 = mk(No, Co, N, B);                                // dY[b] = Wn^T . dT1[b]
-      g3.A = mn(b.W(DGSCT_P_WN), No);
-      g3.B = mn(b.Wk(wb.dT), Co, (long)N * Co);
-      outE(g3, dY, E, Co, (long)No * Co);
       if (conv) {
         Gemm g4 = mk(N, No, Co);                                 // dWn = sum_b dT1[b] . Y[b]^T
         g4.KB = B;
@@ -993,7 +1029,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
         defer([=, &side] { wgemm(side, g4); });
         side_flush();
       }
-      if (!(SK & 2048)) gemm(ctx, g3);
+      if (!(SK & 2048) && phase != 1) dy_product();             // dY[b] = Wn^T . dT1[b]
     } else {
       if (conv) {
         Gemm g2 = mk(N, No, C);                                  // dWn = sum_b dYp[b] . T2[b]^T
@@ -1018,31 +1054,34 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
       atomic_out(g4);
       defer([=, &side] { wgemm(side, g4); });
       side_flush();
-      Gemm g3 = mk(No, Co, C, B);                                // dY[b] = dT2[b] . Wc
-      g3.A = km(b.Wk(wb.dT), C, (long)No * C);
-      g3.B = b.WB(DGSCT_P_WC, Co, C);
-      outE(g3, dY, E, Co, (long)No * Co);
-      if (!(SK & 2048)) gemm(ctx, g3);
+      if (!(SK & 2048) && phase != 1) dy_product();             // dY[b] = dT2[b] . Wc
     }
     // both bias-side reductions of dYp in one pass (they were rowdot -> sum_batch and colsum: two more reads of the cotangent)
     // (round 4: frame by frame -- contiguous rows -- with the per-frame row dots summed by a second small launch: 150 -> ~45 us
     //  at 655 360 x 96)
-    if (conv)                                                    // dbn[n] = sum dYp . colb;  d rowsum(Wc)[c] = sum rowb[n] dYp
-      rowdot_colsum_frames(ctx, dYp, C, (long)N * C, B, N, C, b.colb(), b.rowb(), G(DGSCT_P_BN), b.Wk<float>(wb.dwcsum),
-                           b.Wk<float>(wb.rowtmp), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
-    else
-      rowdot_colsum_frames(ctx, dYp, C, (long)N * C, B, N, C, nullptr, b.rowb(), nullptr, G(DGSCT_P_BC), b.Wk<float>(wb.rowtmp),
-                           b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+    auto bias_sums = [=, &b](const Ctx& c) {
+      if (conv)                                                  // dbn[n] = sum dYp . colb;  d rowsum(Wc)[c] = sum rowb[n] dYp
+        rowdot_colsum_frames(c, dYp, C, (long)N * C, B, N, C, b.colb(), b.rowb(), G(DGSCT_P_BN), b.Wk<float>(wb.dwcsum),
+                             b.Wk<float>(wb.rowtmp), b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+      else
+        rowdot_colsum_frames(c, dYp, C, (long)N * C, B, N, C, nullptr, b.rowb(), nullptr, G(DGSCT_P_BC), b.Wk<float>(wb.rowtmp),
+                             b.Wk<float>(wb.rowpart), row_part_floats(B, C));
+    };
+    if (bias_aux)                                                // ... and the broadcast of d rowsum(Wc) into dWc right behind them (below)
+      defer([=, &side, &b] {
+        bias_sums(side);
+        if (conv) ew(side, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
+      });
+    else bias_sums(ctx);
   }
   side_flush();
   // d rowsum(Wc)[c] is broadcast over co into dWc, which the aux stream accumulates: after the join -- or, when the caller takes over the
   // ordering (DGSCT_BWD_NO_JOIN: it orders whatever reads `grads`, reuses `ws` or frees the inputs after the aux stream itself, so the
   // chain of the NEXT call never waits for this call's weight gradients), on the aux stream behind them
-  const bool deferred = no_join && aux_stream;
   if (!deferred && !(SK & 8192)) stream_join(ctx);
   if (d.remap == DGSCT_REMAP_CONV) {
-    if (deferred) { stream_fork(ctx); ew(side, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co); }
-    else ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
+    if (deferred && !bias_aux) { stream_fork(ctx); ew(side, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co); }
+    else if (!deferred) ew(ctx, EW_ADD_BCAST, G(DGSCT_P_WC), DT_F32, F32(G(DGSCT_P_WC)), F32(b.Wk(wb.dwcsum)), NOARG, (long)C * Co, 1.f, Co);
   }
   check_async("dgsct_adapter_backward");
   return has_error() ? 1 : 0;

@@ -10,6 +10,16 @@ namespace dgsct {
 
 struct Region { std::string name; int64_t offset, bytes; };
 
+// The dY product split off the call (dgsct_adapter_backward_ex2): `phase` 1 = everything but the product that writes dY, 2 = only that
+// product (reads the call's workspace, nothing else of phase 1's arguments), 0 = both.  dy_residual is added to dY in the product's
+// epilogue; dx_event is recorded on the stream once dX is complete, dy_wait is waited for in front of the dY product.
+struct BwdPair {
+  int phase = 0;
+  const void* dy_residual = nullptr;
+  void* dx_event = nullptr;
+  void* dy_wait = nullptr;
+};
+
 struct Plan {
   explicit Plan(const dgsct_adapter_desc& d, bool record_regions = false);
   bool record_regions_ = false;
@@ -47,7 +57,7 @@ struct Plan {
               void* saved, void* ws, void* stream, const void* residual = nullptr, void* aux_stream = nullptr) const;
   int backward(float* const* params, const void* prep, const void* X, const void* Y, const void* saved, const void* dOut,
                const float* dMap, const float* dTmap, void* dX, void* dY, float* grads, void* ws, void* stream,
-               void* aux_stream = nullptr, bool skip_into_dx = false, bool no_join = false) const;
+               void* aux_stream = nullptr, bool skip_into_dx = false, bool no_join = false, const BwdPair* pair = nullptr) const;
 
  private:
   bool validate();

@@ -43,6 +43,8 @@ void* stream_create(int priority_class);
 void stream_destroy(void* stream);
 void stream_fork(const Ctx&);
 void stream_join(const Ctx&);
+void event_record(const Ctx&, void* ev);    // hipEventRecord(ev, ctx.stream) -- the caller's hipEvent_t (pair backward, plan.cpp)
+void event_wait(const Ctx&, void* ev);      // hipStreamWaitEvent(ctx.stream, ev)
 // report (through set_error) the first failed kernel launch / runtime call of this thread since the last check
 void check_async(const char* where);
 // drop a stale sticky runtime error of this thread (left by another HIP user) before a call starts

@@ -101,6 +101,13 @@ void stream_join(const Ctx& ctx) {
   order_after((hipStream_t)ctx.stream, (hipStream_t)ctx.aux, 1);
 }
 
+void event_record(const Ctx& ctx, void* ev) {
+  if (ev && hipEventRecord(static_cast<hipEvent_t>(ev), STREAM(ctx)) != hipSuccess) set_error("hipEventRecord on the caller's event failed");
+}
+void event_wait(const Ctx& ctx, void* ev) {
+  if (ev && hipStreamWaitEvent(STREAM(ctx), static_cast<hipEvent_t>(ev), 0) != hipSuccess) set_error("hipStreamWaitEvent on the caller's event failed");
+}
+
 void part_reduce_run(void* stream, const PartJob& j) {
   if (!j.n) return;
   PartTable t = j.t;

@@ -272,14 +272,16 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
 
 
 def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y, saved, dOut, dMap, dTmap, flat_out=False,
-                 skip_into_dx=False, defer_join=False):
+                 skip_into_dx=False, defer_join=False, hold_dy=False, dx_event=None, slot_base=0):
     """defer_join: the call returns without joining its weight-gradient stream (see DEFER_AUX_JOIN above); `grads` is complete only
-    after drain_aux() -- dX / dY are ordered on the current stream as always."""
+    after drain_aux() -- dX / dY are ordered on the current stream as always.
+    hold_dy: everything but the product that writes dY (pair backward below): returns (dX, ws, grads) -- `ws` is what
+    raw_backward_dy() needs; dx_event (raw hipEvent_t) is recorded on the call's stream once dX is complete."""
     _mark_stream_use(X, Y, saved, dOut, dMap, dTmap, prep)
     sz = _sizes(lib, d)
     dev = X.device
     dX = torch.empty_like(X)
-    dY = torch.empty_like(Y)
+    dY = None if hold_dy else torch.empty_like(Y)
     grads = torch.empty(int(sz.grad_floats), dtype=torch.float32, device=dev)
     stream = _stream_of(X)
     aux = _aux_stream(lib, X, stream)
@@ -288,13 +290,18 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     slot = 0
     if defer:
         slot = _SLOT[key] = 1 - _SLOT.get(key, 1)
-    ws = _workspace(dev, stream, int(sz.ws_bwd_bytes), slot)
+    ws = _workspace(dev, stream, int(sz.ws_bwd_bytes), slot_base + slot)
     if _POISON:
         _poison(dX, dY, grads, ws)
     with _dev_guard(X):
-        lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
-                     dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
-                     dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, aux, skip_into_dx, defer)
+        if hold_dy:
+            lib.backward_hold_dy(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
+                                 dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
+                                 dX.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, aux, skip_into_dx, defer, dx_event)
+        else:
+            lib.backward(d, _ptrs(params), prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
+                         dMap.data_ptr() if dMap is not None else None, dTmap.data_ptr() if dTmap is not None else None,
+                         dX.data_ptr(), dY.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream, aux, skip_into_dx, defer)
         if defer:
             ev = torch.cuda.Event()
             ev.record(_AUX[key])                                       # behind everything this call put on its aux stream
@@ -307,11 +314,26 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
                 torch.cuda.current_stream(dev).wait_event(prev[0])     # the call before this one: long done; its buffers go now
                 del prev
             _queue_drain()
+    if hold_dy:
+        return dX, ws, grads
     if flat_out:
         return dX, dY, grads
     lay = grad_layout(lib, d)
     per_param: List[Optional[torch.Tensor]] = [grads[off:off + n] if off >= 0 else None for off, n in lay]
     return dX, dY, per_param
+
+
+def raw_backward_dy(lib: Lib, d: AdapterDesc, params, prep, ws, Y, residual=None, wait_event=None):
+    """The product raw_backward(hold_dy=True) held back, on the current stream: dY = residual + d adapter / dY, issued behind
+    `wait_event` (raw hipEvent_t).  `ws` is the workspace that call returned; Y only gives the shape / dtype / device."""
+    _mark_stream_use(residual, prep)
+    dY = torch.empty_like(Y)
+    if _POISON:
+        _poison(dY)
+    with _dev_guard(Y):
+        lib.backward_only_dy(d, _ptrs(params), prep.data_ptr(), dY.data_ptr(), ws.data_ptr(), _stream_of(Y),
+                             residual.data_ptr() if residual is not None else None, wait_event)
+    return dY
 
 
 def grad_layout(lib: Lib, d: AdapterDesc):
@@ -420,6 +442,119 @@ class _AdapterFlatFn(torch.autograd.Function):
                                      flat_out=True, skip_into_dx=ctx.skip, defer_join=can_defer)
         ctx.saved_buf = None
         return None, None, None, None, None, None, dOut if ctx.has_res else None, dX, dY, gflat
+
+
+PAIR_BACKWARD = os.environ.get("DGSCT_NO_PAIR", "0") != "1"
+_PAIR_EVENTS: Dict[int, list] = {}
+_PAIR_RING = 16
+
+
+def _pair_events(dev: torch.device):
+    """two recorded-once events of a small per-device ring (a torch event has no handle before its first record); the library
+    re-records them in the middle of the two calls of a pair"""
+    ring = _PAIR_EVENTS.get(dev.index)
+    if ring is None:
+        ring = _PAIR_EVENTS[dev.index] = [[], 0]
+        cur = torch.cuda.current_stream(dev)
+        for _ in range(_PAIR_RING):
+            e = torch.cuda.Event()
+            e.record(cur)
+            ring[0].append(e)
+    i = ring[1]
+    ring[1] = (i + 2) % _PAIR_RING
+    return ring[0][i], ring[0][i + 1]
+
+
+def _cotangent(dOut, X):
+    if dOut is None:
+        return torch.zeros_like(X)
+    dOut = dOut.contiguous()
+    return dOut if dOut.dtype == X.dtype else dOut.to(X.dtype)
+
+
+class _PairFlatFn(torch.autograd.Function):
+    """The audio and the visual adapter of one position (net_trans.py:891-906) as ONE autograd node:
+        f_a' = f_a + audio_adapter(f_a, f_v),   f_v' = f_v + vis_adapter(f_v, f_a)
+    so that  d f_a = dX(audio) + dY(visual)  and  d f_v = dX(visual) + dY(audio)  are formed by the products that write dY (their
+    epilogues read the other call's dX: include/dgsct.h, dgsct_adapter_backward_ex2) instead of by autograd's accumulation -- one
+    pass over [BT][N][C] per adapter call less, on the critical path between two positions.  `side`: the second adapter stream
+    (None: both calls on the current stream, in order -- the host-emulated library of the CPU tests)."""
+
+    @staticmethod
+    def forward(ctx, lib, side, call_a, call_v, f_a, f_v, flat_a, flat_v):
+        # call_x = (spec, training, prep, plist) of VisualAdapter._token_call
+        def one(call, X, Y):
+            spec, training, prep, plist = call
+            out, amap, _, saved, d = raw_forward(lib, spec, plist, prep, X, Y, training, X)
+            return out, amap, saved, d
+        if side is not None:
+            main = torch.cuda.current_stream(f_a.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                oa, ma, sa, da = one(call_a, f_a, f_v)
+            ov, mv, sv, dv = one(call_v, f_v, f_a)
+            main.wait_stream(side)
+            oa.record_stream(main)
+            ma.record_stream(main)
+        else:
+            oa, ma, sa, da = one(call_a, f_a, f_v)
+            ov, mv, sv, dv = one(call_v, f_v, f_a)
+        ctx.lib, ctx.side = lib, side
+        ctx.calls = (call_a, call_v)
+        ctx.descs = (da, dv)
+        ctx.saved_bufs = (sa, sv)
+        ctx.flats = (flat_a, flat_v)
+        ctx.save_for_backward(f_a, f_v)
+        ctx.set_materialize_grads(False)
+        return oa, ma, ov, mv
+
+    @staticmethod
+    def backward(ctx, dOa, dMa, dOv, dMv):
+        if ctx.saved_bufs is None:
+            raise RuntimeError("dg-sct_amd: backward through an adapter call twice is not supported "
+                               "(the saved-activation buffer is consumed in place)")
+        f_a, f_v = ctx.saved_tensors
+        lib, side = ctx.lib, ctx.side
+        (spec_a, _, prep_a, pl_a), (spec_v, _, prep_v, pl_v) = ctx.calls
+        d_a, d_v = ctx.descs
+        s_a, s_v = ctx.saved_bufs
+        defer = [isinstance(fl, torch.Tensor) and fl.is_leaf and fl.grad is None and not getattr(fl, "_backward_hooks", None)
+                 for fl in ctx.flats]                                   # (as in _AdapterFlatFn.backward)
+        ctx.flats = ctx.saved_bufs = None
+        dOa, dOv = _cotangent(dOa, f_a), _cotangent(dOv, f_v)
+        dMa = dMa.contiguous().float() if dMa is not None else None
+        dMv = dMv.contiguous().float() if dMv is not None else None
+
+        def main_part(spec, d, pl, prep, X, Y, saved, dO, dM, can_defer, ev, slot_base=0):
+            return raw_backward(lib, spec, d, pl, prep, X, Y, saved, dO, dM, None, flat_out=True, skip_into_dx=True,
+                                defer_join=can_defer, hold_dy=True, dx_event=ev, slot_base=slot_base)
+
+        if side is not None:
+            dev = f_a.device
+            ev_a, ev_v = _pair_events(dev)
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dXa, ws_a, g_a = main_part(spec_a, d_a, pl_a, prep_a, f_a, f_v, s_a, dOa, dMa, defer[0], ev_a.cuda_event)
+            dXv, ws_v, g_v = main_part(spec_v, d_v, pl_v, prep_v, f_v, f_a, s_v, dOv, dMv, defer[1], ev_v.cuda_event)
+            with torch.cuda.stream(side):                               # d f_v = dX(visual) + dY(audio call)
+                df_v = raw_backward_dy(lib, d_a, pl_a, prep_a, ws_a, f_v, dXv, ev_v.cuda_event)
+            df_a = raw_backward_dy(lib, d_v, pl_v, prep_v, ws_v, f_a, dXa, ev_a.cuda_event)     # d f_a = dX(audio) + dY(visual call)
+            main.wait_stream(side)
+            df_v.record_stream(main)
+        else:
+            dXa, ws_a, g_a = main_part(spec_a, d_a, pl_a, prep_a, f_a, f_v, s_a, dOa, dMa, defer[0], None)
+            # (one stream = one workspace per slot: the second call must not overwrite what the first one's dY product still reads)
+            dXv, ws_v, g_v = main_part(spec_v, d_v, pl_v, prep_v, f_v, f_a, s_v, dOv, dMv, defer[1], None, slot_base=2)
+            df_v = raw_backward_dy(lib, d_a, pl_a, prep_a, ws_a, f_v, dXv)
+            df_a = raw_backward_dy(lib, d_v, pl_v, prep_v, ws_v, f_a, dXa)
+        return None, None, None, None, df_a, df_v, g_a, g_v
+
+
+def pair_apply(lib: Lib, side, call_a, call_v, f_a: torch.Tensor, f_v: torch.Tensor, flat_a: torch.Tensor, flat_v: torch.Tensor):
+    """(f_a + audio_adapter(f_a, f_v), map_a, f_v + vis_adapter(f_v, f_a), map_v); token-major contiguous maps of the adapters'
+    compute dtype, both adapters with flat parameters and without a temporal gate (AdapterStack checks)."""
+    return _PairFlatFn.apply(lib, side, call_a, call_v, f_a, f_v, flat_a, flat_v)
 
 
 def adapter_apply(lib: Lib, spec: AdapterSpec, training: bool, prep: torch.Tensor, X: torch.Tensor, Y: torch.Tensor,

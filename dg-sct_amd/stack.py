@@ -44,9 +44,13 @@ class AdapterStack(nn.Module):
 
     def __init__(self, stages: Sequence[Dict[str, int]], opt: Optional[SimpleNamespace] = None, flavour: str = "ave",
                  compute_dtype: Optional[torch.dtype] = None, lib=None, concurrent: bool = True, fuse_residual: bool = True,
-                 fp8_projections: bool = False):
+                 fp8_projections: bool = False, pair_backward: Optional[bool] = None):
         super().__init__()
         self.concurrent = concurrent
+        # both adapters of a position as one autograd node whose backward forms d f = dX(own) + dY(other) inside the dY products
+        # (ops._PairFlatFn); None = on unless DGSCT_NO_PAIR=1.  Needs the fused residual, flat parameters and no frozen block between
+        # a map and its adapter -- anything else takes the two-node path.
+        self.pair_backward = pair_backward
         self.fuse_residual = fuse_residual        # `f = f + adapter(...)` inside the adapter's last kernel (8f row f2)
         self.opt = opt or default_opt()
         o = self.opt
@@ -119,7 +123,32 @@ class AdapterStack(nn.Module):
                 r = mod(self._view(f_own), self._view(f_other), residual=self._view(f_res))
             return (r[0].squeeze(-1).permute(0, 2, 1),) + tuple(r[1:])
 
+        from . import ops as _ops
+        use_pair = _ops.PAIR_BACKWARD if self.pair_backward is None else bool(self.pair_backward)
+
+        def pair_node(audio_mod, vis_mod, f_a, f_v):
+            """the one-node path, or None when this position does not qualify"""
+            for m in (audio_mod, vis_mod):
+                if "_flat_views" not in m.__dict__ or m.flavour == "pretrain":
+                    return None
+            cd = audio_mod._compute_dtype_for(f_a.dtype)
+            if (f_a.dtype != cd or f_v.dtype != cd or vis_mod._compute_dtype_for(f_v.dtype) != cd or f_a.device != f_v.device
+                    or not f_a.is_contiguous() or not f_v.is_contiguous()):
+                return None
+            if not f_a.is_cuda and audio_mod._lib is None:
+                return None
+            la, sa, ta, pa, pla, fa = audio_mod._token_call(cd, f_a.device)
+            lv, sv, tv, pv, plv, fv = vis_mod._token_call(cd, f_v.device)
+            if la is not lv:
+                raise RuntimeError("dg-sct_amd: the adapters of one position were built on different library instances")
+            oa, ma, ov, mv = _ops.pair_apply(la, side, (sa, ta, pa, pla), (sv, tv, pv, plv), f_a, f_v, fa, fv)
+            return (oa, ma.unsqueeze(1)), (ov, mv.unsqueeze(1))
+
         def pair(audio_mod, vis_mod, f_a, f_v, r_a, r_v):
+            if use_pair and fuse and r_a is f_a and r_v is f_v:
+                got = pair_node(audio_mod, vis_mod, f_a, f_v)
+                if got is not None:
+                    return got
             if side is None:
                 return call(audio_mod, f_a, f_v, r_a), call(vis_mod, f_v, f_a, r_v)
             main = torch.cuda.current_stream(dev)

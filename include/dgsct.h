@@ -164,6 +164,35 @@ int dgsct_adapter_backward_ex(const dgsct_adapter_desc* desc, float* const* para
                               void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream,
                               int skip_into_dx);
 
+/* ---- the two adapters of a position as one backward (round 5) ---------------------------------------
+ * Every caller runs an audio and a visual adapter on the same pair of maps and adds each result to its own map
+ * (`f_a = f_a + audio_adapter(f_a, f_v)`, `f_v = f_v + vis_adapter(f_v, f_a)`: net_trans.py:891-906 and the same lines of the other
+ * tasks), so   d f_a = dX(audio call) + dY(visual call)   and   d f_v = dX(visual call) + dY(audio call).
+ * autograd forms those sums with one more pass over [BT][N][C] per call; here the sum is the epilogue of the product that writes dY.
+ * That product is the last link of a call's data-gradient chain, so a call is issued in two parts:
+ *   flags |= DGSCT_BWD_HOLD_DY : everything except the dY product (dY is not written).  `dx_ready_event` (a hipEvent_t, may be NULL)
+ *                                is recorded on `stream` as soon as dX is complete -- long before the call's last kernel;
+ *   flags |= DGSCT_BWD_ONLY_DY : only the dY product: dY = dy_residual + d adapter / dY, issued on `stream` behind `dy_wait_event`
+ *                                (hipEvent_t, may be NULL).  Reads `ws` as the HOLD_DY part of the same call left it (same desc, params,
+ *                                prep, ws, stream; X / Y / saved / dOut / dX / grads are not touched and may be NULL).
+ * Order on the host: HOLD_DY part of both calls (each on its own stream), then the ONLY_DY parts, each with the OTHER call's dX as
+ * dy_residual and the other call's dx_ready_event as dy_wait_event: the waits are then enqueued after the records they refer to.
+ * dy_residual: [BT][No][Co] of desc.dtype (the other adapter's dX has exactly this shape), NULL = none.  Without either flag the
+ * call is dgsct_adapter_backward_ex (dy_residual and the events still honoured). */
+#define DGSCT_BWD_HOLD_DY 4
+#define DGSCT_BWD_ONLY_DY 8
+typedef struct dgsct_bwd_opts {
+  int32_t flags;                 /* DGSCT_BWD_* */
+  const void* dy_residual;
+  void* dx_ready_event;          /* hipEvent_t */
+  void* dy_wait_event;           /* hipEvent_t */
+} dgsct_bwd_opts;
+int dgsct_adapter_backward_ex2(const dgsct_adapter_desc* desc, float* const* params, const void* prep,
+                               const void* X, const void* Y, const void* saved,
+                               const void* dOut, const float* dMap, const float* dTmap,
+                               void* dX, void* dY, float* grads, void* ws, void* stream, void* aux_stream,
+                               const dgsct_bwd_opts* opts);
+
 /* ---- spatial-map pooling of the task heads ----------------------------------
  * Replaces `f_v = torch.bmm(f_v_spatial_att_maps, f_v)` / `f_a = torch.bmm(f_a_spatial_att_maps, f_a)`
  * (DG-SCT/AVE/nets/net_trans.py:922-924; same lines in AVVP/nets/mgn.py and pretrain/nets/net_trans.py): the maps

@@ -39,6 +39,8 @@ void call_prof_end(void*) {}
 void call_prof_dump(const char*) {}
 void part_reduce_run(void*, const PartJob&) {}   // (the host primitives never leave a second stage behind)
 void stream_join(const Ctx&) {}
+void event_record(const Ctx&, void*) {}
+void event_wait(const Ctx&, void*) {}
 void check_async(const char*) {}
 void clear_async() {}
 int gemm_skinny_mode(int) { return 0; }

@@ -531,6 +531,57 @@ def test_stack_on_gpu_matches_reference_fixture(flat):
         assert not bad, (rep, bad)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_pair_backward_equals_the_two_node_path(dtype):
+    """AdapterStack's one-node path for the two adapters of a position (ops._PairFlatFn: d f = dX(own) + dY(other) formed in the
+    epilogue of the product that writes dY, the two halves of each call issued around the other call's) against the two autograd
+    nodes + accumulation it replaces, library against library on the same inputs: outputs and maps identical, input and parameter
+    gradients equal up to the ONE bf16 rounding the fused sum no longer makes (fp32: up to summation order)."""
+    from dgsct_amd import AdapterStack
+    from dgsct_amd.stack import default_opt
+    fx = load_golden("stack_2stage")
+    res = {}
+    for pair in (False, True):
+        st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4), concurrent=True, pair_backward=pair, compute_dtype=dtype)
+        st.load_state_dict(fx["state0"])
+        st = st.to(DEV).flatten_parameters()
+        st.train()
+        feats = [(a.to(DEV, dtype).requires_grad_(True), b.to(DEV, dtype).requires_grad_(True)) for a, b in fx["feats"]]
+        r = {}
+        for rep in range(2):
+            st.load_state_dict(fx["state0"])
+            for p in st.parameters():
+                p.grad = None
+            for a, b in feats:
+                a.grad = b.grad = None
+            outs, maps = st(feats)
+            torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
+                                    [g.to(DEV, dtype) for pr in fx["cots"] for g in pr] + [fx["mcots"][0].to(DEV), fx["mcots"][1].to(DEV)])
+            assert not ops._PENDING
+            torch.cuda.synchronize()
+        for i, (a, b) in enumerate(outs):
+            r[f"out{i}v"], r[f"out{i}a"] = a.detach().float(), b.detach().float()
+        r["map0"], r["map1"] = maps[0].detach().float(), maps[1].detach().float()
+        for i, (a, b) in enumerate(feats):
+            r[f"dfeat{i}v"], r[f"dfeat{i}a"] = a.grad.float(), b.grad.float()
+        for name, m in st.named_modules():
+            if hasattr(m, "flat_param"):
+                r[name] = m.flat_param.grad.clone()
+        res[pair] = r
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    bad = []
+    for k, a in res[False].items():
+        b = res[True][k]
+        assert torch.isfinite(b).all(), k
+        e = ((a - b).norm() / a.norm().clamp_min(1e-30)).item()
+        if k.startswith(("out", "map")):
+            if not torch.equal(a, b) and e > 1e-6:          # (atomics in the forward reductions: not bit-reproducible run to run)
+                bad.append((k, e))
+        elif e > tol:
+            bad.append((k, e))
+    assert not bad, bad
+
+
 def test_module_dropin_matches_oracle():
     """nn.Module boundary on the GPU: reference call convention ([BT,C,N,1] views), state_dict names, autograd -- against the
     oracle (forward values, input gradients, every parameter gradient, BN buffers)."""

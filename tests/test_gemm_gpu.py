@@ -279,6 +279,27 @@ def test_gemm8_unsplit_weight_gradient(ak, bk):
         lib.prof_enable(False)
 
 
+@pytest.mark.parametrize("ak,bk", [(0, 0), (1, 1), (1, 0)])
+def test_gemm8_residual_in_the_row_pass(gemm8_all, ak, bk):
+    """the dY product of the pair backward (plan.cpp dy_product): dY[b] = Wn^T . dT[b] + dX_other[b] -- a bf16 residual laid out like
+    the output, added in the staged row pass; must stay on gemm8 (a residual used to send the product to the tiled engine)"""
+    import csv, os, tempfile
+    lib = gemm8_all
+    lib.prof_enable(True)
+    try:
+        path = os.path.join(tempfile.mkdtemp(), "g.csv")
+        os.environ["DGSCT_PROF_DUMP"] = path
+        run_case(1, 512, 96, 1024, ak, bk, batch=6, shared_a=True, out_bf16=True, epi=dict(R=True, rdt=1))
+        lib.prof_collect()
+        rows = list(csv.DictReader(open(path)))
+        assert rows and rows[-1]["cfg"] in ("8", "9"), rows[-1]
+        run_case(1, 256, 128, 1024, ak, bk, batch=4, shared_a=True, out_bf16=True, epi=dict(R=True, rdt=1))
+        run_case(1, 256, 256, 1088, ak, bk, batch=1, out_bf16=True, epi=dict(R=True, rdt=1))
+    finally:
+        os.environ.pop("DGSCT_PROF_DUMP", None)
+        lib.prof_enable(False)
+
+
 def test_gemm8_is_actually_used(gemm8_all):
     """the shapes above must reach gemm8.hip (and a shape it cannot take must still be served by the tiled engine)"""
     lib = gemm8_all

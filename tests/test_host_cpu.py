@@ -171,6 +171,55 @@ def test_stack_residual_variants_agree(mode):
         assert rel_err(g1[k], g2[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("half", [False, True], ids=["full", "half_batch"])
+def test_pair_node_matches_the_reference_and_the_two_node_path(half):
+    """ops._PairFlatFn (both adapters of a position as one autograd node, the dY products issued last with the other call's dX as
+    their residual: dgsct_adapter_backward_ex2 HOLD_DY / ONLY_DY) on the host-emulated library: against the reference stack fixture
+    (outputs, maps, input gradients, every parameter gradient) and against the two-node path on a half batch whose inputs do not
+    require gradients (one stream = one workspace: the second call of a pair once overwrote what the first one's dY product reads)."""
+    from dgsct_amd import ops
+    emu = Lib(build_emu())
+    fx = load_golden("stack_2stage")
+    BT = fx["feats"][0][0].shape[0]
+    lo, hi = (0, BT // 2) if half else (0, BT)
+    res = {}
+    for pair in (False, True):
+        st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4), lib=emu, concurrent=False, pair_backward=pair)
+        st.load_state_dict(fx["state0"])
+        st.flatten_parameters().train()
+        feats = [(a[lo:hi].clone().requires_grad_(not half), b[lo:hi].clone().requires_grad_(not half)) for a, b in fx["feats"]]
+        calls = []
+        orig = ops.pair_apply
+        ops.pair_apply = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            outs, maps = st(feats)
+        finally:
+            ops.pair_apply = orig
+        assert len(calls) == (2 * sum(s["layers"] for s in fx["stages"]) if pair else 0)
+        torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
+                                [g[lo:hi] for pr in fx["cots"] for g in pr] + [fx["mcots"][0][lo:hi], fx["mcots"][1][lo:hi]])
+        r = {"outs": outs, "maps": maps, "dfeats": [(a.grad, b.grad) for a, b in feats]}
+        r["grads"] = {}
+        for name, m in st.named_modules():
+            if hasattr(m, "flat_param"):
+                for pn, (off, cnt, shape) in m._flat_layout.items():
+                    r["grads"][name + "." + pn] = m.flat_param.grad[off:off + cnt].view(shape)
+        res[pair] = r
+    a, b = res[False], res[True]
+    for (x1, y1), (x2, y2) in zip(a["outs"], b["outs"]):
+        assert torch.equal(x1, x2) and torch.equal(y1, y2)
+    assert all(torch.equal(m1, m2) for m1, m2 in zip(a["maps"], b["maps"]))
+    for k, g in a["grads"].items():
+        assert rel_err(b["grads"][k], g) < 1e-5, k
+    if not half:
+        for (x1, y1), (x2, y2) in zip(a["dfeats"], b["dfeats"]):
+            assert rel_err(x2, x1) < 1e-5 and rel_err(y2, y1) < 1e-5
+        for (fv, fa), (gv, ga) in zip(b["dfeats"], fx["dfeats"]):
+            assert rel_err(fv, gv) < 1e-4 and rel_err(fa, ga) < 1e-4
+        for k, g in fx["grads"].items():
+            assert rel_err(b["grads"][k], g) < 1e-4, k
+
+
 def test_flattened_parameters_keep_the_checkpoint_format_and_the_gradients():
     """flatten_parameters(): one flat fp32 Parameter per adapter (gradient = the library's flat buffer, adopted by
     autograd without a copy); state_dict keys/values stay the reference's; gradients equal the reference's."""
