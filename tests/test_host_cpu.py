@@ -597,3 +597,34 @@ def test_cpu_baseline_port_matches_the_explicit_oracle(flavour, over):
     torch.autograd.backward([out, amap], [dOut.reshape(out.shape), dMap.reshape(amap.shape)])
     assert rel_err(out.reshape(out_o.shape), out_o) < 1e-4 and rel_err(amap.reshape(map_o.shape), map_o) < 1e-4
     assert rel_err(Xa.grad, dX_o) < 1e-4 and rel_err(Ya.grad, dY_o) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(12, 32, 20, 48), (20, 48, 12, 32)], ids=["orderA_or_B", "swapped"])
+def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape):
+    """oracle/dgsct_oracle_bf16.evaluate() -- the oracle's arithmetic with a switchable bf16 rounding at every tensor the bf16 schedule
+    stores, the yardstick of tests/test_bf16_masked_gpu.py -- is pinned here: with nothing rounded it must reproduce the (reference-pinned)
+    oracle's forward and backward exactly, on its own ReLU decisions and on pinned ones; with the device's rounding points switched on it
+    must move (the switch is connected) but stay within bf16 distance."""
+    from oracle import dgsct_oracle as O
+    from oracle import dgsct_oracle_bf16 as OB
+    N, C, No, Co = shape
+    BT = 3
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=4, r=8, g=2), **O.FLAVOURS["ave"]})
+    p = O.random_params(cfg, "ave", seed=3, scale=0.577)
+    gen = torch.Generator().manual_seed(4)
+    X, Y = torch.randn(BT, N, C, generator=gen), torch.randn(BT, No, Co, generator=gen)
+    dOut, dMap = torch.randn(BT, N, C, generator=gen), torch.randn(BT, N, generator=gen)
+    out_o, map_o, _, s = O.forward({k: v.clone() for k, v in p.items()}, X, Y, cfg, training=True)
+    dX_o, dY_o, g_o = O.backward(p, s, cfg, dOut, dMap, None, training=True)
+    r = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q([]))
+    assert rel_err(r["out"], out_o) < 1e-5 and rel_err(r["map"], map_o) < 1e-5
+    assert rel_err(r["dX"], dX_o) < 1e-5 and rel_err(r["dY"], dY_o) < 1e-5
+    assert set(r["g"]) == {k for k, v in g_o.items() if v is not None}
+    for k, g in r["g"].items():
+        assert rel_err(g.reshape(g_o[k].shape), g_o[k]) < 2e-5, k
+    # pinned decisions (its own, fed back in): the same evaluation
+    r2 = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q([]), masks=r["masks"])
+    assert rel_err(r2["dX"], dX_o) < 1e-5 and rel_err(r2["dY"], dY_o) < 1e-5
+    rq = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q(OB.DEVICE_ROUNDING), masks=r["masks"])
+    e = float((rq["dY"] - dY_o).norm() / dY_o.norm())
+    assert 1e-4 < e < 5e-2, e
