@@ -280,18 +280,25 @@ static __global__ __launch_bounds__(256) void part_reduce_k(const float* part, P
   const int kb = (d.K + d.S - 1) / d.S, k0 = sp * kb, k1 = k0 + kb < d.K ? k0 + kb : d.K;
   const long rs = (long)t.NQ * t.C;
   const float* p = part + ((long)j * d.K) * rs + (long)d.q * t.C + c;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // (a dependent chain of launches waits for this kernel: every load of a thread's <= ~12 partials is in flight at once -- with 4 per
+  //  trip and up to 23 trips' worth the launch took 14 us for 7 MB)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
   int k = k0;
+  for (; k + 7 < k1; k += 8) {
+    const float v0 = p[k * rs], v1 = p[(k + 1) * rs], v2 = p[(k + 2) * rs], v3 = p[(k + 3) * rs];
+    const float v4 = p[(k + 4) * rs], v5 = p[(k + 5) * rs], v6 = p[(k + 6) * rs], v7 = p[(k + 7) * rs];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+  }
   for (; k + 3 < k1; k += 4) { s0 += p[k * rs]; s1 += p[(k + 1) * rs]; s2 += p[(k + 2) * rs]; s3 += p[(k + 3) * rs]; }
   for (; k < k1; ++k) s0 += p[k * rs];
-  if (k1 > k0) unsafeAtomicAdd(d.dst + (long)j * d.dst_stride + c, d.scale * ((s0 + s1) + (s2 + s3)));
+  if (k1 > k0) unsafeAtomicAdd(d.dst + (long)j * d.dst_stride + c, d.scale * (((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))));
 }
 static inline void part_reduce(void* stream, const float* part, PartTable& t, int n) {
   if (n == 0) return;
   int ymax = 1;
   for (int i = 0; i < n; ++i) {
     PartDesc& d = t.d[i];
-    d.S = d.K / 16; if (d.S < 1) d.S = 1; if (d.S > 32) d.S = 32;
+    d.S = d.K / 12; if (d.S < 1) d.S = 1; if (d.S > 64) d.S = 64;
     if (d.J * d.S > ymax) ymax = d.J * d.S;
   }
   hipLaunchKernelGGL(part_reduce_k, dim3((t.C + 255) / 256, ymax, n), dim3(256), 0, (hipStream_t)stream, part, t);
