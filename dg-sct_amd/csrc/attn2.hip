@@ -606,15 +606,25 @@ void tokattn_bwd2(const Ctx& ctx, const void* Yp, const void* T0pk, const void* 
 // are still in its LDS images: one pass over the inputs, no second read.
 // ====================================================================================================================
 namespace {
-constexpr int RED_BYTES = 4 * 16 * 64 * 4;     // [wave][register][lane] fp32 exchange buffer (16 KB)
+// The exchange buffer is 4 KB -- [wave][4 registers][lane] fp32, the 16 registers of a tile go through it in four trips -- and the
+// images of the probabilities that follow the reduction alias it as ONE copy for the workgroup (every wave holds the same reduced values
+// and writes the same bytes).  With the 16 KB buffer / per-wave images of the first version the SPW = 1 kernels needed 50 KB of LDS:
+// 3 workgroups per CU = 768 slots for the 800 row blocks of N = 144 (160 frames x 5) -- 1.04 rounds, i.e. two; the SPW = 2 kernels 84 KB:
+// ONE workgroup per CU, 1.25 rounds for the 320 row blocks of N = 36.  Now 38 KB (4 per CU) and 72 KB (2 per CU): one round each.
+constexpr int RED_REGS = 4;
+constexpr int RED_BYTES = 4 * RED_REGS * 64 * 4;
+static_assert(RED_BYTES >= 2 * 32 * 64, "the shared [32][32] bf16 images of P and dS alias the exchange buffer");
 __device__ __forceinline__ void wg_reduce_acc(f32x16& a, float* red, int wave, int lane) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = a[r];
-  __syncthreads();
+  for (int h = 0; h < 16 / RED_REGS; ++h) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
-    a[r] = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
-  __syncthreads();                                    // the buffer may be reused
+    for (int r = 0; r < RED_REGS; ++r) red[(wave * RED_REGS + r) * 64 + lane] = a[h * RED_REGS + r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RED_REGS; ++r)
+      a[h * RED_REGS + r] = (red[r * 64 + lane] + red[(RED_REGS + r) * 64 + lane]) + (red[(2 * RED_REGS + r) * 64 + lane] + red[(3 * RED_REGS + r) * 64 + lane]);
+    __syncthreads();                                  // the buffer may be reused
+  }
 }
 // rows of a private image += (or =) the [c][n] tiles  sum_t TFa[c][t] fa(t, n) (+ sum_t TFb[c][t] fb(t, n))
 template <bool TWO, bool RMW>
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(256) void xattn_bwd3_k(const XB2Args p) {
   const long C = p.C;
   char* img = smem + wave * SPW * IMG2;
   float* red = reinterpret_cast<float*>(smem + 4 * SPW * IMG2);
-  char* imgP = smem + 4 * SPW * IMG2 + wave * 2 * 32 * PP2;      // aliases `red` (free after the reductions)
+  char* imgP = smem + 4 * SPW * IMG2;                            // aliases `red` (free after the reductions); one copy: see RED_BYTES
   char* imgS = imgP + 32 * PP2;
   const unsigned short* Xg = p.X + ((long)b * p.N + n0) * C;
   const unsigned short* Gg = p.G + ((long)b * p.N + n0) * C;
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(256) void tokattn_bwd3_k(const TB2Args p) {
   const long C = p.C;
   char* img = smem + wave * SPW * IMG2;
   float* red = reinterpret_cast<float*>(smem + 4 * SPW * IMG2);
-  char* imgS = smem + 4 * SPW * IMG2 + wave * 32 * PP2;           // aliases `red`
+  char* imgS = smem + 4 * SPW * IMG2;                             // aliases `red`; one copy for the workgroup (RED_BYTES)
   const unsigned short* Yg = p.Yp + ((long)b * p.N + n0) * C;
   const unsigned short* thF = p.T0pk;
   const unsigned short* tlF = thF + 32 * C;
