@@ -191,3 +191,42 @@ def test_map_pool_c_abi_host_loops(emu, shape):
     assert torch.allclose(dmap.double(), rdmap[:, 0], rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         emu.map_pool_forward(7, BT, N, C, F.data_ptr(), m2.data_ptr(), pooled.data_ptr(), None)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_two_part_backward_equals_the_one_part_call(emu, name):
+    """dgsct_adapter_backward_ex2 (include/dgsct.h): HOLD_DY + ONLY_DY on the same workspace = the plain call, for every flavour (both remap
+    associations, bicubic, temporal); with dy_residual the product's epilogue adds it; the misuse cases return an error, not garbage."""
+    import ctypes as C
+    from dgsct_amd import ops
+    from dgsct_amd._lib import BwdOpts, BWD_HOLD_DY, BWD_ONLY_DY, _PP
+    from helpers import param_table, spec_of
+    fx = load_golden(name)
+    dev = torch.device("cpu")
+    r = run_library(emu, fx, dev, torch.float32, training=True)
+    spec, params, d = r["spec"], r["params"], r["desc"]
+    X, Y = fx["X"].contiguous(), fx["Y"].contiguous()
+    prep = ops.prepare(emu, spec, params, torch.float32, dev)
+    _, _, _, saved, d = ops.raw_forward(emu, spec, params, prep, X, Y, True)
+    dOut, dMap = fx["dOut"].contiguous(), fx["dMap"]
+    dTm = fx["dTmap"] if fx["dTmap"] is not None else None
+    dX, ws, grads = ops.raw_backward(emu, spec, d, params, prep, X, Y, saved, dOut, dMap, dTm, flat_out=True, hold_dy=True)
+    extra = torch.randn_like(Y)
+    dY = ops.raw_backward_dy(emu, d, params, prep, ws, Y)
+    dY2 = ops.raw_backward_dy(emu, d, params, prep, ws, Y, residual=extra)            # (the workspace is read, not consumed)
+    assert rel_err(dX, r["dX"]) < 1e-6 and rel_err(dY, r["dY"]) < 1e-6
+    assert rel_err(dY2, r["dY"] + extra) < 1e-6
+    lay = ops.grad_layout(emu, d)
+    for i, (off, n) in enumerate(lay):
+        if off >= 0 and r["grads"].get(__import__("dgsct_amd")._lib.PARAM_NAMES[i]) is not None:
+            g = r["grads"][__import__("dgsct_amd")._lib.PARAM_NAMES[i]]
+            assert rel_err(grads[off:off + n].view(g.shape), g) < 1e-6, i
+    # misuse: both parts at once; a residual for the part that does not write dY; ONLY_DY without a workspace
+    ptrs = C.cast(ops._ptrs(params), _PP)
+    def call(flags, resid=None, ws_ptr=ws.data_ptr(), dY_ptr=dY.data_ptr()):
+        o = BwdOpts(flags, resid, None, None)
+        return emu.c.dgsct_adapter_backward_ex2(C.byref(d), ptrs, prep.data_ptr(), X.data_ptr(), Y.data_ptr(), saved.data_ptr(), dOut.data_ptr(),
+                                                dMap.data_ptr(), None, dX.data_ptr(), dY_ptr, grads.data_ptr(), ws_ptr, None, None, C.byref(o))
+    assert call(BWD_HOLD_DY | BWD_ONLY_DY) != 0 and b"two parts" in emu.c.dgsct_last_error()
+    assert call(BWD_HOLD_DY, resid=extra.data_ptr()) != 0 and b"dy_residual" in emu.c.dgsct_last_error()
+    assert call(BWD_ONLY_DY, ws_ptr=None) != 0 and b"NULL" in emu.c.dgsct_last_error()

@@ -19,9 +19,10 @@ def main(path, sid, idxs):
     ks = [r for r in rows if r[2] == sid and lo <= r[0] <= hi]
     calls = []
     for r in ks:
-        if "fillBufferAligned" in r[3] or "zero2_k" in r[3]: calls.append([])
+        first_fwd = "fillBufferAligned" in r[3] or "cvt_multi_k" in r[3]
+        if (first_fwd and not (calls and len(calls[-1]) <= 2 and "cvt_multi" in short(calls[-1][0][3]))) or "zero2_k" in r[3]: calls.append([])
         if calls: calls[-1].append(r)
-    print(f"stream {sid}: {len(calls)} calls in the last step ({(hi-lo)/1e6:.1f} ms under the tracer)")
+    print(f"stream {sid}: {len(calls)} calls in the last step ({(hi-lo)/1e6:.1f} ms under the tracer); {len(ks)} kernels; first: {[short(r[3]) for r in ks[:6]]}")
     for i, cl in enumerate(calls):
         span = (cl[-1][1] - cl[0][0]) / 1e3; busy = sum(r[1] - r[0] for r in cl) / 1e3
         print(f"  call {i:3d}: {len(cl):3d} kernels  span {span:8.1f} us  kernel time {busy:8.1f} us  first {short(cl[0][3])}")
