@@ -554,7 +554,13 @@ bool gemm8_try(const Ctx& ctx, const Gemm& g) {
   if (g.m_mod > 0 || g.bias_n_bs != 0) return false;
   if ((g.r1_m == nullptr) != (g.r1_n == nullptr)) return false;
   const long kflat = (long)g.K * g.KB;
-  if (kflat % 64 || kflat < 1024 || g.K % 8) return false;
+  if (kflat % 64 || kflat < 256 || g.K % 8) return false;
+  // Short contractions (round 5): the late stages' [rows, C] x [C, C] products on 128 x 128 tiles pull every operand panel through L2
+  // 3-4 times; 256 x 192 / 256 x 256 tiles halve that and hold <= 180-640 CUs' worth of tiles in one round.  Measured alone / in the
+  // step (tools/gemm8_gate_ab.py, tools/call_overlap.py AB=gemm8=2): 23 040 x 384 x 512 26.6 -> 21.3 us, 92 160 x 192 x 256 37 -> 27 us, the
+  // batched 1024 x 192 x 576 x 160 frames 69.5 -> 54.2 us, step -0.35 ms; 40 960 x 384 x 384 loses 6 % (two column tiles of a 6-tile k-loop)
+  // and split-K weight gradients keep their 1024 gate.
+  if (mode < 2 && kflat < 1024 && (g.atomic || !(kflat >= 512 || g.N * (long)(g.batch > 1 && g.A.bs == 0 ? g.batch : 1) <= 256))) return false;
   if (g.M % G8_ROWS || g.M < G8_ROWS) return false;
   if (!g8_al16(g.A.p) || !g8_al16(g.B.p) || !g8_al16(g.D) || g.A.ld % 8 || g.B.ld % 8 || g.A.kbs % 8 || g.B.kbs % 8 || g.B.bs % 8) return false;
   if (!g.A.kmajor && g.M % 8) return false;
