@@ -15,7 +15,7 @@ def main(path, sid, idxs):
     for r in adam:
         if not ends or r[0] - ends[-1] > 20e6: ends.append(r[1])
         else: ends[-1] = r[1]
-    lo, hi = ends[-2], ends[-1]
+    lo, hi = ends[-2] - (ends[-1] - ends[-2]) * 0.6, ends[-1]          # (the forward of the last step starts before the previous Adam group's end is seen on this stream)
     ks = [r for r in rows if r[2] == sid and lo <= r[0] <= hi]
     calls = []
     for r in ks:
