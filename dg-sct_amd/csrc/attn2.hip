@@ -1060,6 +1060,15 @@ __global__ __launch_bounds__(256) void tokattn_fwd_small_k(const TFS2Args p) {
     float cs0 = 0.f, cs1 = 0.f;                                   // column sums of channels c0 + 2 lane, + 1
     Slab s;
     slab_load(s, Yb, C, p.N < 32 ? p.N : 32, c0, p.C, lane);
+    // my_tokens of this slab for the epilogue, requested NOW: they do not depend on O, and 16 L2 round trips per tile in front of each
+    // tile's stores were the largest part of the kernel on wide frames (23 of 47 us at N = 36, C = 1024: eight tiles per wave)
+    float t0s[CS2 / 32][16];
+#pragma unroll
+    for (int j = 0; j < CS2 / 32; ++j) {
+      const int c = c0 + 32 * j + (lane & 31), cj = c < p.C ? c : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const int tt = mt_row(r, lane); t0s[j][r] = p.T0[(long)(tt < p.tk ? tt : 0) * C + cj]; }
+    }
     for (int rt = 0; rt < nrt; ++rt) {
       const int rows = p.N - rt * 32 < 32 ? p.N - rt * 32 : 32;
       wave_sync();
@@ -1089,16 +1098,13 @@ __global__ __launch_bounds__(256) void tokattn_fwd_small_k(const TFS2Args p) {
     for (int j = 0; j < CS2 / 32; ++j) {
       if (j >= nt) break;
       const int c = c0 + 32 * j + (lane & 31);
-      float v[16], t0[16];
-      // unconditional loads from clamped rows, select afterwards: `tt < tk ? T0[..] : 0` compiles to branch + load +
-      // s_waitcnt vmcnt(0) PER ELEMENT (the hipcc pitfall of gemm.hip's guarded staging): 16 serial L2 round trips per
-      // tile were 30 of this kernel's 56 us at N = 144, C = 512 and 57 of 80 us at N = 36, C = 1024
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const int tt = mt_row(r, lane); t0[r] = p.T0[(long)(tt < p.tk ? tt : 0) * C + c]; }
+      float v[16];
+      // (T0 was loaded unconditionally from clamped rows above: `tt < tk ? T0[..] : 0` compiles to branch + load + s_waitcnt vmcnt(0)
+      //  PER ELEMENT -- the hipcc pitfall of gemm.hip's guarded staging)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tt = mt_row(r, lane);
-        v[r] = tt < p.tk ? t0[r] + o[j][r] * sl[tt] : 0.f;
+        v[r] = tt < p.tk ? t0s[j][r] + o[j][r] * sl[tt] : 0.f;
         if (tt < p.tk) p.tok[((long)b * p.tk + tt) * C + c] = v[r];
         const unsigned short h = f2bf(v[r]);
         // hi / lo of tok[tt][c] -> [tt][32 channels] images in the wave's (now free) slab image; whole 16-byte fragment
