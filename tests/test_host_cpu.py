@@ -628,3 +628,55 @@ def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape):
     rq = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q(OB.DEVICE_ROUNDING), masks=r["masks"])
     e = float((rq["dY"] - dY_o).norm() / dY_o.norm())
     assert 1e-4 < e < 5e-2, e
+
+
+def test_pair_node_in_eval_mode_without_grad_and_over_two_backward_passes():
+    """the one-node path of a position outside its training-step comfort zone (host-emulated library): eval mode under no_grad (BatchNorm
+    running statistics, no autograd context), a mixed stack in which one adapter of a position is not flattened (that position falls back to
+    two nodes), and two backward passes accumulating into the same flat gradients."""
+    emu = Lib(build_emu())
+    fx = load_golden("stack_2stage")
+    feats = [(a.clone(), b.clone()) for a, b in fx["feats"]]
+
+    def make(pair, flatten="all"):
+        st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4), lib=emu, concurrent=False, pair_backward=pair)
+        st.load_state_dict(fx["state0"])
+        if flatten == "all":
+            st.flatten_parameters()
+        elif flatten == "mixed":
+            for ml in (st.audio_adapter_blocks_p1, st.vis_adapter_blocks_p1, st.audio_adapter_blocks_p2):
+                for m in ml:
+                    m.flatten_parameters()
+            st.vis_adapter_blocks_p2[0].flatten_parameters()          # every other p2 visual adapter keeps its ~30 tensors
+        return st
+
+    # eval + no_grad
+    a, b = make(False).eval(), make(True).eval()
+    with torch.no_grad():
+        oa, ma = a(feats)
+        ob, mb = b(feats)
+    for (x1, y1), (x2, y2) in zip(oa, ob):
+        assert torch.equal(x1, x2) and torch.equal(y1, y2)
+    assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1], mb[1])
+
+    # mixed flattening + two accumulating passes
+    def grads_after_two_passes(st):
+        st.train()
+        for _ in range(2):
+            outs, maps = st(feats)
+            torch.autograd.backward([t for pr in outs for t in pr] + [maps[0], maps[1]],
+                                    [g for pr in fx["cots"] for g in pr] + [fx["mcots"][0], fx["mcots"][1]])
+        out = {}
+        for name, m in st.named_modules():
+            if hasattr(m, "flat_param") and "_flat_views" in m.__dict__:
+                for pn, (off, cnt, shape) in m._flat_layout.items():
+                    out[name + "." + pn] = m.flat_param.grad[off:off + cnt].view(shape).clone()
+        for k, p in st.named_parameters():
+            if p.grad is not None and not k.endswith("flat_param"):
+                out[k] = p.grad.clone()
+        return out
+    g0 = grads_after_two_passes(make(False, "mixed"))
+    g1 = grads_after_two_passes(make(True, "mixed"))
+    assert set(g0) == set(g1) and len(g0) >= len(fx["grads"])
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 1e-5, k
