@@ -597,7 +597,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     gemm(ctx, g3);
   };
   if (phase == 2) {
-    dy_product();
+    const int sk2 = (C >= g_skip_minc.load(std::memory_order_relaxed) && C <= g_skip_maxc.load(std::memory_order_relaxed)) ? g_skip.load(std::memory_order_relaxed) : 0;
+    if (!(sk2 & 2048)) dy_product();                          // (what-if switch: the remap products)
     check_async("dgsct_adapter_backward (dY product)");
     return has_error() ? 1 : 0;
   }
