@@ -289,6 +289,7 @@ int dgsct_test_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemmfx")) return gemmfx_mode(value);
   if (key && !strcmp(key, "g8pipe")) return dgsct::gemm8_pipe_mode(value);
   if (key && !strcmp(key, "g8wg")) return dgsct::gemm8_wg_target(value);
+  if (key && !strcmp(key, "wgbt")) return dgsct::wgrad_bt_mode(value);
   if (key && !strcmp(key, "cfgx")) return dgsct::gemm_cfgx_mode(value);
   if (key && !strcmp(key, "noatomic")) return dgsct::gemm_noatomic_mode(value);
   if (key && !strcmp(key, "skipmaxc")) return dgsct::plan_skip_maxc(value);

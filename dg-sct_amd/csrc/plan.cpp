@@ -826,6 +826,7 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   }
   }
   // B6 ---- channel-gate head
+  bool wgbt = false;
   {
     const MatOp wcattT = b.WB(DGSCT_P_WCATT, dd, C), wbT = b.WB(DGSCT_P_WB, C, dd);
     // the chain's four launches (sigmoid', dq, dm1, its two consumers) as two products with the elementwise parts folded in
@@ -835,7 +836,14 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g1 = mk(C, dd, B);                                      // dWcatt = dpre^T . q
     g1.A = mn(b.Wk(wb.dpre_c), C); g1.B = mn(b.S(s.q), dd);
     outF(g1, G(DGSCT_P_WCATT), dd);
-    defer([=, &side] { wgemm(side, g1); });
+    // (round 5) the four weight gradients that contract over the frames only -- dWcatt, dWb here, dWa1, dWa2 in B4 -- as ONE launch
+    // (gemm_wgbt.hip) instead of four 2-3-workgroup launches of the tiled engine
+    WgBtJob wj[WGBT_MAX] = {{b.Wk(wb.dpre_c), b.S(s.q), G(DGSCT_P_WCATT), C, dd, B, C, dd, dd},
+                            {b.Wk(wb.dq), b.S(s.m1), G(DGSCT_P_WB), dd, C, B, dd, C, C},
+                            {b.Wk(wb.dpa1), b.S(s.aE), G(DGSCT_P_WA1), C, C, B, C, C, C},
+                            {b.Wk(wb.dpa2), b.S(s.aE), G(DGSCT_P_WA2), dd, C, B, dd, C, C}};
+    wgbt = wgrad_bt_supported(side, wj, 4);
+    if (!wgbt) defer([=, &side] { wgemm(side, g1); });
     if (skf) {                                                   // dq = (dpre . Wcatt) * (q > 0), dpre = dch ch (1 - ch) made (and stored) on the way in
       SkFuse f; f.M = B; f.N = dd; f.K = C;
       f.a_mode = 2; f.A = b.Wk(wb.dch); f.lda = C; f.a_mul = b.S<float>(s.ch); f.ld_mul = C; f.a_store = b.Wk(wb.dpre_c); f.ld_store = C;
@@ -853,7 +861,8 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g3 = mk(dd, C, B);                                      // dWb = dq^T . m1
     g3.A = mn(b.Wk(wb.dq), dd); g3.B = mn(b.S(s.m1), C);
     outF(g3, G(DGSCT_P_WB), C);
-    defer([=, &side] { wgemm(side, g3); });
+    if (!wgbt) defer([=, &side] { wgemm(side, g3); });
+    else defer([=, &side] { if (!(SK & 1)) wgrad_bt(side, wj, 4); });      // (its operands dpa1 / dpa2 exist by the flush in B4)
     if (skf) {                                                   // dm1 = dq . Wb -> dpa1 = dm1 mvq1 (aq1 > 0), coef = dm1 aq1 from the epilogue
       SkFuse f; f.M = B; f.N = C; f.K = dd;
       f.A = b.Wk(wb.dq); f.lda = dd; f.B = wbT.p; f.ldb = wbT.ld; f.b_kmajor = wbT.kmajor;
@@ -928,12 +937,12 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
     Gemm g1 = mk(C, C, B);                                       // dWa1 = dpa1^T . a
     g1.A = mn(b.Wk(wb.dpa1), C); g1.B = mn(b.S(s.aE), C);
     outF(g1, G(DGSCT_P_WA1), C);
-    defer([=, &side] { wgemm(side, g1); });
+    if (!wgbt) defer([=, &side] { wgemm(side, g1); });
     Gemm g2 = mk(dd, C, B);                                      // dWa2 = dpa2^T . a
     g2.A = mn(b.Wk(wb.dpa2), dd); g2.B = mn(b.S(s.aE), C);
     outF(g2, G(DGSCT_P_WA2), C);
     defer([=, &side, &b] {
-      wgemm(side, g2);
+      if (!wgbt) wgemm(side, g2);
       // the four bias gradients of the gate MLPs + d fc_affine_v_s_att.weight: column sums of [BT][C] matrices, one launch
       ColsumSeg segs[7] = {{b.Wk(wb.dpre_c), E, B, C, G(DGSCT_P_BCATT)}, {b.Wk(wb.dq), E, B, dd, G(DGSCT_P_BB)},
                            {b.Wk(wb.dpa1), E, B, C, G(DGSCT_P_BA1)}, {b.Wk(wb.dpa2), E, B, dd, G(DGSCT_P_BA2)},

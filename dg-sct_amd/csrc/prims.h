@@ -315,6 +315,14 @@ void gemm_fp8(const Ctx&, int M, int N, int K, const void* A, long lda, const vo
 // tok fp32 [B][tk][C] = T0 + softmax_N(T0 Yp^T) Yp;  lse fp32 [B][tk] = log sum_n exp(logit);  a fp32 [B][C] = mean_N Yp
 // (a must be pre-zeroed; aE: optional copy of a in E);  scratch: tokattn_scratch_floats(B, N, C) floats.  tk <= 32.
 long tokattn_scratch_floats(int B, int N, int C);
+// ---- the frame-deep weight gradients of the gate MLPs as one launch (gemm_wgbt.hip): D[m][n] = sum_{k < K} A[k][m] * B[k][n], A / B bf16
+// [K][lda / ldb] (MN-major), D fp32 [M][ldd], overwritten; up to WGBT_MAX problems per launch
+constexpr int WGBT_MAX = 4;
+struct WgBtJob { const void* A; const void* B; float* D; int M, N, K; long lda, ldb, ldd; };
+bool wgrad_bt_supported(const Ctx&, const WgBtJob* jobs, int n);
+void wgrad_bt(const Ctx&, const WgBtJob* jobs, int n);
+int wgrad_bt_mode(int set);
+
 // tokpk (optional, bf16 mode): the latent tokens PACKED for the wave-centric fast kernels (attn2.hip): per frame
 // [hi 32 x C | lo 32 x C | transposed C x 32] bf16 = tok_pack_elems(B, C) elements; consumers fall back to the generic
 // kernels when it is null.

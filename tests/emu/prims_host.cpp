@@ -44,6 +44,20 @@ void event_wait(const Ctx&, void*) {}
 void check_async(const char*) {}
 void clear_async() {}
 int gemm_skinny_mode(int) { return 0; }
+static int g_wgbt = 1;
+int wgrad_bt_mode(int set) { const int old = g_wgbt; if (set >= 0) g_wgbt = set ? 1 : 0; return old; }
+bool wgrad_bt_supported(const Ctx&, const WgBtJob*, int n) { return g_wgbt && n >= 1 && n <= WGBT_MAX; }
+void wgrad_bt(const Ctx& ctx, const WgBtJob* jobs, int n) {          // (either element type: the host loops read through ld())
+  for (int i = 0; i < n; ++i) {
+    const WgBtJob& j = jobs[i];
+    for (int m = 0; m < j.M; ++m)
+      for (int c = 0; c < j.N; ++c) {
+        double s = 0;
+        for (int k = 0; k < j.K; ++k) s += (double)ld(j.A, ctx.mode, (long)k * j.lda + m) * (double)ld(j.B, ctx.mode, (long)k * j.ldb + c);
+        j.D[(long)m * j.ldd + c] = (float)s;
+      }
+  }
+}
 int gemm_tall_mode(int) { return 0; }
 int gemm8_mode(int) { return 0; }                 // (the 8-wave GEMM kernel is a device-side choice: nothing to emulate)
 int gemm_noatomic_mode(int) { return 0; }

@@ -644,3 +644,47 @@ def test_forward_gemm_epilogues_equal_the_reductions_they_replace(shape, BT):
     for k in ("bn1", "bn2", "rm2", "rv1"):
         assert _l2(b[k], a[k]) < 2e-4, (k, _l2(b[k], a[k]))                      # (mean | rstd | scale | shift) from sums with another shift
     assert _l2(b["out"], a["out"]) < 4e-3 and _l2(b["map"], a["map"]) < 1e-3, (_l2(b["out"], a["out"]), _l2(b["map"], a["map"]))
+
+
+@pytest.mark.parametrize("shape,BT", [((2304, 128, 4096, 96), 4), ((4096, 96, 2304, 128), 3), ((576, 256, 1024, 192), 10), ((144, 512, 256, 384), 160),
+                                      ((36, 1024, 64, 768), 20), ((64, 768, 36, 1536), 7)])
+def test_grouped_frame_deep_weight_gradients_equal_the_four_launches(shape, BT):
+    """round 5, csrc/gemm_wgbt.hip: d fc_affine_v_c_att / _bottleneck / _audio_1 / _audio_2 .weight -- the four weight gradients that contract
+    over the frames only -- as one launch of 64 x 64 tiles against the four tiled-engine launches ("wgbt" = 0) on the same saved activations:
+    same bf16 operands, fp32 accumulation either way -> equal to summation order; widths that are not multiples of 64 (C / 2 = 48), frame
+    counts that are not multiples of 16 or 64 (3, 7, 20, 160)."""
+    N, C, No, Co = shape
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS["ave"]})
+    p = O.random_params(cfg, "ave", seed=5, scale=0.577)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(31)
+    X = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    Y = torch.randn(BT, No, Co, generator=gen).to(DEV, dtype).contiguous()
+    dOut = torch.randn(BT, N, C, generator=gen).to(DEV, dtype).contiguous()
+    dMap = torch.randn(BT, N, generator=gen).to(DEV)
+    params = param_table({k: v.clone() for k, v in p.items()}, spec, DEV)
+    prep = ops.prepare(lib, spec, params, dtype, DEV)
+    out, amap, tmap, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+    torch.cuda.synchronize()
+    res = {}
+    old = lib.test_tune("wgbt", -1)
+    assert old == 1
+    try:
+        for mode in (0, 1):
+            lib.test_tune("wgbt", mode)
+            _, _, grads = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved.clone(), dOut, dMap, None)
+            torch.cuda.synchronize()
+            res[mode] = {n: g.clone() for n, g in zip(PARAM_NAMES, grads) if g is not None}
+    finally:
+        lib.test_tune("wgbt", old)
+    names = ("fc_affine_v_c_att.weight", "fc_affine_bottleneck.weight", "fc_affine_audio_1.weight", "fc_affine_audio_2.weight")
+    for n in names:
+        a, b = res[1][n], res[0][n]
+        assert torch.isfinite(a).all() and b.float().norm() > 0
+        # (the two backward passes are separate runs: dpa2 / dpre carry the run-to-run noise of the atomically summed `u` / `dch`, ~1e-4)
+        assert _l2(a, b) < 1e-3, (n, _l2(a, b))
+    for n in res[0]:                                   # ... and nothing else moved (same forward, same chain)
+        if n not in names and res[0][n].float().norm() > 0 and n not in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias", "gate", "gate_av"):
+            assert _l2(res[1][n], res[0][n]) < 2e-3, (n, _l2(res[1][n], res[0][n]))
