@@ -683,8 +683,10 @@ def test_grouped_frame_deep_weight_gradients_equal_the_four_launches(shape, BT):
     for n in names:
         a, b = res[1][n], res[0][n]
         assert torch.isfinite(a).all() and b.float().norm() > 0
-        # (the two backward passes are separate runs: dpa2 / dpre carry the run-to-run noise of the atomically summed `u` / `dch`, ~1e-4)
-        assert _l2(a, b) < 1e-3, (n, _l2(a, b))
+        # (the two backward passes are separate runs: the operands dpa2 / dpre are ROUNDED products of the atomically summed `u` / `dch`, whose
+        #  last-bit run-to-run noise moves a few of their bf16 roundings by one ulp (2^-9): ~1e-4 at 160 frames, up to ~1e-3 at 3 frames x 48
+        #  channels -- seen once in ~30 runs of the suite at a 1e-3 bound.  A wrong tile or a dropped frame is an O(1) error.)
+        assert _l2(a, b) < 4e-3, (n, _l2(a, b))
     for n in res[0]:                                   # ... and nothing else moved (same forward, same chain)
         if n not in names and res[0][n].float().norm() > 0 and n not in ("ln_before.bias", "fc_affine_v_s_att.bias", "fc.bias", "gate", "gate_av"):
-            assert _l2(res[1][n], res[0][n]) < 2e-3, (n, _l2(res[1][n], res[0][n]))
+            assert _l2(res[1][n], res[0][n]) < 8e-3, (n, _l2(res[1][n], res[0][n]))     # (two runs: atomically summed statistics, as in the test above)
