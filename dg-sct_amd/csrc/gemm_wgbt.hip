@@ -16,6 +16,7 @@
 #include "device_util.h"
 #include "mma_tile.h"
 #include "err.h"
+#include "gemm_int.h"
 
 namespace dgsct {
 
@@ -112,7 +113,16 @@ void wgrad_bt(const Ctx& ctx, const WgBtJob* jobs, int n) {
     }
   }
   t.tile0[WGBT_MAX] = tiles;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    flops += 2.0 * jobs[i].M * (double)jobs[i].N * (double)jobs[i].K;
+    bytes += 2.0 * jobs[i].K * ((double)jobs[i].M + (double)jobs[i].N) + 4.0 * jobs[i].M * (double)jobs[i].N;
+  }
+  // (logged with the GEMM family -- bench.py's roofline block counts its FLOPs and its time -- under the first problem's shape, cfg 12)
+  GemmProfShape shp{jobs[0].M, jobs[0].N, jobs[0].K, 1, n, 1, 12, 0, 0, 0, 0, bytes};
+  void* rec = gemm_prof_begin(ctx.stream, flops, shp);
   hipLaunchKernelGGL(wgrad_bt_k, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)ctx.stream, t);
+  gemm_prof_end(rec, ctx.stream);
 }
 
 }  // namespace dgsct

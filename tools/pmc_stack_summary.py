@@ -14,7 +14,7 @@ COUNT = {(2304, 128, 4096, 96): 4, (4096, 96, 2304, 128): 4, (576, 256, 1024, 19
 
 
 def fam(name):
-    if "gemm_kernel" in name or "gemm8_kernel" in name or "gemm_fx_kernel" in name:      # both MFMA GEMM kernels (4-wave tiled engine, 8-wave deep-product kernel)
+    if "gemm_kernel" in name or "gemm8_kernel" in name or "gemm_fx_kernel" in name or "wgrad_bt_k" in name:      # both MFMA GEMM kernels (4-wave tiled engine, 8-wave deep-product kernel)
         return "gemm_kernel<*>"
     name = re.sub(r"^void ", "", name).replace("dgsct::", "").replace("(anonymous namespace)::", "")
     return re.sub(r"[<(].*", "", name)

@@ -26,7 +26,7 @@ def main(path, top=40, gemm_json=None, steps=None):
     # family roll-up
     fam = {}
     for name, n, tot, mn, mx in rows:
-        k = "gemm_kernel<*>" if ("gemm_kernel" in name or "gemm8_kernel" in name or "gemm_fx_kernel" in name) else ("torch/other" if "dgsct" not in name else re.sub(r"<.*", "", short(name)))
+        k = "gemm_kernel<*>" if ("gemm_kernel" in name or "gemm8_kernel" in name or "gemm_fx_kernel" in name or "wgrad_bt_k" in name) else ("torch/other" if "dgsct" not in name else re.sub(r"<.*", "", short(name)))
         a = fam.setdefault(k, [0, 0])
         a[0] += n; a[1] += tot
     if gemm_json and steps:
@@ -39,7 +39,7 @@ def main(path, top=40, gemm_json=None, steps=None):
                    "setup_dispatches_excluded": setup,
                    "steps_traced": steps,
                    "source": "rocprofv3 --kernel-trace of `python bench.py --steps 5 --warmup 2 --no-roofline --no-cpu-baseline` "
-                             "(7 steps under the timed two-stream schedule); gemm = gemm_kernel<*> + gemm8_kernel<*> + gemm_fx_kernel<*>"}, open(gemm_json, "w"))
+                             "(7 steps under the timed two-stream schedule); gemm = gemm_kernel<*> + gemm8_kernel<*> + gemm_fx_kernel<*> + wgrad_bt_k"}, open(gemm_json, "w"))
     print("# by family")
     for k, (n, tot) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         print(f"{n:7d} {tot/1e6:10.3f} {tot/n/1e3:9.2f} {'':8} {'':9} {100*tot/total:6.2f}  {k}")
