@@ -11,7 +11,8 @@ gradient at every AVE width (5.9 % against the fp32 oracle at C = 1024), which i
 
 How it is pinned.  `evaluate(..., Q([]))` (nothing rounded) must equal `dgsct_oracle.forward / backward` -- asserted on CPU by
 `tests/test_host_cpu.py::test_rounding_aware_oracle_without_rounding_is_the_oracle` -- and that oracle is pinned against vectors generated
-by the reference itself (oracle/make_golden.py).  Only the 'ave' flavour (conv remap; every BASELINE config) is restated here.
+by the reference itself (oracle/make_golden.py).  Restated here: the 'ave' / 'avvp' flavour (conv remap; every BASELINE config) and the AVS
+flavours' differences (bicubic remap operator, no ln_before, gate in front of ln_post); not the temporal gate of 'pretrain', not eval-mode BN.
 
 Names of the rounding points: W:<weight> bf16 weight copies; T, Yp remap intermediate / result; T0 my_tokens; P1, P2 the two softmaxes;
 tok latent tokens (tokS: as the logit operand, tokV: as the value operand); X1 (X1m: the copy the modulation reads), aE, aq, vq1, m1, q,
@@ -38,7 +39,8 @@ class Q:
         if name in self.names or '*' in self.names and ('-'+name) not in self.names: return x.bfloat16().float()
         return x
 def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
-    """forward + backward of the 'ave'-flavour adapter (conv remap, ln_before, BatchNorm in training mode) with `q(name, tensor)` applied at
+    """forward + backward of the adapter (cfg.remap conv | bicubic, cfg.ln_before, cfg.gate_before_ln_post; BatchNorm in training mode, no
+    temporal gate) with `q(name, tensor)` applied at
     every tensor the bf16 schedule stores or feeds to an MFMA; masks: pinned ReLU decisions (keys aq1, aq2, vq1, q, vq2, Z) or None.
     Returns dict(out, map, dX, dY, g = {parameter name: gradient}, masks = the ReLU decisions used)."""
     B,N,C = X.shape; R=B*N
@@ -49,8 +51,14 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
         return m
     relu = lambda name, x: x * M(name, x)
     W = lambda n: q('W:'+n.replace('fc_affine_','').replace('.weight',''), p[n])    # bf16 weight copies
-    Wc,bc = p['fc.weight'],p['fc.bias']; Wn = p['conv_adapter.weight'].reshape(N,cfg.No); bn = p['conv_adapter.bias']
-    rowb,colb,colb2 = bn, Wc.sum(1), bc
+    Wc,bc = p['fc.weight'],p['fc.bias']
+    conv = cfg.remap == 'conv'
+    if conv:
+        Wn = p['conv_adapter.weight'].reshape(N,cfg.No); bn = p['conv_adapter.bias']
+        rowb,colb,colb2 = bn, Wc.sum(1), bc
+    else:                                          # AVS-S4: fc, then the fixed bicubic operator (dgsct_oracle.forward, F1)
+        Wn = p['_bicubic']; bn = None
+        rowb,colb,colb2 = Wn.sum(1), bc, torch.zeros_like(bc)
     order = cfg.remap_order()
     if order=='A':
         T1 = q('T', torch.einsum('mn,bnk->bmk', q('W:Wn',Wn), Y)); Yp = T1 @ q('W:Wc',Wc).t()
@@ -79,7 +87,11 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
     sl = (vq2*(aq2*ws)[:,None,:]).sum(-1)+bs; sg = torch.sigmoid(sl); amap = torch.softmax(torch.tanh(sl),-1)
     mod = cfg.alpha*ch[:,None,:] + cfg.beta*sg[:,:,None] + (1-cfg.alpha)
     X2 = X1m*mod
-    X3f, xh_b, rstd_b = O._ln(X2, p['ln_before.weight'], p['ln_before.bias'], cfg.eps); X3 = q('X3',X3f)
+    if cfg.ln_before:
+        X3f, xh_b, rstd_b = O._ln(X2, p['ln_before.weight'], p['ln_before.bias'], cfg.eps)
+    else:
+        X3f = X2
+    X3 = q('X3',X3f)
     Wd = p['down_sampler.weight'].reshape(cfg.ds, C//cfg.g); Wu = p['up_sampler.weight'].reshape(C, cfg.ds//cfg.g)
     Zp = q('Zp', O._groupmm(X3, q('W:Wd',Wd), cfg.g))
     def bn_(x,name):
@@ -88,12 +100,19 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
     Zb,zh,rstd1 = bn_(Zp,'bn1'); Z = q('Z',relu('Z', Zb))
     Op = q('Op', O._groupmm(Z, q('W:Wu',Wu), cfg.g))
     Oo,oh,rstd2 = bn_(Op,'bn2')
-    L,xh_p,rstd_p = O._ln(Oo, p['ln_post.weight'], p['ln_post.bias'], cfg.eps)
-    gate = p['gate']; out = q('out', L*gate)
-    # ---- backward
+    gate = p['gate']
     g={}
-    g['gate']=(dOut*L).sum().reshape(1); dL = dOut*gate
-    dO,g['ln_post.weight'],g['ln_post.bias'] = O._ln_bwd(dL,xh_p,rstd_p,p['ln_post.weight']); dO = q('dO',dO)
+    if cfg.gate_before_ln_post:                    # AVS order: gate, then ln_post (dgsct_oracle.forward F11 / backward B11)
+        G = Oo*gate
+        L,xh_p,rstd_p = O._ln(G, p['ln_post.weight'], p['ln_post.bias'], cfg.eps); out = q('out', L)
+        dG,g['ln_post.weight'],g['ln_post.bias'] = O._ln_bwd(dOut,xh_p,rstd_p,p['ln_post.weight'])
+        g['gate'] = (dG*Oo).sum().reshape(1)       # (a cancellation residue: not compared)
+        dO = q('dO', dG*gate)
+    else:
+        L,xh_p,rstd_p = O._ln(Oo, p['ln_post.weight'], p['ln_post.bias'], cfg.eps)
+        out = q('out', L*gate)
+        g['gate']=(dOut*L).sum().reshape(1); dL = dOut*gate
+        dO,g['ln_post.weight'],g['ln_post.bias'] = O._ln_bwd(dL,xh_p,rstd_p,p['ln_post.weight']); dO = q('dO',dO)
     def bn_bwd(dy,xh,rstd,name):
         w=p[name+'.weight']; dyf,xhf=dy.reshape(R,-1),xh.reshape(R,-1); dw=(dyf*xhf).sum(0); db=dyf.sum(0)
         g[name+'.weight'],g[name+'.bias']=dw,db
@@ -102,7 +121,10 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
     dZ,dWu = O._groupmm_bwd(dOp,Z,q('W:Wu',Wu),cfg.g); g['up_sampler.weight']=dWu.reshape(p['up_sampler.weight'].shape); dZ=q('dZ',dZ)
     dZb = dZ*used['Z']; dZp = q('dZ', bn_bwd(dZb,zh,rstd1,'bn1'))
     dX3,dWd = O._groupmm_bwd(dZp,X3,q('W:Wd',Wd),cfg.g); g['down_sampler.weight']=dWd.reshape(p['down_sampler.weight'].shape); dX3=q('dX3',dX3)
-    dX2,g['ln_before.weight'],g['ln_before.bias'] = O._ln_bwd(dX3,xh_b,rstd_b,p['ln_before.weight'])
+    if cfg.ln_before:
+        dX2,g['ln_before.weight'],g['ln_before.bias'] = O._ln_bwd(dX3,xh_b,rstd_b,p['ln_before.weight'])
+    else:
+        dX2 = dX3
     dX1 = q('dX1', dX2*mod); dmod = dX2*X1m
     dch = cfg.alpha*dmod.sum(1); dsg = cfg.beta*dmod.sum(2)
     dsl = dsg*sg*(1-sg); dt = amap*(dMap-(amap*dMap).sum(-1,keepdim=True)); dsl = dsl + dt*(1-torch.tanh(sl)**2)
@@ -133,11 +155,15 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
     dS1 = q('dS1', P1*(dP1-(P1*dP1).sum(-1,keepdim=True)))
     g['my_tokens'] = dtok.sum(0) + torch.einsum('btn,bnc->tc',dS1,Yp)
     dYp = q('dYp', P1.transpose(1,2)@dtokE + torch.einsum('btn,tc->bnc',dS1,q('T0',T0)) + (da/N)[:,None,:])
-    wcsum = Wc.sum(1)
-    g['fc.bias']=dYp.sum((0,1)); g['conv_adapter.bias']=torch.einsum('bmc,c->m',dYp,wcsum); dwcsum=torch.einsum('bmc,m->c',dYp,bn)
+    if conv:
+        wcsum = Wc.sum(1)
+        g['fc.bias']=dYp.sum((0,1)); g['conv_adapter.bias']=torch.einsum('bmc,c->m',dYp,wcsum); dwcsum=torch.einsum('bmc,m->c',dYp,bn)
+    else:
+        g['fc.bias']=torch.einsum('bmc,m->c',dYp,Wn.sum(1)); dwcsum=None
     if order=='A':
         dT1 = q('dT', dYp @ q('W:Wc',Wc)); dWc = torch.einsum('bmc,bmk->ck',dYp,T1); dY = torch.einsum('mn,bmk->bnk',q('W:Wn',Wn),dT1); dWn = torch.einsum('bmk,bnk->mn',dT1,Y)
     else:
         dT2t = q('dT', torch.einsum('bmc,mn->bcn',dYp,q('W:Wn',Wn))); dWn = torch.einsum('bmc,bcn->mn',dYp,T2t); dY = torch.einsum('bcn,ck->bnk',dT2t,q('W:Wc',Wc)); dWc = torch.einsum('bcn,bnk->ck',dT2t,Y)
-    g['fc.weight']=dWc+dwcsum[:,None]; g['conv_adapter.weight']=dWn
+    g['fc.weight']=dWc+dwcsum[:,None] if dwcsum is not None else dWc
+    if conv: g['conv_adapter.weight']=dWn
     return dict(out=out,map=amap,dX=dX,dY=q('dY',dY),g=g,masks=used)

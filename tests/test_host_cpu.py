@@ -599,8 +599,9 @@ def test_cpu_baseline_port_matches_the_explicit_oracle(flavour, over):
     assert rel_err(Xa.grad, dX_o) < 1e-4 and rel_err(Ya.grad, dY_o) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(12, 32, 20, 48), (20, 48, 12, 32)], ids=["orderA_or_B", "swapped"])
-def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape):
+@pytest.mark.parametrize("flavour", ["ave", "avs_s4", "avs_ms3"])
+@pytest.mark.parametrize("shape", [(16, 32, 36, 48), (36, 48, 16, 32)], ids=["orderA_or_B", "swapped"])
+def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape, flavour):
     """oracle/dgsct_oracle_bf16.evaluate() -- the oracle's arithmetic with a switchable bf16 rounding at every tensor the bf16 schedule
     stores, the yardstick of tests/test_bf16_masked_gpu.py -- is pinned here: with nothing rounded it must reproduce the (reference-pinned)
     oracle's forward and backward exactly, on its own ReLU decisions and on pinned ones; with the device's rounding points switched on it
@@ -609,8 +610,10 @@ def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape):
     from oracle import dgsct_oracle_bf16 as OB
     N, C, No, Co = shape
     BT = 3
-    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=4, r=8, g=2), **O.FLAVOURS["ave"]})
-    p = O.random_params(cfg, "ave", seed=3, scale=0.577)
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=4, r=8, g=2), **O.FLAVOURS[flavour]})
+    p = O.random_params(cfg, flavour, seed=3, scale=0.577)
+    if cfg.remap == "bicubic":
+        p["_bicubic"] = O.bicubic_matrix(No, N)
     gen = torch.Generator().manual_seed(4)
     X, Y = torch.randn(BT, N, C, generator=gen), torch.randn(BT, No, Co, generator=gen)
     dOut, dMap = torch.randn(BT, N, C, generator=gen), torch.randn(BT, N, generator=gen)
@@ -621,6 +624,8 @@ def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape):
     assert rel_err(r["dX"], dX_o) < 1e-5 and rel_err(r["dY"], dY_o) < 1e-5
     assert set(r["g"]) == {k for k, v in g_o.items() if v is not None}
     for k, g in r["g"].items():
+        if k == "gate" and cfg.gate_before_ln_post:
+            continue                         # (LN(gate * O): analytically ~0, the oracle evaluates this one residue in float64)
         assert rel_err(g.reshape(g_o[k].shape), g_o[k]) < 2e-5, k
     # pinned decisions (its own, fed back in): the same evaluation
     r2 = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q([]), masks=r["masks"])
