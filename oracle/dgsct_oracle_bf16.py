@@ -12,7 +12,8 @@ gradient at every AVE width (5.9 % against the fp32 oracle at C = 1024), which i
 How it is pinned.  `evaluate(..., Q([]))` (nothing rounded) must equal `dgsct_oracle.forward / backward` -- asserted on CPU by
 `tests/test_host_cpu.py::test_rounding_aware_oracle_without_rounding_is_the_oracle` -- and that oracle is pinned against vectors generated
 by the reference itself (oracle/make_golden.py).  Restated here: the 'ave' / 'avvp' flavour (conv remap; every BASELINE config) and the AVS
-flavours' differences (bicubic remap operator, no ln_before, gate in front of ln_post); not the temporal gate of 'pretrain', not eval-mode BN.
+flavours' differences (bicubic remap operator, no ln_before, gate in front of ln_post), the temporal gate of 'pretrain', 'avqa' without
+BatchNorm; not eval-mode BN.
 
 Names of the rounding points: W:<weight> bf16 weight copies; T, Yp remap intermediate / result; T0 my_tokens; P1, P2 the two softmaxes;
 tok latent tokens (tokS: as the logit operand, tokV: as the value operand); X1 (X1m: the copy the modulation reads), aE, aq, vq1, m1, q,
@@ -38,9 +39,9 @@ class Q:
     def __call__(self, name, x):
         if name in self.names or '*' in self.names and ('-'+name) not in self.names: return x.bfloat16().float()
         return x
-def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
-    """forward + backward of the adapter (cfg.remap conv | bicubic, cfg.ln_before, cfg.gate_before_ln_post; BatchNorm in training mode, no
-    temporal gate) with `q(name, tensor)` applied at
+def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None,dTmap=None):
+    """forward + backward of the adapter (cfg.remap conv | bicubic, cfg.ln_before, cfg.gate_before_ln_post, cfg.temporal, cfg.use_bn; BatchNorm
+    in training mode) with `q(name, tensor)` applied at
     every tensor the bf16 schedule stores or feeds to an MFMA; masks: pinned ReLU decisions (keys aq1, aq2, vq1, q, vq2, Z) or None.
     Returns dict(out, map, dX, dY, g = {parameter name: gradient}, masks = the ReLU decisions used)."""
     B,N,C = X.shape; R=B*N
@@ -86,6 +87,10 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
     ws,bs = p['fc_affine_v_s_att.weight'].reshape(-1), p['fc_affine_v_s_att.bias']
     sl = (vq2*(aq2*ws)[:,None,:]).sum(-1)+bs; sg = torch.sigmoid(sl); amap = torch.softmax(torch.tanh(sl),-1)
     mod = cfg.alpha*ch[:,None,:] + cfg.beta*sg[:,:,None] + (1-cfg.alpha)
+    tg = None
+    if cfg.temporal:                               # pretrain flavour (dgsct_oracle.forward: temporal gate), fp32 on the device
+        wt, bt = p['temporal_gated.0.weight'].reshape(-1), p['temporal_gated.0.bias']
+        tg = torch.sigmoid(a @ wt + bt); mod = mod + cfg.gamma*tg[:,None,None]
     X2 = X1m*mod
     if cfg.ln_before:
         X3f, xh_b, rstd_b = O._ln(X2, p['ln_before.weight'], p['ln_before.bias'], cfg.eps)
@@ -97,9 +102,9 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
     def bn_(x,name):
         w,b = p[name+'.weight'],p[name+'.bias']; xf=x.reshape(R,-1); mu=xf.mean(0); var=((xf-mu)**2).mean(0); rstd=torch.rsqrt(var+cfg.eps); xh=(x-mu)*rstd
         return xh*w+b, xh, rstd
-    Zb,zh,rstd1 = bn_(Zp,'bn1'); Z = q('Z',relu('Z', Zb))
+    Zb,zh,rstd1 = bn_(Zp,'bn1') if cfg.use_bn else (Zp,None,None); Z = q('Z',relu('Z', Zb))
     Op = q('Op', O._groupmm(Z, q('W:Wu',Wu), cfg.g))
-    Oo,oh,rstd2 = bn_(Op,'bn2')
+    Oo,oh,rstd2 = bn_(Op,'bn2') if cfg.use_bn else (Op,None,None)
     gate = p['gate']
     g={}
     if cfg.gate_before_ln_post:                    # AVS order: gate, then ln_post (dgsct_oracle.forward F11 / backward B11)
@@ -117,9 +122,9 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
         w=p[name+'.weight']; dyf,xhf=dy.reshape(R,-1),xh.reshape(R,-1); dw=(dyf*xhf).sum(0); db=dyf.sum(0)
         g[name+'.weight'],g[name+'.bias']=dw,db
         return w*rstd*(dy-db/R-xh*(dw/R))
-    dOp = q('dO', bn_bwd(dO,oh,rstd2,'bn2'))
+    dOp = q('dO', bn_bwd(dO,oh,rstd2,'bn2')) if cfg.use_bn else dO
     dZ,dWu = O._groupmm_bwd(dOp,Z,q('W:Wu',Wu),cfg.g); g['up_sampler.weight']=dWu.reshape(p['up_sampler.weight'].shape); dZ=q('dZ',dZ)
-    dZb = dZ*used['Z']; dZp = q('dZ', bn_bwd(dZb,zh,rstd1,'bn1'))
+    dZb = dZ*used['Z']; dZp = q('dZ', bn_bwd(dZb,zh,rstd1,'bn1')) if cfg.use_bn else q('dZ', dZb)
     dX3,dWd = O._groupmm_bwd(dZp,X3,q('W:Wd',Wd),cfg.g); g['down_sampler.weight']=dWd.reshape(p['down_sampler.weight'].shape); dX3=q('dX3',dX3)
     if cfg.ln_before:
         dX2,g['ln_before.weight'],g['ln_before.bias'] = O._ln_bwd(dX3,xh_b,rstd_b,p['ln_before.weight'])
@@ -127,6 +132,14 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
         dX2 = dX3
     dX1 = q('dX1', dX2*mod); dmod = dX2*X1m
     dch = cfg.alpha*dmod.sum(1); dsg = cfg.beta*dmod.sum(2)
+    da_t = None
+    if cfg.temporal:
+        dtg = cfg.gamma*dmod.sum((1,2))
+        if dTmap is not None: dtg = dtg + dTmap
+        dpre_t = dtg*tg*(1-tg)
+        g['temporal_gated.0.weight'] = (dpre_t[:,None]*a).sum(0).reshape(p['temporal_gated.0.weight'].shape)
+        g['temporal_gated.0.bias'] = dpre_t.sum().reshape(1)
+        da_t = dpre_t[:,None]*wt[None,:]
     dsl = dsg*sg*(1-sg); dt = amap*(dMap-(amap*dMap).sum(-1,keepdim=True)); dsl = dsl + dt*(1-torch.tanh(sl)**2)
     u = (dsl[:,:,None]*vq2).sum(1); g['fc_affine_v_s_att.bias']=dsl.sum().reshape(1); g['fc_affine_v_s_att.weight']=(u*aq2).sum(0)
     daq2 = u*ws
@@ -145,6 +158,7 @@ def evaluate(cfg,p,X,Y,dOut,dMap,q,masks=None):
     dpa1 = q('dpre', daq1*used['aq1']); dpa2 = q('dpre', daq2*used['aq2'])
     g['fc_affine_audio_1.weight']=dpa1.t()@aE; g['fc_affine_audio_1.bias']=dpa1.sum(0); g['fc_affine_audio_2.weight']=dpa2.t()@aE; g['fc_affine_audio_2.bias']=dpa2.sum(0)
     da = dpa1 @ W('fc_affine_audio_1.weight') + dpa2 @ W('fc_affine_audio_2.weight')
+    if da_t is not None: da = da + da_t
     U = dX1 @ q('tokS',tok).transpose(1,2)
     g['gate_av']=(P2*U).sum().reshape(1); dP2 = gav*U
     dS2 = q('dS2', P2*(dP2-(P2*dP2).sum(-1,keepdim=True)))

@@ -599,8 +599,8 @@ def test_cpu_baseline_port_matches_the_explicit_oracle(flavour, over):
     assert rel_err(Xa.grad, dX_o) < 1e-4 and rel_err(Ya.grad, dY_o) < 1e-4
 
 
-@pytest.mark.parametrize("flavour", ["ave", "avs_s4", "avs_ms3"])
-@pytest.mark.parametrize("shape", [(16, 32, 36, 48), (36, 48, 16, 32)], ids=["orderA_or_B", "swapped"])
+@pytest.mark.parametrize("flavour", ["ave", "avs_s4", "avs_ms3", "pretrain", "avqa"])
+@pytest.mark.parametrize("shape", [(16, 32, 36, 64), (36, 64, 16, 32)], ids=["orderA_or_B", "swapped"])
 def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape, flavour):
     """oracle/dgsct_oracle_bf16.evaluate() -- the oracle's arithmetic with a switchable bf16 rounding at every tensor the bf16 schedule
     stores, the yardstick of tests/test_bf16_masked_gpu.py -- is pinned here: with nothing rounded it must reproduce the (reference-pinned)
@@ -618,8 +618,9 @@ def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape, flavour):
     X, Y = torch.randn(BT, N, C, generator=gen), torch.randn(BT, No, Co, generator=gen)
     dOut, dMap = torch.randn(BT, N, C, generator=gen), torch.randn(BT, N, generator=gen)
     out_o, map_o, _, s = O.forward({k: v.clone() for k, v in p.items()}, X, Y, cfg, training=True)
-    dX_o, dY_o, g_o = O.backward(p, s, cfg, dOut, dMap, None, training=True)
-    r = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q([]))
+    dTm = torch.randn(BT, generator=gen) if cfg.temporal else None
+    dX_o, dY_o, g_o = O.backward(p, s, cfg, dOut, dMap, dTm, training=True)
+    r = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q([]), dTmap=dTm)
     assert rel_err(r["out"], out_o) < 1e-5 and rel_err(r["map"], map_o) < 1e-5
     assert rel_err(r["dX"], dX_o) < 1e-5 and rel_err(r["dY"], dY_o) < 1e-5
     assert set(r["g"]) == {k for k, v in g_o.items() if v is not None}
@@ -628,9 +629,9 @@ def test_rounding_aware_oracle_without_rounding_is_the_oracle(shape, flavour):
             continue                         # (LN(gate * O): analytically ~0, the oracle evaluates this one residue in float64)
         assert rel_err(g.reshape(g_o[k].shape), g_o[k]) < 2e-5, k
     # pinned decisions (its own, fed back in): the same evaluation
-    r2 = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q([]), masks=r["masks"])
+    r2 = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q([]), masks=r["masks"], dTmap=dTm)
     assert rel_err(r2["dX"], dX_o) < 1e-5 and rel_err(r2["dY"], dY_o) < 1e-5
-    rq = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q(OB.DEVICE_ROUNDING), masks=r["masks"])
+    rq = OB.evaluate(cfg, p, X, Y, dOut, dMap, OB.Q(OB.DEVICE_ROUNDING), masks=r["masks"], dTmap=dTm)
     e = float((rq["dY"] - dY_o).norm() / dY_o.norm())
     assert 1e-4 < e < 5e-2, e
 
