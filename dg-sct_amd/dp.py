@@ -112,6 +112,7 @@ class GradAllReducer:
             if self._expected[bi] is not None and self._pending[bi] == self._expected[bi]:
                 self.hook_launches += 1
                 self._launch(bi)
+        hook._dgsct_drains_aux = True           # ops._may_adopt: this hook never reads .grad before _launch() has drained the aux streams
         return hook
 
     def _comm_stream(self, device):

@@ -177,6 +177,21 @@ def drain_aux(device: Optional[torch.device] = None):
         del keep
 
 
+def _wait_pending(dev: torch.device, stream: int):
+    """A call that does NOT defer (forward, joined backward) is about to reuse workspace slot 0 of this stream: if the previous
+    backward on the stream deferred its join, its weight-gradient kernels on the aux stream may still be reading that workspace
+    (stream_fork only orders aux behind main, never the reverse).  Order the current stream behind that call's aux event first, and
+    let its buffers go.  A dictionary lookup when nothing is pending."""
+    if not _PENDING:
+        return
+    key = (dev.index, stream)
+    with _WS_LOCK:
+        prev = _PENDING.pop(key, None)
+    if prev is not None:
+        torch.cuda.current_stream(dev).wait_event(prev[0])
+        del prev
+
+
 def _queue_drain():
     """drain_aux() when the autograd engine has run the last node of this backward pass.  Queued by EVERY deferring call: backward nodes
     run on the engine's per-device worker threads and the callbacks on whichever thread finishes the graph task, so a once-per-pass
@@ -261,6 +276,7 @@ def raw_forward(lib: Lib, spec: AdapterSpec, params, prep, X: torch.Tensor, Y: t
     tmap = torch.empty(BT, dtype=torch.float32, device=dev) if spec.temporal else None
     saved = torch.empty(int(sz.saved_bytes), dtype=torch.uint8, device=dev)
     stream = _stream_of(X)
+    _wait_pending(dev, stream)                 # slot 0 may still be read by a deferred backward's weight gradients
     ws = _workspace(dev, stream, int(sz.ws_fwd_bytes))
     if _POISON:
         _poison(out, amap, tmap, saved, ws)
@@ -290,6 +306,9 @@ def raw_backward(lib: Lib, spec: AdapterSpec, d: AdapterDesc, params, prep, X, Y
     slot = 0
     if defer:
         slot = _SLOT[key] = 1 - _SLOT.get(key, 1)
+    else:
+        _wait_pending(dev, stream)             # a joined call takes slot 0 whatever the deferred call before it used
+        _SLOT.pop(key, None)                   # (the next deferring call starts at slot 0 again: nothing is pending then)
     ws = _workspace(dev, stream, int(sz.ws_bwd_bytes), slot_base + slot)
     if _POISON:
         _poison(dX, dY, grads, ws)
@@ -411,6 +430,7 @@ class _AdapterFlatFn(torch.autograd.Function):
         ctx.skip, ctx.has_res = bool(skip), res is not None
         ctx.saved_buf = saved
         ctx.flat = flat
+        _count_use(flat)
         ctx.save_for_backward(X, Y)
         ctx.set_materialize_grads(False)
         if tmap is None:
@@ -427,7 +447,8 @@ class _AdapterFlatFn(torch.autograd.Function):
         # parameter has no gradient yet (else AccumulateGrad adds the new one into it on this stream, right now) and no tensor
         # hook wants to see it.  Gradient accumulation over several backward passes therefore joins from the second pass on.
         flat = ctx.flat
-        can_defer = (isinstance(flat, torch.Tensor) and flat.is_leaf and flat.grad is None and not getattr(flat, "_backward_hooks", None))
+        can_defer = _may_adopt(flat)
+        _use_done(flat)
         # (a DataParallel replica's flat tensor is NOT a leaf: its gradient is consumed by the broadcast's backward at once)
         ctx.flat = None
         spec = ctx.spec
@@ -442,6 +463,39 @@ class _AdapterFlatFn(torch.autograd.Function):
                                      flat_out=True, skip_into_dx=ctx.skip, defer_join=can_defer)
         ctx.saved_buf = None
         return None, None, None, None, None, None, dOut if ctx.has_res else None, dX, dY, gflat
+
+
+def _may_adopt(flat) -> bool:
+    """True when autograd will ADOPT the gradient buffer returned for this flat parameter without reading it on the calling stream --
+    the condition for leaving the weight-gradient (aux) stream un-joined.  It reads the buffer (clone / add / hook) when: the
+    parameter already has a gradient (accumulation), a tensor hook or a post-accumulate-grad hook other than this package's reducer
+    wants to see it (torch DDP's reducer hooks read .grad mid-backward; dp.GradAllReducer drains the aux streams first and marks its
+    hooks), grad mode is on (create_graph=True: AccumulateGrad clones), or the same parameter is used by more than one call of the
+    graph (the engine's input buffer SUMS the two buffers before accumulation: `_dgsct_uses`, counted in forward)."""
+    if not (isinstance(flat, torch.Tensor) and flat.is_leaf and flat.grad is None):
+        return False
+    if getattr(flat, "_backward_hooks", None) or torch.is_grad_enabled():
+        return False
+    post = getattr(flat, "_post_accumulate_grad_hooks", None)
+    if post and any(not getattr(h, "_dgsct_drains_aux", False) for h in post.values()):
+        return False
+    return getattr(flat, "_dgsct_uses", 1) <= 1
+
+
+def _count_use(flat):
+    """forward side of `_may_adopt`: how many calls of the graph being built read this flat parameter.  The count stands until the
+    LAST of those calls has run its backward (every one of them must join); a forward whose graph is dropped without a backward
+    leaves the count high, which only costs the deferral (safe side)."""
+    if isinstance(flat, torch.Tensor) and flat.requires_grad and torch.is_grad_enabled():
+        flat._dgsct_uses = getattr(flat, "_dgsct_uses", 0) + 1
+        flat._dgsct_left = getattr(flat, "_dgsct_left", 0) + 1
+
+
+def _use_done(flat):
+    if isinstance(flat, torch.Tensor) and getattr(flat, "_dgsct_left", 0) > 0:
+        flat._dgsct_left -= 1
+        if flat._dgsct_left == 0:
+            flat._dgsct_uses = 0
 
 
 PAIR_BACKWARD = os.environ.get("DGSCT_NO_PAIR", "0") != "1"
@@ -504,6 +558,8 @@ class _PairFlatFn(torch.autograd.Function):
         ctx.descs = (da, dv)
         ctx.saved_bufs = (sa, sv)
         ctx.flats = (flat_a, flat_v)
+        _count_use(flat_a)
+        _count_use(flat_v)
         ctx.save_for_backward(f_a, f_v)
         ctx.set_materialize_grads(False)
         return oa, ma, ov, mv
@@ -518,8 +574,9 @@ class _PairFlatFn(torch.autograd.Function):
         (spec_a, _, prep_a, pl_a), (spec_v, _, prep_v, pl_v) = ctx.calls
         d_a, d_v = ctx.descs
         s_a, s_v = ctx.saved_bufs
-        defer = [isinstance(fl, torch.Tensor) and fl.is_leaf and fl.grad is None and not getattr(fl, "_backward_hooks", None)
-                 for fl in ctx.flats]                                   # (as in _AdapterFlatFn.backward)
+        defer = [_may_adopt(fl) for fl in ctx.flats]                    # (as in _AdapterFlatFn.backward)
+        for fl in ctx.flats:
+            _use_done(fl)
         ctx.flats = ctx.saved_bufs = None
         dOa, dOv = _cotangent(dOa, f_a), _cotangent(dOv, f_v)
         dMa = dMa.contiguous().float() if dMa is not None else None

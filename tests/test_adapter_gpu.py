@@ -678,3 +678,128 @@ def test_flat_gradients_accumulate_over_two_backward_passes():
     assert grads[1]
     for n, g1 in grads[1].items():
         assert fp32_err(grads[2][n], 2 * g1) < 1e-3, (n, fp32_err(grads[2][n], 2 * g1))
+
+
+def test_joined_call_after_a_deferred_one_waits_for_its_weight_gradients():
+    """a deferred backward (aux join left to the caller) followed on the same stream by a call that does NOT defer -- a
+    forward, or a joined backward: both take workspace slot 0, which the deferred call's weight-gradient kernels may still be reading on
+    the aux stream.  ops._wait_pending orders the stream behind that aux event first.  The deferred call's gradients must equal the
+    joined reference whatever follows it."""
+    N, C, No, Co, BT = 144, 64, 96, 48, 8
+    cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=8, r=8, g=2)
+    p = O.random_params(cfg, "ave", seed=5)
+    spec = spec_of(cfg)
+    lib = default_lib()
+    params = param_table(p, spec, DEV)
+    prep = ops.prepare(lib, spec, params, torch.float32, DEV)
+
+    def one(seed):
+        g2 = torch.Generator().manual_seed(seed)
+        X = torch.randn(BT, N, C, generator=g2).to(DEV).contiguous()
+        Y = torch.randn(BT, No, Co, generator=g2).to(DEV).contiguous()
+        dOut = torch.randn(BT, N, C, generator=g2).to(DEV).contiguous()
+        dMap = torch.randn(BT, N, generator=g2).to(DEV)
+        return X, Y, dOut, dMap
+
+    def ref(seed):
+        X, Y, dOut, dMap = one(seed)
+        _, _, _, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+        r = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, None, flat_out=True, defer_join=False)
+        torch.cuda.synchronize()
+        return [t.clone() for t in r]
+
+    want = {s: ref(s) for s in (21, 22)}
+    for follow in ("forward", "joined_backward"):
+        ops.drain_aux()
+        X, Y, dOut, dMap = one(21)
+        _, _, _, saved, d = ops.raw_forward(lib, spec, params, prep, X, Y, True)
+        X2, Y2, dOut2, dMap2 = one(22)
+        _, _, _, saved2, d2 = ops.raw_forward(lib, spec, params, prep, X2, Y2, True)
+        got = ops.raw_backward(lib, spec, d, params, prep, X, Y, saved, dOut, dMap, None, flat_out=True, defer_join=True)
+        assert ops._PENDING                                         # slot 0, still running on the aux stream
+        if follow == "forward":
+            ops.raw_forward(lib, spec, params, prep, X2, Y2, True)   # overwrites workspace slot 0 on this stream
+            assert not ops._PENDING                                 # ... after having waited for the pending call
+        else:
+            got2 = ops.raw_backward(lib, spec, d2, params, prep, X2, Y2, saved2, dOut2, dMap2, None, flat_out=True, defer_join=False)
+            assert not ops._PENDING
+        ops.drain_aux()
+        torch.cuda.synchronize()
+        for a, b in zip(got, want[21]):
+            assert fp32_err(a, b) < 1e-3, (follow, fp32_err(a, b))
+        if follow != "forward":
+            for a, b in zip(got2, want[22]):
+                assert fp32_err(a, b) < 1e-3, (follow, fp32_err(a, b))
+
+
+def test_deferral_conditions_of_the_flat_gradient():
+    """ADVICE r5 (ops._may_adopt): the aux join may be deferred only when autograd adopts the flat gradient unread.  (a) ONE adapter
+    called twice in a graph: the engine sums the two gradient buffers, so both calls must join -- the result is the sum of the two calls'
+    gradients; (b) a foreign post-accumulate-grad hook (what torch DDP registers) reads .grad at once: it must see the complete
+    gradient; (c) grad mode / tensor hooks switch the deferral off as well."""
+    from dgsct_amd import VisualAdapter
+    from dgsct_amd.stack import default_opt
+    N, C, No, Co, BT = 64, 64, 36, 32, 10
+
+    def build():
+        torch.manual_seed(11)
+        m = VisualAdapter(input_dim=C, output_dim=C, adapter_kind="bottleneck", dim_list=[C], layer_idx=0, reduction_factor=8,
+                          opt=default_opt(num_tokens=8), use_bn=True, use_gate=True, conv_dim_in=No, conv_dim_out=N, linear_in=Co,
+                          linear_out=C, num_tk=8).to(DEV)
+        with torch.no_grad():
+            m.gate.fill_(0.5); m.gate_av.fill_(0.5)
+        m.flatten_parameters()
+        m.train()
+        return m
+
+    gen = torch.Generator().manual_seed(2)
+    xs = [torch.randn(BT, N, C, generator=gen).to(DEV) for _ in range(2)]
+    ys = [torch.randn(BT, No, Co, generator=gen).to(DEV) for _ in range(2)]
+    view = lambda f: f.permute(0, 2, 1).unsqueeze(-1)
+
+    def run(m, idx, hook=None):
+        m.flat_param.grad = None
+        h = m.flat_param.register_post_accumulate_grad_hook(hook) if hook else None
+        loss = 0
+        for i in idx:
+            out, amap = m(view(xs[i]), view(ys[i]))
+            loss = loss + (out.float() ** 2).sum() + amap.sum()
+        loss.backward()
+        if h is not None:
+            h.remove()
+        torch.cuda.synchronize()
+        return m.flat_param.grad.clone()
+
+    m = build()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    singles = []
+    for i in range(2):
+        m.load_state_dict(sd)
+        singles.append(run(m, [i]))
+    m.load_state_dict(sd)
+    both = run(m, [0, 1])                                           # (a) same flat parameter twice in one graph
+    # BatchNorm running stats differ between the orders but do not enter training-mode gradients
+    assert fp32_err(both, singles[0] + singles[1]) < 1e-3, fp32_err(both, singles[0] + singles[1])
+    assert getattr(m.flat_param, "_dgsct_uses", 0) == 0
+    seen = {}
+    m.load_state_dict(sd)
+
+    def foreign(param):                                             # (b) reads the gradient right away, on the calling stream
+        seen["g"] = param.grad.clone()
+
+    g = run(m, [0], hook=foreign)
+    torch.cuda.synchronize()
+    assert fp32_err(seen["g"], singles[0]) < 1e-3 and fp32_err(g, singles[0]) < 1e-3
+    # (c) the predicate itself
+    fp = m.flat_param
+    fp.grad = None
+    with torch.no_grad():
+        assert ops._may_adopt(fp)
+    assert not ops._may_adopt(fp)                                   # grad mode on (create_graph): AccumulateGrad clones
+    with torch.no_grad():
+        h = fp.register_hook(lambda g_: g_)
+        assert not ops._may_adopt(fp)
+        h.remove()
+        fp._dgsct_uses = 2
+        assert not ops._may_adopt(fp)
+        fp._dgsct_uses = 0
