@@ -15,7 +15,9 @@ from oracle import make_golden_refbf16 as RB  # noqa: E402  (inputs_of / params_
 
 FX = load_golden("ref_bf16")
 CASES = sorted(FX["cases"])
-K = 1.25          # device(bf16) may be at most this much further from reference(fp32) than reference(bf16) is
+K = 1.25          # device(bf16) may be at most this much further from reference(fp32) than reference(bf16) is: out, map, dX, dY and the
+HEADLINE = ("out", "map", "dX", "dY", "dfc.weight", "dconv_adapter.weight", "dmy_tokens")     # remap / token gradients
+K_OTHER = 1.5     # every other weight MATRIX (measured 0.02-1.23: the gate-MLP weights sit at ~1.0-1.2, one ReLU flip moves them by a row)
 
 
 def _l2(a, b):
@@ -81,7 +83,8 @@ def _device(case, dtype, training=True, eval_state=None):
 @pytest.mark.parametrize("name", CASES)
 def test_device_bf16_is_no_further_from_the_reference_than_the_reference_in_bf16(name):
     """|| device(bf16) - reference(fp32) || <= 1.25 x || reference(bf16) - reference(fp32) ||, rel-L2, un-pinned (no device masks), for
-    out, map, dX, dY and every weight-matrix gradient; BASELINE's 1e-2 for the outputs on top."""
+    out, map, dX, dY, dWc, dWn, d my_tokens (1.5 x for the other weight matrices); BASELINE's 1e-2 for the outputs on top.
+    Measured (round 6): dX 0.66-0.84 x, dY 0.27-0.79 x, dWc 0.28-0.75 x, dWn 0.27-0.70 x, out 0.61-0.69 x, map 0.02 x."""
     case = FX["cases"][name]
     _, _, _, _, res, got, _, _ = _device(case, torch.bfloat16)
     rb = case["ref_bf16_err"]
@@ -95,7 +98,7 @@ def test_device_bf16_is_no_further_from_the_reference_than_the_reference_in_bf16
         is_mat = k in ("out", "map", "dX", "dY") or (ref.dim() >= 2 and min(ref.shape[:2]) > 1)
         e = _l2(got[k], ref)
         rows.append((k, e, rb[k]))
-        if is_mat and k[1:] not in ("ln_before.bias",) and e > K * rb[k] + 1e-4:
+        if is_mat and e > (K if k in HEADLINE else K_OTHER) * rb[k] + 1e-4:
             bad.append((k, e, rb[k]))
     print(f"\n{name}: tensor, device(bf16) vs reference(fp32), reference(bf16) vs reference(fp32)   [rel-L2]")
     for k, e, r in rows:
