@@ -241,6 +241,9 @@ def cpu_baseline(backbone, max_seconds=30.0, b16_seconds=45.0):
     b16 = round(16.0 / t16, 4) if t16 else None
     return dict(value=b16 if b16 is not None else b1, unit="clips/s", cores=torch.get_num_threads(), kind="port", cpu_model=model,
                 logical_cpus=ncpu, physical_cores=physical, value_b1=b1, value_b16=b16, b16_cold_shapes=cold16,
+                # a shape timed on its single cold pass (first touch of multi-GB buffers) makes the CPU look slower than it is: the
+                # GPU / CPU ratio of such a line is an upper bound
+                value_is_lower_bound=bool(cold16),
                 sample=(f"B=16: fwd+bwd of each of the {n16} distinct adapter shapes at BT=160 (one warm-up pass + one timed pass; {cold16} shape(s) timed cold "
                         f"once the leg's own {b16_seconds:.0f} s budget ran out), weighted by the stack's call "
                         f"counts (= {t16:.1f} s for the 48-adapter step; `value`); ") +
@@ -431,6 +434,30 @@ def main():
     host_ms = [round(x / args.steps * 1e3, 2) for x in host_parts]
     clips_per_s = per_gpu_batch * world / (elapsed / args.steps)
 
+    host_floor = None
+    if rank == 0 and world == 1 and not use_graph and not args.no_roofline:
+        # What the HOST needs per step: the same step on ONE clip (BT = 10: a sixteenth of the device work, every
+        # launch still issued) is enqueue-bound -- its wall time per step is the host's floor for this schedule: Python + autograd +
+        # ctypes + the library's launches and event forks.  Not part of `value`.
+        try:
+            f1, c1, m1 = make_inputs(stages, T, dtype, device, seed=99)
+
+            def small_step():
+                trainer.fwd_bwd(f1, c1, m1)
+                update()
+            for _ in range(2):
+                small_step()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            nq = 5
+            for _ in range(nq):
+                small_step()
+            torch.cuda.synchronize()
+            host_floor = round((time.perf_counter() - tq) / nq * 1e3, 2)
+            del f1, c1, m1
+        except Exception as ex:                          # diagnostics only
+            host_floor = None
+
     roofline = None
     if rank == 0 and not args.no_roofline:
         # dominant kernel family = the MFMA GEMM engine (gemm_kernel<...>): time every launch of two extra steps
@@ -529,16 +556,37 @@ def main():
             if gj.get("gemm_ms_per_step"):
                 in_step = dict(frac=round(gemm_flops / nprof / (gj["gemm_ms_per_step"] * 1e-3) / 1e12 / peak, 4), gemm_ms_per_step=gj["gemm_ms_per_step"],
                                launches_per_step=gj.get("launches_per_step"), source=os.path.relpath(gfiles[-1], ROOT))
-        roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+        # ---- one set of books.  The family is {gemm_kernel, gemm8_kernel, gemm_fx_kernel, wgrad_bt_k}: the launch count,
+        # the traffic per launch and the algorithmic bytes per launch all use the launch count of the committed trace / PMC passes of
+        # this command (same family definition in tools/rocpd_stats.py and tools/pmc_stack_summary.py); the library's own event log counts
+        # the skinny / tall products as well and is kept as `launches_logged`.  The HEADLINE fraction is the one inside the timed
+        # two-stream schedule (trace); the serial-pass figure (each launch alone between its own events) is `frac_serial`.
+        fam_launches = int(in_step["launches_per_step"]) if in_step and in_step.get("launches_per_step") else launches // nprof
+        frac_head = in_step["frac"] if in_step else round(achieved / peak, 4)
+        ach_head = round(frac_head * peak, 2)
+        row_kernels = None
+        if tsrc:
+            # the HBM-bound kernels individually ("the purely elementwise / normalisation kernels ... HBM fraction when
+            # profiled individually"): PMC bytes (FETCH x2 + WRITE) over the kernel's own duration in the same per-shape passes
+            row_kernels = {}
+            for k in ("tail_fwd_k", "tail_bwd_ave_k", "modln_fwd_k", "modln_bwd_k", "gatemod_fwd_k", "gatemod_bwd_k", "vq1_bwd_k", "xattn_fwd2_k",
+                      "xattn_bwd2_k", "xattn_fwd3_k", "xattn_bwd3_k", "tokattn_fwd_k", "tokattn_fwd_small_k", "tokattn_bwd_k", "tokattn_bwd2_k",
+                      "gproj_narrow_k", "gproj_wide_k", "gemm_tall_k", "scale_cols_k", "relu_bwd_scale_k"):
+                e = tj.get(k)
+                if e and e.get("serial_ms"):
+                    gbs = (e["fetch_bytes"] + e["write_bytes"]) / 1e9 / (e["serial_ms"] * 1e-3)
+                    row_kernels[k] = dict(launches_per_step=e["launches_per_step"], ms_per_step_alone=round(e["serial_ms"], 3),
+                                          mb_per_launch=round(e["bytes_per_launch"] / 1e6, 1), achieved_gbps=round(gbs), frac_of_hbm_peak=round(gbs / 8000.0, 3))
+        roofline = dict(bound="mfma", achieved=ach_head, peak=peak, unit="TFLOP/s", frac=frac_head,
                         frac_serial=round(achieved / peak, 4), frac_in_step=in_step["frac"] if in_step else None, in_step=in_step,
-                        traffic=traffic, traffic_unit=f"bytes/launch (PMC, {tsrc})" if tsrc else None,
+                        traffic=traffic, traffic_unit=f"bytes/launch (PMC, {tsrc}; family bytes / {fam_launches} launches)" if tsrc else None,
                         traffic_source=("committed: separate rocprofv3 --pmc passes over this workload's 8 adapter shapes "
                                         "(tools/pmc_stack.sh), not measured in this run") if tsrc else None,
-                        alg_bytes_per_launch=round(alg_bytes_per_step(stages, BT) / max(launches // nprof, 1)), kernel="dgsct::gemm_kernel<*> + gemm8_kernel<*> (all MFMA GEMM launches of a step)",
-                        launches_per_step=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
+                        alg_bytes_per_launch=round(alg_bytes_per_step(stages, BT) / max(fam_launches, 1)), kernel="dgsct::gemm_kernel<*> + gemm8_kernel<*> + gemm_fx_kernel<*> + wgrad_bt_k (the MFMA GEMM family of a step)",
+                        launches_per_step=fam_launches, launches_logged=launches // nprof, avg_launch_us=round(gemm_ms * 1e3 / max(launches, 1), 2),
                         alg_tflop_per_step=round(alg / 1e12, 3), executed_tflop_per_step=round(gemm_flops / nprof / 1e12, 3),
                         gemm_ms_per_step=round(gemm_ms / nprof, 3), heaviest_launch=heaviest,
-                        step_frac_of_mfma_peak=step_block["frac_of_mfma_peak"], step=step_block, per_stage=per_stage)
+                        step_frac_of_mfma_peak=step_block["frac_of_mfma_peak"], step=step_block, per_stage=per_stage, row_kernels=row_kernels)
     dp_info = None
     if dp:
         # what a driver log needs to diagnose a multi-GPU run without a second one: ranks RCCL really has, buckets launched from
@@ -573,6 +621,9 @@ def main():
         barrier()
 
     if rank == 0:
+        _l = default_lib()
+        if _l.test_tune("skip", -1) > 0 or _l.test_tune("noatomic", -1) > 0:
+            raise SystemExit("bench.py: a what-if switch (dgsct_test_tune skip / noatomic) is set in this process: the step computed garbage, no line")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.backbone)
@@ -588,6 +639,7 @@ def main():
                         step="fwd+bwd" + ("+allreduce" if dp else "") + ("" if args.no_optim else "+adam"),
                         streams=1 if args.serial else 2, hip_graph=use_graph, host_enqueue_ms_per_step=round(host_s / args.steps * 1e3, 2),
                         host_ms_fwdbwd_allreduce_optim=host_ms,
+                        host_floor_ms_per_step=host_floor,
                         **({"gpu_ms_fwd_bwd": [round(sum(a.elapsed_time(b) for a, b, _ in phase_ev[-args.steps:]) / args.steps, 2),
                                                round(sum(b.elapsed_time(c) for _, b, c in phase_ev[-args.steps:]) / args.steps, 2)]}
                            if args.phases and len(phase_ev) >= args.steps else {})),

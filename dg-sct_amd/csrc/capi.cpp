@@ -283,7 +283,18 @@ int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, cons
   return has_error() ? 1 : 0;
 }
 
+// The what-if switches ("skip", "skipminc", "skipmaxc", "noatomic") drop launches / atomics: RESULTS ARE GARBAGE, timing is real.  They are
+// process-global, so they can be SET only in a process that opted in with DGSCT_WHATIF=1 (tools/call_overlap.py does; nothing in the
+// package, the tests or bench.py does); querying (value < 0) is always allowed and bench.py refuses to print a line while one is set.
+static bool whatif_allowed(int value) {
+  if (value < 0) return true;
+  static const bool on = getenv("DGSCT_WHATIF") && !strcmp(getenv("DGSCT_WHATIF"), "1");
+  if (!on && value != 0) set_error("dgsct_test_tune: what-if switches need DGSCT_WHATIF=1 in the environment (results are garbage with them)");
+  return on || value == 0;
+}
+
 int dgsct_test_tune(const char* key, int value) {
+  if (key && (!strcmp(key, "skip") || !strcmp(key, "noatomic") || !strcmp(key, "skipmaxc") || !strcmp(key, "skipminc")) && !whatif_allowed(value)) return -2;
   if (key && !strcmp(key, "gemm8")) return gemm8_mode(value);
   if (key && !strcmp(key, "skip")) return dgsct::plan_skip_mode(value);            // what-if timing switches (plan.cpp): results are garbage
   if (key && !strcmp(key, "gemmfx")) return gemmfx_mode(value);

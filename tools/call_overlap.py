@@ -2,6 +2,7 @@
 rocprofv3 the late stages turn host-bound and the answer changes), one eager step of the bench stack.
 usage: python tools/call_overlap.py [BT]"""
 import os, sys, time
+os.environ.setdefault("DGSCT_WHATIF", "1")       # this tool may set the what-if switches (dgsct_test_tune "skip": results garbage, timing real)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
