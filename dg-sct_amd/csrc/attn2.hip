@@ -15,6 +15,7 @@
 //   TF [C/32][2][2][32][8]     : element (((j*2 + kk)*2 + h)*32 + c)*8 + e    = hi of tok[16 kk + 4 h + (e&3) + 8 (e>>2)][32 j + c]
 // (TF's latent-token order is the order in which a lane holds the probabilities of its token row after the first product).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdlib>
 #include "prims.h"
 #include "device_util.h"
@@ -1129,12 +1130,231 @@ __global__ __launch_bounds__(256) void tokattn_fwd_small_k(const TFS2Args p) {
     }
   }
 }
+
+// ---- round 6: the same kernel on EIGHT wavefronts (512 threads), same arithmetic and rounding points ------------------------------
+// The 4-wave kernel above is a latency chain at one wave per SIMD (160 workgroups on 256 CUs): phase A gives a wave up to two row
+// tiles x every 128-channel slab in turn (8 load -> LDS -> MFMA steps), phase B one slab x every row tile.  Here
+//   phase A: one row tile per wave (N <= 256 = 8 tiles); when the frame has <= 4 row tiles the spare waves split the SLABS of a tile
+//            (partial logit tiles summed through LDS: fp32 summation order differs from the 4-wave kernel, nothing else);
+//   phase B: items of 64 channels (C / 64 = 6 ... 16 items over 8 waves) instead of 128: two MFMA column tiles per item.
+// N = 144, C = 512 alone: see profiles/r06_attn_bench.txt.
+template <int HS>
+struct HSlab { uint4 v[HS / 16]; };
+template <int HS>
+__device__ __forceinline__ void hslab_load(HSlab<HS>& s, const unsigned short* g, long ld, int rows_valid, int c0, int C, int lane) {
+  constexpr int CPR = HS / 8;                       // 16-byte chunks per row
+#pragma unroll
+  for (int i = 0; i < HS / 16; ++i) {
+    const int idx = i * 64 + lane, r = idx / CPR, c = (idx % CPR) * 8;
+    const int rr = r < rows_valid ? r : rows_valid - 1;
+    const int cc = c0 + c < C ? c0 + c : C - 8;
+    s.v[i] = *reinterpret_cast<const uint4*>(g + (long)rr * ld + cc);
+  }
+}
+template <int HS>
+__device__ __forceinline__ void hslab_store_lds(const HSlab<HS>& s, char* img, int rows_valid, int c0, int C, int lane) {
+  constexpr int CPR = HS / 8;
+#pragma unroll
+  for (int i = 0; i < HS / 16; ++i) {
+    const int idx = i * 64 + lane, r = idx / CPR, c = (idx % CPR) * 8;
+    uint4 v = s.v[i];
+    if (r >= rows_valid || c0 + c >= C) v = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(img + r * PX2 + c * 2) = v;
+  }
+}
+constexpr int TF8_NW = 8;
+constexpr int TF8_HS = 64;
+__global__ __launch_bounds__(TF8_NW * 64) void tokattn_fwd_small8_k(const TFS2Args p) {
+  constexpr int NW = TF8_NW, HS = TF8_HS;
+  // ONE LDS object: [NW private slab images | shared probabilities [256 n][32 t] | partial logit tiles of the slab-split phase A]
+  __shared__ __attribute__((aligned(16))) char smem[NW * IMG2 + 256 * PP2 + NW * 4096];
+  __shared__ float red[2][NW][32];
+  __shared__ float sl[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const long C = p.C;
+  char* img = smem + wave * IMG2;
+  char* sP = smem + NW * IMG2;
+  float* part = reinterpret_cast<float*>(smem + NW * IMG2 + 256 * PP2);
+  const unsigned short* Yb = p.Yp + (long)b * p.N * C;
+  const unsigned short* thF = p.T0pk;
+  const unsigned short* tlF = thF + 32 * C;
+  const int nrt = (p.N + 31) / 32, nsl = (p.C + CS2 - 1) / CS2;
+  const int t = lane & 31;
+  // ---- phase A: wave -> (row tile rt, slab group sg of nsg): nsg = 1 for 5 ... 8 row tiles, 2 for 3 ... 4, 4 for 1 ... 2
+  const int nsg = nrt > 4 ? 1 : (nrt > 2 ? 2 : 4);
+  const int rt = wave / nsg, sg = wave - rt * nsg;
+  const bool activeA = rt < nrt;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (activeA) {
+    const int rows = p.N - rt * 32 < 32 ? p.N - rt * 32 : 32;
+    const unsigned short* Yg = Yb + (long)rt * 32 * C;
+    const int spg = (nsl + nsg - 1) / nsg, s0 = sg * spg, s1 = s0 + spg < nsl ? s0 + spg : nsl;      // this wave's slabs [s0, s1)
+    if (s0 < s1) {
+      Slab s;
+      slab_load(s, Yg, C, rows, s0 * CS2, p.C, lane);
+      for (int si = s0; si < s1; ++si) {
+        const int c0 = si * CS2, kc = (p.C - c0 < CS2 ? p.C - c0 : CS2) / 16;
+        wave_sync();
+        slab_store_lds(s, img, rows, c0, p.C, lane);
+        wave_sync();
+        if (si + 1 < s1) slab_load(s, Yg, C, rows, c0 + CS2, p.C, lane);
+        const unsigned short* bh = thF + ((long)(c0 >> 4) * 64 + lane) * 8;
+        const unsigned short* bl = tlF + ((long)(c0 >> 4) * 64 + lane) * 8;
+        const char* ap = img + (lane & 31) * PX2 + (lane >> 5) * 16;
+#pragma unroll
+        for (int g = 0; g < CS2 / 64; ++g) {
+          if (g * 4 >= kc) break;
+          bfx8 fh[4], fl[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int kk = g * 4 + q < kc ? g * 4 + q : 0; fh[q] = ldg8(bh + kk * 512); fl[q] = ldg8(bl + kk * 512); }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (g * 4 + q < kc) {
+              const bfx8 af = lds8(ap + (g * 4 + q) * 32);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, fh[q], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, fl[q], acc, 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+  if (nsg > 1) {                                                  // sum the slab groups' partial tiles (group 0 of each row tile keeps the sum)
+    if (activeA && sg > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave * 1024 + r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (activeA && sg == 0) {
+      for (int k = 1; k < nsg; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += part[(wave + k) * 1024 + r * 64 + lane];
+    }
+  }
+  const bool ownerA = activeA && sg == 0;
+  float mx = -INFINITY;
+  if (ownerA) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (rt * 32 + mt_row(r, lane) < p.N) mx = fmaxf(mx, acc[r]);
+  }
+  mx = fmaxf(mx, xor32b(mx));
+  if (lane < 32) red[0][wave][t] = mx;
+  __syncthreads();
+  float m = red[0][0][t];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) m = fmaxf(m, red[0][w][t]);
+  float sum = 0.f;
+  if (ownerA) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = rt * 32 + mt_row(r, lane);
+      const float pv = n < p.N ? __expf(acc[r] - m) : 0.f;
+      sum += pv;
+      *reinterpret_cast<unsigned short*>(sP + n * PP2 + t * 2) = f2bf(pv);
+    }
+  }
+  sum += xor32b(sum);
+  if (lane < 32) red[1][wave][t] = sum;
+  __syncthreads();
+  if (wave == 0 && lane < 32) {
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) l += red[1][w][t];
+    sl[t] = 1.f / l;
+    if (t < p.tk) p.lse[(long)b * p.tk + t] = m + __logf(l);
+  }
+  __syncthreads();
+  // ---- phase B: wave -> 64-channel items wave, wave + 8, ...
+  unsigned short* hiF = p.tokpk + (long)b * 96 * C;
+  unsigned short* loF = hiF + 32 * C;
+  unsigned short* TFo = loF + 32 * C;
+  const int nh = (p.C + HS - 1) / HS;
+  for (int hi = wave; hi < nh; hi += NW) {
+    const int c0 = hi * HS, nt = (p.C - c0 < HS ? p.C - c0 : HS) / 32;
+    f32x16 o[HS / 32];
+#pragma unroll
+    for (int j = 0; j < HS / 32; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+    float cs0 = 0.f, cs1 = 0.f;                                   // column sums of channels c0 + 2 lane, + 1 (lanes 0 .. 31)
+    HSlab<HS> s;
+    hslab_load<HS>(s, Yb, C, p.N < 32 ? p.N : 32, c0, p.C, lane);
+    float t0s[HS / 32][16];
+#pragma unroll
+    for (int j = 0; j < HS / 32; ++j) {
+      const int c = c0 + 32 * j + (lane & 31), cj = c < p.C ? c : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const int tt = mt_row(r, lane); t0s[j][r] = p.T0[(long)(tt < p.tk ? tt : 0) * C + cj]; }
+    }
+    for (int r2 = 0; r2 < nrt; ++r2) {
+      const int rows = p.N - r2 * 32 < 32 ? p.N - r2 * 32 : 32;
+      wave_sync();
+      hslab_store_lds<HS>(s, img, rows, c0, p.C, lane);
+      wave_sync();
+      if (r2 + 1 < nrt) hslab_load<HS>(s, Yb + (long)(r2 + 1) * 32 * C, C, p.N - (r2 + 1) * 32 < 32 ? p.N - (r2 + 1) * 32 : 32, c0, p.C, lane);
+      const mt_bf16x8 a0 = mt_frag_mn(sP + r2 * 32 * PP2, PP2, 0, 0, lane), a1 = mt_frag_mn(sP + r2 * 32 * PP2, PP2, 0, 1, lane);
+#pragma unroll
+      for (int j = 0; j < HS / 32; ++j) {
+        if (j >= nt) break;
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, mt_frag_mn(img, PX2, 32 * j, 0, lane), o[j], 0, 0, 0);
+        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, mt_frag_mn(img, PX2, 32 * j, 1, lane), o[j], 0, 0, 0);
+      }
+      if (lane < HS / 2) {
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+          const unsigned w = *reinterpret_cast<const unsigned*>(img + r * PX2 + lane * 4);
+          cs0 += __uint_as_float(w << 16); cs1 += __uint_as_float(w & 0xffff0000u);
+        }
+      }
+    }
+    if (lane < HS / 2 && c0 + 2 * lane < p.C) {
+      const float a0v = cs0 * p.invN, a1v = cs1 * p.invN;
+      *reinterpret_cast<float2*>(p.a + (long)b * C + c0 + 2 * lane) = make_float2(a0v, a1v);
+      *reinterpret_cast<unsigned*>(p.aE + (long)b * C + c0 + 2 * lane) = pack2(a0v, a1v);
+    }
+    // epilogue: tok = T0 + O / l; fp32 rows + the three packed bf16 images (as in the 4-wave kernel)
+#pragma unroll
+    for (int j = 0; j < HS / 32; ++j) {
+      if (j >= nt) break;
+      const int c = c0 + 32 * j + (lane & 31);
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tt = mt_row(r, lane);
+        v[r] = tt < p.tk ? t0s[j][r] + o[j][r] * sl[tt] : 0.f;
+        if (tt < p.tk) p.tok[((long)b * p.tk + tt) * C + c] = v[r];
+        const unsigned short h = f2bf(v[r]);
+        *reinterpret_cast<unsigned short*>(img + tt * 80 + (lane & 31) * 2) = h;
+        *reinterpret_cast<unsigned short*>(img + 2560 + tt * 80 + (lane & 31) * 2) = f2bf(v[r] - bf2f(h));
+      }
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = lane + 64 * i, tt = q & 31, h8 = q >> 5;             // piece: token tt, channels 8 h8 .. + 7 of this tile
+        const int cc = c0 + 32 * j + 8 * h8;
+        const long fo = (((long)(cc >> 4) * 2 + ((cc >> 3) & 1)) * 32 + tt) * 8;
+        *reinterpret_cast<uint4*>(hiF + fo) = *reinterpret_cast<const uint4*>(img + tt * 80 + h8 * 16);
+        *reinterpret_cast<uint4*>(loF + fo) = *reinterpret_cast<const uint4*>(img + 2560 + tt * 80 + h8 * 16);
+      }
+      wave_sync();
+      unsigned short* tf = TFo + (((long)((c0 >> 5) + j) * 2) * 64 + lane) * 8;
+      *reinterpret_cast<uint4*>(tf) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+      *reinterpret_cast<uint4*>(tf + 512) = make_uint4(pack2(v[8], v[9]), pack2(v[10], v[11]), pack2(v[12], v[13]), pack2(v[14], v[15]));
+    }
+  }
+}
+static std::atomic<int> g_tfs8{1};
+int tokattn_small8_mode(int set) { const int old = g_tfs8.load(); if (set >= 0) g_tfs8.store(set); return old; }     // dgsct_test_tune "tfs8": 0 = the 4-wave kernel
 bool tokattn_fwd_small_ok(const Ctx& ctx, int N, int C) { return attn2_ok(ctx, C) && N <= 256; }
 void tokattn_fwd_small(const Ctx& ctx, const void* Yp, const float* T0, const void* T0pk, int B, int N, int C, int tk, float* tok,
                        void* tokpk, float* lse, float* a, void* aE) {
   TFS2Args q{(const unsigned short*)Yp, T0, (const unsigned short*)T0pk, N, C, tk, 1.f / (float)N, tok, (unsigned short*)tokpk, lse, a,
              (unsigned short*)aE};
-  hipLaunchKernelGGL(tokattn_fwd_small_k, dim3(B), dim3(256), 0, (hipStream_t)ctx.stream, q);
+  if (g_tfs8.load(std::memory_order_relaxed)) hipLaunchKernelGGL(tokattn_fwd_small8_k, dim3(B), dim3(TF8_NW * 64), 0, (hipStream_t)ctx.stream, q);
+  else hipLaunchKernelGGL(tokattn_fwd_small_k, dim3(B), dim3(256), 0, (hipStream_t)ctx.stream, q);
 }
 
 }  // namespace dgsct

@@ -305,6 +305,7 @@ int dgsct_test_tune(const char* key, int value) {
   if (key && !strcmp(key, "noatomic")) return dgsct::gemm_noatomic_mode(value);
   if (key && !strcmp(key, "skipmaxc")) return dgsct::plan_skip_maxc(value);
   if (key && !strcmp(key, "skipminc")) return dgsct::plan_skip_minc(value);
+  if (key && !strcmp(key, "tfs8")) return dgsct::tokattn_small8_mode(value);
   if (key && !strcmp(key, "skinny")) return gemm_skinny_mode(value);
   if (key && !strcmp(key, "gemmtall")) return gemm_tall_mode(value);
   if (key && !strcmp(key, "rowfuse")) return rowfuse_mode(value);

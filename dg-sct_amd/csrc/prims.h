@@ -326,6 +326,7 @@ int wgrad_bt_mode(int set);
 // tokpk (optional, bf16 mode): the latent tokens PACKED for the wave-centric fast kernels (attn2.hip): per frame
 // [hi 32 x C | lo 32 x C | transposed C x 32] bf16 = tok_pack_elems(B, C) elements; consumers fall back to the generic
 // kernels when it is null.
+int tokattn_small8_mode(int set);   // dgsct_test_tune "tfs8": 1 (default) the 8-wave short-frame kernel, 0 the 4-wave one
 long tok_pack_elems(int nb, int C);
 void tok_pack(const Ctx&, const float* src, int nb, int tk, int C, void* pk, const float* other = nullptr, const float* base = nullptr,
               float* D = nullptr);       // D[b][t] = sum_c src * (other - base)   (optional)

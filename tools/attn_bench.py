@@ -18,6 +18,8 @@ dtype = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torc
 es = 2 if dtype == torch.bfloat16 else 4
 dev = torch.device("cuda:0")
 lib = default_lib()
+if os.environ.get("TFS8") is not None:          # A/B: 0 = the 4-wave short-frame tokattn_fwd kernel
+    lib.test_tune("tfs8", int(os.environ["TFS8"]))
 names = ["tokattn_fwd(+combine,pack)", "xattn_fwd", "xattn_bwd", "tokattn_bwd(+pack)"]
 units = [1, 2, 3, 2]            # algorithmic passes over a [B][N][C] activation: read Yp | X->X1 | X,dX1->dX | Yp->dYp
 tot = [0.0] * 4
