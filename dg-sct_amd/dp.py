@@ -261,15 +261,31 @@ class GradAllReducer:
         self._reset()
 
     @staticmethod
-    def stage_buckets(stack) -> List[List[torch.nn.Parameter]]:
-        """One bucket per backbone stage of an AdapterStack, last stage first."""
-        out, idx = [], 0
+    def stage_buckets(stack, split_positions: Optional[str] = None) -> List[List[torch.nn.Parameter]]:
+        """One bucket per backbone stage of an AdapterStack, last stage first (backward order).
+
+        ``split_positions`` (default: environment ``DGSCT_DP_BUCKETS``): ``"position"`` cuts every stage whose adapters hold more than an
+        eighth of the gradient bytes into one bucket per POSITION (p2 adapters of a layer, then its p1 adapters: the order their
+        gradients appear in backward).  Stage 0 holds 53 % of the payload (the token-remap weights) and is the LAST stage of backward:
+        as one bucket its whole all-reduce is exposed behind the step; per position, three quarters of it run under the remaining
+        stage-0 backward.  On ONE rank every extra hook-launched collective costs ~0.5 ms of event traffic, more
+        than it can hide, so the default stays per stage; the switch exists so that an 8-GPU run can A/B it:
+            DGSCT_DP_BUCKETS=position python -m torch.distributed.run ... bench.py --gpus 8"""
+        mode = split_positions if split_positions is not None else os.environ.get("DGSCT_DP_BUCKETS", "stage")
+        per_stage, idx = [], 0
         for s in stack.stages:
-            ps = []
+            pos = []                                                    # buckets of this stage in FORWARD order: (layer, p1), (layer, p2), ...
             for i in range(idx, idx + s["layers"]):
-                for ml in (stack.audio_adapter_blocks_p1, stack.vis_adapter_blocks_p1, stack.audio_adapter_blocks_p2,
-                           stack.vis_adapter_blocks_p2):
-                    ps += list(ml[i].parameters())
-            out.append(ps)
+                pos.append(list(stack.audio_adapter_blocks_p1[i].parameters()) + list(stack.vis_adapter_blocks_p1[i].parameters()))
+                pos.append(list(stack.audio_adapter_blocks_p2[i].parameters()) + list(stack.vis_adapter_blocks_p2[i].parameters()))
+            per_stage.append(pos)
             idx += s["layers"]
-        return out[::-1]
+        total = sum(p.numel() for st in per_stage for b in st for p in b) or 1
+        out = []
+        for pos in per_stage[::-1]:
+            n = sum(p.numel() for b in pos for p in b)
+            if mode == "position" and n * 8 > total:
+                out += pos[::-1]
+            else:
+                out.append([p for b in pos for p in b])
+        return out

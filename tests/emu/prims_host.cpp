@@ -45,6 +45,8 @@ void check_async(const char*) {}
 void clear_async() {}
 int gemm_skinny_mode(int) { return 0; }
 static int g_wgbt = 1;
+static int g_tfs8 = 1;
+int tokattn_small8_mode(int set) { const int old = g_tfs8; if (set >= 0) g_tfs8 = set ? 1 : 0; return old; }      // (a kernel-shape switch: nothing to emulate)
 int wgrad_bt_mode(int set) { const int old = g_wgbt; if (set >= 0) g_wgbt = set ? 1 : 0; return old; }
 bool wgrad_bt_supported(const Ctx&, const WgBtJob*, int n) { return g_wgbt && n >= 1 && n <= WGBT_MAX; }
 void wgrad_bt(const Ctx& ctx, const WgBtJob* jobs, int n) {          // (either element type: the host loops read through ld())

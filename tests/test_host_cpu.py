@@ -330,7 +330,7 @@ def test_data_parallel_replica_runs_and_routes_gradients(flat):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def _dp_worker(rank, world, port, emu_path, q, flat):
+def _dp_worker(rank, world, port, emu_path, q, flat, buckets="stage"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -342,7 +342,9 @@ def _dp_worker(rank, world, port, emu_path, q, flat):
     st.load_state_dict(fx["state0"], strict=False)
     if flat:
         st.flatten_parameters()
-    red = GradAllReducer(GradAllReducer.stage_buckets(st))
+    red = GradAllReducer(GradAllReducer.stage_buckets(st, buckets))
+    if buckets == "position":                                      # (layer, p1 / p2) buckets of the heavy stages: 2 per layer (DGSCT_DP_BUCKETS=position)
+        assert len(red.buckets) == 2 * sum(s["layers"] for s in fx["stages"]), len(red.buckets)
     BT = fx["feats"][0][0].shape[0]
     lo, hi = rank * BT // world, (rank + 1) * BT // world
     feats = [(a[lo:hi].clone(), b[lo:hi].clone()) for a, b in fx["feats"]]
@@ -371,8 +373,8 @@ def _dp_worker(rank, world, port, emu_path, q, flat):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("flat", [False, True])
-def test_dp_allreduce_gloo_world2(flat):
+@pytest.mark.parametrize("flat,buckets", [(False, "stage"), (True, "stage"), (True, "position")])
+def test_dp_allreduce_gloo_world2(flat, buckets):
     """N > 1 path on CPU: clips sharded over 2 ranks, bucketed all-reduce (average) == single-rank gradient / 1
     of the concatenated batch divided by world (sum-of-clips loss), BN off."""
     emu_path = build_emu()
@@ -388,8 +390,8 @@ def test_dp_allreduce_gloo_world2(flat):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    port += 7 * int(flat)
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, emu_path, q, flat)) for r in range(2)]
+    port += 7 * int(flat) + 13 * int(buckets == "position")
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, emu_path, q, flat, buckets)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
