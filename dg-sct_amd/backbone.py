@@ -91,6 +91,28 @@ class _WindowAttentionV1(nn.Module):
         self.qkv = nn.Linear(dim, 3 * dim)
         self.proj = nn.Linear(dim, dim)
 
+    def _tables(self, mask):
+        """frozen per-block tables of the fused kernel (csrc/wattn.hip): bm [1 | nW, heads, n, n] = relative-position bias (+ shift mask),
+        scale [heads]; fp32, rebuilt only when the bias table changes (it is frozen in the reference: main_trans.py:211-256)"""
+        tab = self.relative_position_bias_table
+        key = (tab._version, tab.device, mask is None)
+        if getattr(self, "_tab_cache", (None,))[0] != key:
+            n, h = self.window_size[0] * self.window_size[1], self.num_heads
+            with torch.no_grad():
+                bm = tab[self.relative_position_index.reshape(-1)].reshape(n, n, h).permute(2, 0, 1).float()[None]
+                if mask is not None:
+                    bm = bm + mask.float()[:, None]
+                self._tab_cache = (key, bm.contiguous(), torch.full((h,), float(self.scale), dtype=torch.float32, device=tab.device))
+        return self._tab_cache[1], self._tab_cache[2]
+
+    def forward_map(self, y, H, W, shift, mask=None, lib=None):
+        """the same attention on the UN-partitioned map y [B, H*W, C]: qkv projection of the map, then one fused kernel that does the
+        window partition / cyclic shift by address arithmetic (no roll / partition copies, no [windows, heads, n, n] tensor), then proj"""
+        from . import ops
+        bm, scale = self._tables(mask)
+        o = ops.window_attention(self.qkv(y), bm, scale, H, W, self.window_size[0], shift, self.num_heads, lib)
+        return self.proj(o)
+
     def forward(self, x, mask=None):
         Bw, n, C = x.shape
         h = self.num_heads
@@ -110,9 +132,12 @@ class HTSATBlock(nn.Module):
     0): ``forward(x [B, H*W, C]) -> (x, attn)`` like the reference call ``f_a, _ = blk_a(f_a)``."""
 
     def __init__(self, dim: int, input_resolution: Tuple[int, int], num_heads: int, window_size: int = 8, shift_size: int = 0,
-                 mlp_ratio: float = 4.0):
+                 mlp_ratio: float = 4.0, fused: Optional[bool] = None, lib=None):
         super().__init__()
         self.dim, self.input_resolution, self.num_heads = dim, tuple(input_resolution), num_heads
+        # fused: None = the HIP window-attention kernel whenever it applies (bf16 on the GPU), False = the ATen formulation (the one pinned
+        # bit-exactly to the reference class on the CPU); lib: a C-ABI instance other than the default (the host emulation of the CPU tests)
+        self.fused, self._lib = fused, lib
         if min(self.input_resolution) <= window_size:                          # a window as large as the map: one window, no shift
             shift_size, window_size = 0, min(self.input_resolution)
         self.window_size, self.shift_size = window_size, shift_size
@@ -122,9 +147,20 @@ class HTSATBlock(nn.Module):
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self.register_buffer("attn_mask", _shift_mask(*self.input_resolution, window_size, shift_size))
 
+    def _use_fused(self, x) -> bool:
+        from . import ops
+        if self.fused is False or x.dtype != torch.bfloat16 or not (x.is_cuda or self._lib is not None):
+            return False
+        return ops.window_attention_supported(x.new_empty(1, 1, 3 * self.dim), self.window_size, self.num_heads)
+
     def forward(self, x):
         H, W = self.input_resolution
         B, L, C = x.shape
+        if self._use_fused(x):
+            # fused window attention (csrc/wattn.hip): the attention probabilities are never materialised, so the second result of the
+            # reference call `f_a, _ = blk_a(f_a)` (net_trans.py:897, discarded there) is None on this path
+            x = x + self.attn.forward_map(self.norm1(x), H, W, self.shift_size, self.attn_mask, self._lib)
+            return x + self.mlp(self.norm2(x)), None
         y = self.norm1(x).reshape(B, H, W, C)
         s = self.shift_size
         if s:
@@ -157,6 +193,33 @@ class _WindowAttentionV2(nn.Module):
         self.v_bias = nn.Parameter(torch.zeros(dim))
         self.proj = nn.Linear(dim, dim)
 
+    def _tables(self, mask):
+        """frozen tables of the fused kernel: bm = 16 sigmoid(cpb_mlp(offsets))[pair] (+ shift mask), scale = exp(min(logit_scale, log 100))"""
+        w = self.cpb_mlp[0].weight
+        key = (w._version, self.cpb_mlp[2].weight._version, self.logit_scale._version, w.device, mask is None)
+        if getattr(self, "_tab_cache", (None,))[0] != key:
+            n, h = self.window_size[0] * self.window_size[1], self.num_heads
+            with torch.no_grad():
+                table = self.cpb_mlp(self.relative_coords_table.to(w.dtype)).reshape(-1, h).float()
+                bm = (16 * torch.sigmoid(table[self.relative_position_index.reshape(-1)].reshape(n, n, h).permute(2, 0, 1)))[None]
+                if mask is not None:
+                    bm = bm + mask.float()[:, None]
+                scale = torch.clamp(self.logit_scale.float(), max=math.log(100.0)).exp().reshape(h)
+                self._tab_cache = (key, bm.contiguous(), scale.contiguous())
+        return self._tab_cache[1], self._tab_cache[2]
+
+    def forward_map(self, y, H, W, shift, mask=None, lib=None):
+        """cosine window attention on the un-partitioned map (see _WindowAttentionV1.forward_map): q, k are normalised here, the fused kernel
+        (csrc/wattn.hip) applies the per-head logit scale, the continuous position bias and the shift mask"""
+        from . import ops
+        B, L, C = y.shape
+        h = self.num_heads
+        bias3 = torch.cat([self.q_bias, torch.zeros_like(self.v_bias), self.v_bias])
+        qkv = F.linear(y, self.qkv.weight, bias3).reshape(B, L, 3, h, C // h)
+        qkv = torch.stack([F.normalize(qkv[:, :, 0], dim=-1), F.normalize(qkv[:, :, 1], dim=-1), qkv[:, :, 2]], dim=2).reshape(B, L, 3 * C)
+        bm, scale = self._tables(mask)
+        return self.proj(ops.window_attention(qkv, bm, scale, H, W, self.window_size[0], shift, h, lib))
+
     def forward(self, x, mask=None):
         Bw, n, C = x.shape
         h = self.num_heads
@@ -178,9 +241,10 @@ class SwinV2Block(nn.Module):
     ``attn_branch(x) = norm1(_attn(x))`` and ``mlp_branch(x) = norm2(mlp(x))`` (post-norm; drop-path 0 in the frozen model)."""
 
     def __init__(self, dim: int, input_resolution: Tuple[int, int], num_heads: int, window_size: int = 12, shift_size: int = 0,
-                 mlp_ratio: float = 4.0):
+                 mlp_ratio: float = 4.0, fused: Optional[bool] = None, lib=None):
         super().__init__()
         self.dim, self.input_resolution, self.num_heads = dim, tuple(input_resolution), num_heads
+        self.fused, self._lib = fused, lib                                     # (as HTSATBlock)
         if min(self.input_resolution) <= window_size:
             shift_size, window_size = 0, min(self.input_resolution)
         self.window_size, self.shift_size = window_size, shift_size
@@ -190,9 +254,13 @@ class SwinV2Block(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.register_buffer("attn_mask", _shift_mask(*self.input_resolution, window_size, shift_size))
 
+    _use_fused = HTSATBlock._use_fused
+
     def _attn(self, x):
         H, W = self.input_resolution
         B, L, C = x.shape
+        if self._use_fused(x):
+            return self.attn.forward_map(x, H, W, self.shift_size, self.attn_mask, self._lib)
         y = x.reshape(B, H, W, C)
         s = self.shift_size
         if s:
@@ -223,14 +291,14 @@ class FrozenBlocks(nn.Module):
     adapter layer; shifted windows on every second block of a stage, as the backbones alternate), randomly initialised -- no
     pretrained weights exist offline -- and frozen.  ``vis_block`` / ``aud_block`` are the callables ``AdapterStack.forward`` takes."""
 
-    def __init__(self, stages: Sequence[Dict[str, int]], dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, stages: Sequence[Dict[str, int]], dtype: torch.dtype = torch.bfloat16, fused: Optional[bool] = None):
         super().__init__()
         vis, aud = [], []
         for s in stages:
             rv, ra = int(round(math.sqrt(s["Nv"]))), int(round(math.sqrt(s["Na"])))
             for i in range(s["layers"]):
-                vis.append(SwinV2Block(s["Cv"], (rv, rv), _SWIN_HEADS[s["Cv"]], window_size=12, shift_size=0 if i % 2 == 0 else 6))
-                aud.append(HTSATBlock(s["Ca"], (ra, ra), _HTSAT_HEADS[s["Ca"]], window_size=8, shift_size=0 if i % 2 == 0 else 4))
+                vis.append(SwinV2Block(s["Cv"], (rv, rv), _SWIN_HEADS[s["Cv"]], window_size=12, shift_size=0 if i % 2 == 0 else 6, fused=fused))
+                aud.append(HTSATBlock(s["Ca"], (ra, ra), _HTSAT_HEADS[s["Ca"]], window_size=8, shift_size=0 if i % 2 == 0 else 4, fused=fused))
         self.vis, self.aud = nn.ModuleList(vis), nn.ModuleList(aud)
         self.to(dtype)
         for p in self.parameters():

@@ -927,6 +927,10 @@ static bool xattn_fwd3_launch(const Ctx& ctx, const XF2Args& a, int B) {
   return true;
 }
 static bool xattn_bwd3_launch(const Ctx& ctx, XB2Args a, int B) {
+  // round 6 (tools/attn_bench.py, DGSCT_ATTN_CSPLIT_MINC sweep): at C = 512 the wave-per-block kernel is the faster BACKWARD (N = 144:
+  // 58.3 vs 70.3 us) while the C-split FORWARD still wins there (20.5 vs 24.9 us): the backward splits from C >= 768 only
+  static const int min_c_bwd = getenv("DGSCT_XBWD_CSPLIT_MINC") ? atoi(getenv("DGSCT_XBWD_CSPLIT_MINC")) : 768;
+  if (a.C < min_c_bwd) return false;
   if (!csplit_ok(B, a.N, a.C, 2)) return false;          // X and dX1 slabs in registers: 64 VGPRs per slab pair
   const int spw = ((a.C + CS2 - 1) / CS2 + 3) / 4;
   a.wpf = (a.N + 31) / 32;

@@ -272,6 +272,25 @@ int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream) {
   return has_error() ? 1 : 0;
 }
 
+int dgsct_window_attn_forward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
+                              const float* scale, void* out, float* lse, void* stream) {
+  begin_call();
+  if (!qkv || !bm || !scale || !out || !lse) { set_error("dgsct_window_attn_forward: NULL argument"); return 2; }
+  const int rc = window_attn_forward(stream, B, H, W, ws, shift, heads, hd, nwm, qkv, bm, scale, out, lse);
+  if (rc) return rc;
+  check_async("dgsct_window_attn_forward");
+  return has_error() ? 1 : 0;
+}
+int dgsct_window_attn_backward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
+                               const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, void* stream) {
+  begin_call();
+  if (!qkv || !bm || !scale || !out || !lse || !dout || !dqkv) { set_error("dgsct_window_attn_backward: NULL argument"); return 2; }
+  const int rc = window_attn_backward(stream, B, H, W, ws, shift, heads, hd, nwm, qkv, bm, scale, out, lse, dout, dqkv);
+  if (rc) return rc;
+  check_async("dgsct_window_attn_backward");
+  return has_error() ? 1 : 0;
+}
+
 int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, const float* bias, int relu, void* D, void* w8,
                         float* scale, void* stream) {
   begin_call();

@@ -361,6 +361,14 @@ void temporal_gate_bwd(const Ctx&, int R, int D, float gamma, const float* akv, 
 void frame_scale_fwd(const Ctx&, int rows, long inner, float gamma, const void* x, const float* g, void* y);
 void frame_scale_bwd(const Ctx&, int rows, long inner, float gamma, const void* x, const float* g, const void* dy, void* dx, float* dg);
 
+// ---- fused window attention of the frozen backbone blocks (wattn.hip; reference htsat.py:50-132) --------------
+// O = softmax(scale_h q k^T + bm[w % nwm][h]) v per (frame, window, head), window partition + cyclic shift as address arithmetic on the
+// [B][H*W][3][heads][hd] qkv projection of the un-partitioned map; bf16, hd in {8, 16, 24, 32}, ws*ws <= 144.  Return 0 or 2 (set_error).
+int window_attn_forward(void* stream, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
+                        const float* scale, void* out, float* lse);
+int window_attn_backward(void* stream, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
+                         const float* scale, const void* out, const float* lse, const void* dout, void* dqkv);
+
 // Small fp32/E elementwise helpers on [n]-sized vectors (n <= a few 100k).
 enum EwOp : int {
   EW_MUL = 0,          // o = a*b

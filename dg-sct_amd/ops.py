@@ -670,3 +670,57 @@ def map_pool(f: torch.Tensor, spatial_att_maps: torch.Tensor, lib: Optional[Lib]
     from ._lib import default_lib
     pooled = _MapPoolFn.apply(lib or default_lib(), f.contiguous(), spatial_att_maps.reshape(BT, N).contiguous().float())
     return pooled.to(f.dtype).unsqueeze(1)
+
+
+# ---- fused window attention of the frozen backbone blocks -------------------------------------------------------
+class _WindowAttnFn(torch.autograd.Function):
+    """softmax(scale q k^T + bm) v per (frame, window, head) on the qkv projection of the UN-partitioned map; window partition and cyclic
+    shift are address arithmetic inside the kernel (csrc/wattn.hip).  bm / scale are frozen tables: no gradient."""
+
+    @staticmethod
+    def forward(ctx, lib, qkv, bm, scale, H, W, ws, shift, heads):
+        B, L, C3 = qkv.shape
+        hd = C3 // (3 * heads)
+        nW = (H // ws) * (W // ws)
+        geom = (B, H, W, ws, shift, heads, hd, int(bm.shape[0]))
+        out = torch.empty(B, L, heads * hd, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, nW, heads, ws * ws, dtype=torch.float32, device=qkv.device)
+        _mark_stream_use(qkv, bm, scale)
+        with _dev_guard(qkv):
+            lib.window_attn_forward(geom, qkv.data_ptr(), bm.data_ptr(), scale.data_ptr(), out.data_ptr(), lse.data_ptr(), _stream_of(qkv))
+        ctx.lib, ctx.geom = lib, geom
+        ctx.save_for_backward(qkv, bm, scale, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, bm, scale, out, lse = ctx.saved_tensors
+        dout = dout.contiguous()
+        if dout.dtype != qkv.dtype:
+            dout = dout.to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        _mark_stream_use(qkv, bm, scale, out, lse, dout)
+        with _dev_guard(qkv):
+            ctx.lib.window_attn_backward(ctx.geom, qkv.data_ptr(), bm.data_ptr(), scale.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                         dout.data_ptr(), dqkv.data_ptr(), _stream_of(qkv))
+        return None, dqkv, None, None, None, None, None, None, None
+
+
+def window_attention_supported(qkv: torch.Tensor, ws: int, heads: int) -> bool:
+    """what csrc/wattn.hip takes: bf16 (the host emulation of the CPU tests: bf16 too), head width 8 / 16 / 24 / 32, windows of <= 144 tokens"""
+    if qkv.dtype != torch.bfloat16 or qkv.dim() != 3 or qkv.shape[-1] % (3 * heads):
+        return False
+    hd = qkv.shape[-1] // (3 * heads)
+    return hd in (8, 16, 24, 32) and ws * ws <= 144 and (ws * ws) % 4 == 0
+
+
+def window_attention(qkv: torch.Tensor, bm: torch.Tensor, scale: torch.Tensor, H: int, W: int, ws: int, shift: int, heads: int,
+                     lib: Optional[Lib] = None) -> torch.Tensor:
+    """qkv [B, H*W, 3*heads*hd] bf16 (token-major map, NOT partitioned / rolled), bm [1 | nW, heads, n, n] fp32, scale [heads] fp32
+    -> O [B, H*W, heads*hd] at the map positions (what window_reverse + roll-back of the reference block produce)."""
+    if not window_attention_supported(qkv, ws, heads):
+        raise RuntimeError("dg-sct_amd: window_attention takes bf16 qkv with head width 8/16/24/32 and windows of <= 144 tokens")
+    if bm.dtype != torch.float32 or scale.dtype != torch.float32 or bm.shape[1:] != (heads, ws * ws, ws * ws):
+        raise RuntimeError("dg-sct_amd: window_attention: bm must be fp32 [1 | windows, heads, n, n] and scale fp32 [heads]")
+    from ._lib import default_lib
+    return _WindowAttnFn.apply(lib or default_lib(), qkv.contiguous(), bm.contiguous(), scale.contiguous(), H, W, ws, shift, heads)

@@ -205,6 +205,23 @@ int dgsct_map_pool_forward(int dtype, int BT, int N, int C, const void* F, const
 int dgsct_map_pool_backward(int dtype, int BT, int N, int C, const void* F, const float* map, const float* dPooled,
                             void* dF, float* dMap, void* stream);
 
+/* ---- fused window attention of the FROZEN backbone blocks ------------------------------------
+ * Replaces the body of HTS-AT's `WindowAttention.forward` between its qkv and proj Linears (DG-SCT/AVE/nets/htsat.py:103-131)
+ * together with the window partition / reverse and the cyclic `torch.roll`s of the block around it (htsat.py:196-229), and the same
+ * part of the timm Swin-V2 block the AVE loop calls at DG-SCT/AVE/nets/net_trans.py:894 (cosine form: q, k passed in normalised):
+ *   O[b][p(w,i)][h][:] = sum_j softmax_j( scale[h] * q_i . k_j + bm[w % nwm][h][i][j] ) v_j
+ * qkv  : bf16 [B][H*W][3][heads][hd] -- the qkv projection of the UN-partitioned, un-rolled token-major map;
+ * bm   : fp32 [nwm][heads][n][n], n = ws*ws -- relative-position bias plus (nwm = number of windows) the additive shift mask;
+ *        nwm = 1 for un-shifted blocks.  Frozen: no gradient is produced for it or for `scale` (fp32 [heads]);
+ * out  : bf16 [B][H*W][heads][hd];   lse: fp32 [B][windows][heads][n] (kept for backward);
+ * backward: dqkv laid out like qkv, every element written (no pre-zeroing needed).
+ * p(w,i) is the map position of token i of window w after the block's roll by -shift: ((wy*ws + iy + shift) % H, (wx*ws + ix + shift) % W).
+ * Limits: ws*ws <= 144 and a multiple of 4, hd in {8,16,24,32}, H % ws == W % ws == 0.  Asynchronous on `stream`; 0 or an error code. */
+int dgsct_window_attn_forward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
+                              const float* scale, void* out, float* lse, void* stream);
+int dgsct_window_attn_backward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
+                               const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, void* stream);
+
 /* ---- gate application of the post-backbone TemporalAttention ---------------------------
  * Replaces the tail of `TemporalAttention.forward` (DG-SCT/AVE/nets/net_trans.py:240-251; AVVP nets/mgn.py:148-159):
  *   audio_gate = audio_gated(audio_key_value_feature); video_gate = video_gated(video_key_value_feature)     [T,B,1]

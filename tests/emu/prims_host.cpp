@@ -13,6 +13,7 @@
 
 #include "../../dg-sct_amd/csrc/prims.h"
 #include "../../dg-sct_amd/csrc/gemm_int.h"
+#include "../../dg-sct_amd/csrc/err.h"
 
 namespace dgsct {
 
@@ -1072,5 +1073,99 @@ void gemm_fp8(const Ctx&, int M, int N, int K, const void* A, long lda, const vo
       if (relu) v = std::max(v, 0.f);
       st(D, DT_BF16, (long)m * ldd + n, v);
     }
+}
+}  // namespace dgsct
+
+// ---- fused window attention of the frozen blocks (wattn.hip): plain loops, same addressing, bf16 storage ------------------------------
+namespace dgsct {
+namespace {
+struct WinGeom { int B, H, W, ws, shift, heads, hd, nwm, n, nwx, nW, L, C; };
+static bool win_geom(WinGeom& g, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm) {
+  if (B < 1 || ws < 1 || H % ws || W % ws || ws * ws > 144 || (ws * ws) % 4 || hd % 8 || hd > 32 || hd < 8 || shift < 0 || shift >= ws || heads < 1) {
+    set_error("window attention (host emulation): unsupported geometry"); return false;
+  }
+  g = WinGeom{B, H, W, ws, shift, heads, hd, nwm, ws * ws, W / ws, (H / ws) * (W / ws), H * W, heads * hd};
+  if (nwm != 1 && nwm != g.nW) { set_error("window attention (host emulation): bias/mask table with %d window types", nwm); return false; }
+  return true;
+}
+static int win_row(const WinGeom& g, int w, int t) {
+  const int wy = w / g.nwx, wx = w % g.nwx, ly = t / g.ws, lx = t % g.ws;
+  return ((wy * g.ws + ly + g.shift) % g.H) * g.W + (wx * g.ws + lx + g.shift) % g.W;
+}
+}  // namespace
+int window_attn_forward(void*, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv_, const float* bm,
+                        const float* scale, void* out_, float* lse) {
+  WinGeom g;
+  if (!win_geom(g, B, H, W, ws, shift, heads, hd, nwm)) return 2;
+  const uint16_t* qkv = (const uint16_t*)qkv_; uint16_t* out = (uint16_t*)out_;
+  const int n = g.n;
+  std::vector<float> s(n);
+  for (int b = 0; b < B; ++b) for (int w = 0; w < g.nW; ++w) for (int h = 0; h < heads; ++h) {
+    const float* bmh = bm + ((long)(w % nwm) * heads + h) * n * n;
+    for (int i = 0; i < n; ++i) {
+      const uint16_t* q = qkv + ((long)b * g.L + win_row(g, w, i)) * 3 * g.C + h * hd;
+      float mx = -INFINITY;
+      for (int j = 0; j < n; ++j) {
+        const uint16_t* k = qkv + ((long)b * g.L + win_row(g, w, j)) * 3 * g.C + g.C + h * hd;
+        float a = 0.f;
+        for (int d = 0; d < hd; ++d) a += bf2f(q[d]) * bf2f(k[d]);
+        s[j] = a * scale[h] + bmh[(long)i * n + j];
+        mx = std::max(mx, s[j]);
+      }
+      float sum = 0.f;
+      for (int j = 0; j < n; ++j) { s[j] = std::exp(s[j] - mx); sum += s[j]; }
+      uint16_t* o = out + ((long)b * g.L + win_row(g, w, i)) * g.C + h * hd;
+      for (int d = 0; d < hd; ++d) {
+        float a = 0.f;
+        for (int j = 0; j < n; ++j) a += bf2f(f2bf(s[j])) * bf2f(qkv[((long)b * g.L + win_row(g, w, j)) * 3 * g.C + 2 * g.C + h * hd + d]);   // (bf16 probabilities, as on the device)
+        o[d] = f2bf(a / sum);
+      }
+      lse[(((long)b * g.nW + w) * heads + h) * n + i] = mx + std::log(sum);
+    }
+  }
+  return 0;
+}
+int window_attn_backward(void*, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv_, const float* bm,
+                         const float* scale, const void* out_, const float* lse, const void* dout_, void* dqkv_) {
+  WinGeom g;
+  if (!win_geom(g, B, H, W, ws, shift, heads, hd, nwm)) return 2;
+  const uint16_t* qkv = (const uint16_t*)qkv_; const uint16_t* out = (const uint16_t*)out_; const uint16_t* dout = (const uint16_t*)dout_;
+  uint16_t* dqkv = (uint16_t*)dqkv_;
+  const int n = g.n;
+  std::vector<float> P((size_t)n * n), dS((size_t)n * n), Dv(n);
+  for (int b = 0; b < B; ++b) for (int w = 0; w < g.nW; ++w) for (int h = 0; h < heads; ++h) {
+    const float* bmh = bm + ((long)(w % nwm) * heads + h) * n * n;
+    auto row = [&](int t) { return (long)b * g.L + win_row(g, w, t); };
+    for (int i = 0; i < n; ++i) {
+      float d = 0.f;
+      for (int c = 0; c < hd; ++c) d += bf2f(out[row(i) * g.C + h * hd + c]) * bf2f(dout[row(i) * g.C + h * hd + c]);
+      Dv[i] = d;
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+      float a = 0.f, dp = 0.f;
+      for (int c = 0; c < hd; ++c) {
+        a += bf2f(qkv[row(i) * 3 * g.C + h * hd + c]) * bf2f(qkv[row(j) * 3 * g.C + g.C + h * hd + c]);
+        dp += bf2f(dout[row(i) * g.C + h * hd + c]) * bf2f(qkv[row(j) * 3 * g.C + 2 * g.C + h * hd + c]);
+      }
+      const float p = std::exp(a * scale[h] + bmh[(long)i * n + j] - lse[(((long)b * g.nW + w) * heads + h) * n + i]);
+      P[(size_t)i * n + j] = bf2f(f2bf(p));
+      dS[(size_t)i * n + j] = bf2f(f2bf(p * (dp - Dv[i])));
+    }
+    for (int i = 0; i < n; ++i) for (int c = 0; c < hd; ++c) {
+      float a = 0.f;
+      for (int j = 0; j < n; ++j) a += dS[(size_t)i * n + j] * bf2f(qkv[row(j) * 3 * g.C + g.C + h * hd + c]);
+      dqkv[row(i) * 3 * g.C + h * hd + c] = f2bf(a * scale[h]);
+    }
+    for (int j = 0; j < n; ++j) for (int c = 0; c < hd; ++c) {
+      float ak = 0.f, av = 0.f;
+      for (int i = 0; i < n; ++i) {
+        ak += dS[(size_t)i * n + j] * bf2f(qkv[row(i) * 3 * g.C + h * hd + c]);
+        av += P[(size_t)i * n + j] * bf2f(dout[row(i) * g.C + h * hd + c]);
+      }
+      dqkv[row(j) * 3 * g.C + g.C + h * hd + c] = f2bf(ak * scale[h]);
+      dqkv[row(j) * 3 * g.C + 2 * g.C + h * hd + c] = f2bf(av);
+    }
+  }
+  return 0;
 }
 }  // namespace dgsct

@@ -14,6 +14,8 @@ import pytest
 import torch
 
 from helpers import ROOT
+import sys
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 from dgsct_amd.backbone import FrozenBlocks, HTSATBlock, SwinV2Block
 
 
@@ -118,13 +120,99 @@ def test_adapter_stack_with_frozen_blocks_on_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["plain", "shifted"])
-def test_htsat_block_bf16_on_gpu(name):
+@pytest.mark.parametrize("fused", [False, True], ids=["aten", "fused"])
+@pytest.mark.parametrize("name", ["plain", "shifted", "one_window"])
+def test_htsat_block_bf16_on_gpu(name, fused):
+    """bf16 on the GPU against the REFERENCE class's fp32 results (fixture): the ATen formulation and the fused window-attention kernel
+    (csrc/wattn.hip), output and input gradient"""
     fx = _cases()[name]
     dim, res, heads, ws, shift = fx["cfg"]
     dev = torch.device("cuda:0")
-    blk = HTSATBlock(dim, (res, res), heads, window_size=ws, shift_size=shift).eval()
+    blk = HTSATBlock(dim, (res, res), heads, window_size=ws, shift_size=shift, fused=fused).eval()
     blk.load_state_dict(fx["state"])
     blk = blk.to(dev, torch.bfloat16)
-    y, _ = blk(fx["x"].to(dev, torch.bfloat16))
+    x = fx["x"].to(dev, torch.bfloat16).requires_grad_(True)
+    y, attn = blk(x)
+    assert (attn is None) == fused
+    y.backward(fx["cot"].to(dev, torch.bfloat16))
     assert ((y.float().cpu() - fx["y"]).norm() / fx["y"].norm()) < 2e-2
+    assert ((x.grad.float().cpu() - fx["dx"]).norm() / fx["dx"].norm()) < 3e-2
+
+
+_L2 = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm().clamp_min(1e-30)).item()     # noqa: E731
+# (block class, width, map side, heads, window, shift): HTS-AT stage-0 / stage-3 geometry (head width 24), Swin-V2-B stage 0 (12 x 12 windows of
+# 144 tokens, shifted), Swin-V2 with the map as ONE 6 x 6 window (stage 3 at 192^2: 36 tokens)
+_FUSED_CASES = [(HTSATBlock, 96, 16, 4, 8, 0), (HTSATBlock, 96, 16, 4, 8, 4), (HTSATBlock, 192, 8, 8, 8, 0), (SwinV2Block, 128, 24, 4, 12, 6),
+                (SwinV2Block, 128, 24, 4, 12, 0), (SwinV2Block, 256, 6, 8, 12, 0)]
+
+
+def _block_pair(cls, dim, res, heads, ws, shift, lib, device):
+    torch.manual_seed(3)
+    ref = cls(dim, (res, res), heads, window_size=ws, shift_size=shift, fused=False)
+    with torch.no_grad():
+        for n_, p_ in ref.named_parameters():
+            if "bias_table" in n_:
+                p_.copy_(0.5 * torch.randn_like(p_))                          # (trunc_normal(0.02) would leave the bias invisible)
+    fused = cls(dim, (res, res), heads, window_size=ws, shift_size=shift, fused=True, lib=lib)
+    fused.load_state_dict(ref.state_dict())
+    x = torch.randn(3, res * res, dim).bfloat16()
+    g = torch.randn(3, res * res, dim).bfloat16()
+    out = {}
+    for tag, m, dt in (("fp32", ref, torch.float32), ("aten", ref, torch.bfloat16), ("fused", fused, torch.bfloat16)):
+        m = m.to(device, dt)
+        xi = x.clone().to(device, dt).requires_grad_(True)              # (a fresh leaf: .to() of a bf16 CPU tensor to bf16 / cpu is the tensor itself)
+        y = m(xi)
+        y = y[0] if isinstance(y, tuple) else y
+        y.backward(g.to(device, dt))
+        out[tag] = (y.detach().float().cpu(), xi.grad.float().cpu())
+    return out
+
+
+def _check_fused(out):
+    """the fused path is held to the fp32 evaluation of the SAME block: no further from it than 1.5 x the bf16 ATen path is (+ 2e-3)"""
+    for k in (0, 1):
+        e_f, e_a = _L2(out["fused"][k], out["fp32"][k]), _L2(out["aten"][k], out["fp32"][k])
+        assert e_f < 1.5 * e_a + 2e-3, (k, e_f, e_a)
+
+
+@pytest.mark.parametrize("case", _FUSED_CASES, ids=lambda c: f"{c[0].__name__}-{c[1]}-{c[2]}-s{c[5]}")
+def test_fused_window_attention_semantics_on_the_host_emulation(case):
+    """CPU: the C ABI's window attention (dgsct_window_attn_*, here the host-loop emulation of tests/emu with the kernel's addressing:
+    window partition + cyclic shift as index arithmetic on the un-partitioned qkv map, bias + mask as one table) inside the blocks,
+    against the ATen formulation that is pinned to the reference class"""
+    from build_emu import build_emu
+    from dgsct_amd._lib import Lib
+    _check_fused(_block_pair(*case, Lib(build_emu()), torch.device("cpu")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _FUSED_CASES, ids=lambda c: f"{c[0].__name__}-{c[1]}-{c[2]}-s{c[5]}")
+def test_fused_window_attention_kernel_on_gpu(case):
+    _check_fused(_block_pair(*case, None, torch.device("cuda:0")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(2, 16, 16, 8, 4, 4, 24), (2, 24, 24, 12, 6, 4, 32), (3, 6, 6, 6, 0, 8, 32), (2, 8, 8, 8, 0, 3, 16), (1, 24, 12, 12, 0, 2, 8)])
+def test_window_attention_kernel_against_the_emulation(geom):
+    """the gfx950 kernel against the host loops on identical bf16 inputs through the same C-ABI entry points: forward O and lse, backward
+    dqkv -- shifted and un-shifted windows, head widths 8 ... 32, 36 / 64 / 144-token windows, non-square maps"""
+    from build_emu import build_emu
+    from dgsct_amd import ops
+    from dgsct_amd._lib import Lib, default_lib
+    B, H, W, ws, shift, heads, hd = geom
+    n, nW = ws * ws, (H // ws) * (W // ws)
+    gen = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, H * W, 3 * heads * hd, generator=gen).bfloat16()
+    bm = torch.randn(nW if shift else 1, heads, n, n, generator=gen)
+    if shift:
+        bm[:, :, : n // 2, n // 2:] -= 100.0                                  # mask-like entries
+    scale = torch.rand(heads, generator=gen) + 0.2
+    dout = torch.randn(B, H * W, heads * hd, generator=gen).bfloat16()
+    res = {}
+    for tag, lib, dev in (("emu", Lib(build_emu()), torch.device("cpu")), ("hip", default_lib(), torch.device("cuda:0"))):
+        q = qkv.detach().clone().to(dev).requires_grad_(True)
+        o = ops.window_attention(q, bm.to(dev), scale.to(dev), H, W, ws, shift, heads, lib)
+        o.backward(dout.to(dev))
+        res[tag] = (o.detach(), q.grad)
+    assert _L2(res["hip"][0], res["emu"][0]) < 6e-3
+    assert _L2(res["hip"][1], res["emu"][1]) < 1e-2
