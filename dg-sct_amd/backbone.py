@@ -256,6 +256,15 @@ class SwinV2Block(nn.Module):
 
     _use_fused = HTSATBlock._use_fused
 
+    # buffers a timm checkpoint may or may not carry depending on the release (registered persistent in some, not in others); they are
+    # pure functions of the window size, rebuilt by the constructor, so a by-name load ignores them
+    _DERIVED = ("relative_coords_table", "relative_position_index")
+
+    def load_timm_state_dict(self, sd, strict: bool = True):
+        """load a timm `SwinTransformerV2Block` state dict by name: derived index / offset tables are dropped, everything else must match"""
+        sd = {k: v for k, v in sd.items() if not k.endswith(self._DERIVED)}
+        return self.load_state_dict(sd, strict=strict)
+
     def _attn(self, x):
         H, W = self.input_resolution
         B, L, C = x.shape

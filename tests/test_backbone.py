@@ -78,6 +78,28 @@ def test_swinv2_block_windowing_against_a_per_token_evaluation(res, ws, shift):
         assert blk.shift_size == 0 and blk.attn_mask is None                 # a window as large as the map: no shift (stages 2-3 at 192^2)
 
 
+def test_swinv2_block_loads_a_timm_style_state_dict():
+    """a timm checkpoint names the block's tensors `attn.{qkv.weight, q_bias, v_bias, logit_scale, cpb_mlp.0.*, cpb_mlp.2.weight,
+    proj.*}`, `norm1 / norm2.*`, `mlp.fc1 / fc2.*`, `attn_mask`, and -- depending on the release -- the derived buffers
+    `attn.relative_coords_table` / `attn.relative_position_index`.  Both key sets must load by name (parity itself stays UNPINNED: timm is
+    not installed here)."""
+    blk = SwinV2Block(128, (24, 24), 4, window_size=12, shift_size=6)
+    own = blk.state_dict()
+    expect = {"attn.logit_scale", "attn.cpb_mlp.0.weight", "attn.cpb_mlp.0.bias", "attn.cpb_mlp.2.weight", "attn.qkv.weight", "attn.q_bias",
+              "attn.v_bias", "attn.proj.weight", "attn.proj.bias", "norm1.weight", "norm1.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+              "mlp.fc2.weight", "mlp.fc2.bias", "norm2.weight", "norm2.bias", "attn_mask"}
+    assert set(own) == expect, set(own) ^ expect
+    torch.manual_seed(1)
+    sd = {k: torch.randn_like(v) for k, v in own.items()}
+    blk.load_timm_state_dict(sd)                                              # release without the derived buffers
+    sd2 = dict(sd, **{"attn.relative_coords_table": blk.attn.relative_coords_table.clone(),
+                      "attn.relative_position_index": blk.attn.relative_position_index.clone()})
+    blk.load_timm_state_dict(sd2)                                             # release that stores them
+    assert all(torch.equal(blk.state_dict()[k], v) for k, v in sd.items())
+    with pytest.raises(RuntimeError):
+        blk.load_timm_state_dict(dict(sd, bogus=torch.zeros(1)))
+
+
 def test_frozen_blocks_are_frozen_and_shaped_for_the_ave_stack():
     from dgsct_amd import ave_stage_shapes
     fb = FrozenBlocks(ave_stage_shapes("swinv2_base"), dtype=torch.float32)
