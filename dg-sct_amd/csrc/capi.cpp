@@ -318,6 +318,7 @@ int dgsct_test_tune(const char* key, int value) {
   if (key && !strcmp(key, "skip")) return dgsct::plan_skip_mode(value);            // what-if timing switches (plan.cpp): results are garbage
   if (key && !strcmp(key, "gemmfx")) return gemmfx_mode(value);
   if (key && !strcmp(key, "g8pipe")) return dgsct::gemm8_pipe_mode(value);
+  if (key && !strcmp(key, "g8stag")) return dgsct::gemm8_stag_mode(value);
   if (key && !strcmp(key, "g8wg")) return dgsct::gemm8_wg_target(value);
   if (key && !strcmp(key, "wgbt")) return dgsct::wgrad_bt_mode(value);
   if (key && !strcmp(key, "cfgx")) return dgsct::gemm_cfgx_mode(value);

@@ -74,6 +74,7 @@ struct G8 {
   const float* r1_m; const float* r1_n; const float* bias_n;
   const char* R;                          // bf16 residual laid out like D (ldd, dbs), added in the row pass (plain stores only); NULL: none
   int gm;                                 // m-tiles per group of the work list (tile order, see the kernel)
+  int stag;                               // staggered DMA issue of the two wave halves (PIPE loop; dgsct_test_tune "g8stag")
   int dbg;                                // DGSCT_GEMM8_DBG (timing experiments only, results are garbage): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMA
 };
 
@@ -297,6 +298,13 @@ void gemm8_kernel(const G8 p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g8_val(fa[S][i]), g8_val(fb[S][j]), acc[i][j], 0, 0, 0);
       if (prio) __builtin_amdgcn_s_setprio(0);
     };
+    // (round 6, p.stag) The two waves of a SIMD are waves w and w + NW / 2.  In lock-step both issue their 7 LDS-DMA instructions of the
+    // tile after next right behind the barrier (~100 cycles each beside reads and MFMAs) while the SIMD's matrix pipe has nothing to do.
+    // With `stag` the upper half of the waves issues its share a quarter of a k-tile LATER (tile it + 1 into the buffer the barrier at
+    // the end of iteration it - 1 freed, behind the first MFMA group of iteration it; still covered by the vmcnt(0) in front of this
+    // iteration's barrier), so one wave of every SIMD multiplies while the other one issues.
+    const bool late = p.stag && wave >= G8_NW / 2;
+    const bool late1 = late && p.stag == 1, late2 = late && p.stag == 2;
     if (nk > 0) {
       issue(kt_begin, 0);
       if (nk > 1) { issue(kt_begin + 1, 1); g8_wait_vm<NDMA>(); } else g8_wait_vm<0>();
@@ -310,11 +318,13 @@ void gemm8_kernel(const G8 p) {
         mmap(0);
         __builtin_amdgcn_sched_barrier(0);
         landedp(1);
+        if (late1 && it >= 1 && it + 1 < nk) issue(kt_begin + it + 1, (it + 1) & 1);
         rdp(std::integral_constant<int, 2>{}, boff);
         __builtin_amdgcn_sched_barrier(0);
         mmap(1);
         __builtin_amdgcn_sched_barrier(0);
         landedp(0);
+        if (late2 && it >= 1 && it + 1 < nk) issue(kt_begin + it + 1, (it + 1) & 1);
         rdp(std::integral_constant<int, 3>{}, boff);
         __builtin_amdgcn_sched_barrier(0);
         mmap(0);
@@ -323,7 +333,7 @@ void gemm8_kernel(const G8 p) {
         if (it + 1 < nk) {
           g8_wait_vm<0>();                                     // tile it + 1 (the only group in flight) has landed
           __builtin_amdgcn_s_barrier();
-          if (it + 2 < nk) issue(kt_begin + it + 2, it & 1);
+          if (!late && it + 2 < nk) issue(kt_begin + it + 2, it & 1);
           rdp(std::integral_constant<int, 0>{}, bnext);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -520,6 +530,8 @@ static void g8_launch_p(const G8& k, int ak, int bk, bool batched, bool two, dim
 }
 // "g8pipe" (dgsct_test_tune / DGSCT_G8PIPE): 1 = the cross-tile pipelined k-loop (default), 0 = the round-3 loop (two barriers per k-tile)
 static std::atomic<int> g_g8pipe{getenv("DGSCT_G8PIPE") ? atoi(getenv("DGSCT_G8PIPE")) : 1};
+static std::atomic<int> g_g8stag{getenv("DGSCT_G8STAG") ? atoi(getenv("DGSCT_G8STAG")) : 1};      // 1: after the first MFMA group (default), 2: after the second, 0: lock-step
+int gemm8_stag_mode(int set) { const int old = g_g8stag.load(); if (set >= 0) g_g8stag.store(set); return old; }
 int gemm8_pipe_mode(int set) { const int old = g_g8pipe.load(); if (set >= 0) g_g8pipe.store(set ? 1 : 0); return old; }
 template <int BN>
 static void g8_launch(const G8& k, int ak, int bk, bool batched, bool two, dim3 grid, hipStream_t s) {
@@ -651,6 +663,7 @@ split_done:
   k.gm = gm_env < 1 ? 1 : (gm_env > tiles_m ? tiles_m : gm_env);
   static const int dbg_env = getenv("DGSCT_GEMM8_DBG") ? atoi(getenv("DGSCT_GEMM8_DBG")) : 0;
   k.dbg = dbg_env;
+  k.stag = g_g8stag.load(std::memory_order_relaxed);
   dim3 grid((unsigned)tiles, splitk, 1);
   hipStream_t s = (hipStream_t)ctx.stream;
   GemmProfShape shp{g.M, g.N, g.K, g.KB, g.batch, splitk, BN == 256 ? 8 : 9, g.A.kmajor, g.B.kmajor, g.atomic, !g.atomic, 0.0};

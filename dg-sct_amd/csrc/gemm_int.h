@@ -29,6 +29,7 @@ bool gemm_tall_try(const Ctx& ctx, const Gemm& g);
 int gemm_tall_mode(int set);        // 0: off, 1: on (default; DGSCT_NO_GEMM_TALL).  set < 0: query.
 
 int gemm8_pipe_mode(int set);      // k-loop variant of gemm8 (1: pipelined across k-tiles, default; 0: two barriers per k-tile)
+int gemm8_stag_mode(int set);      // (round 6) the two wave halves issue their LDS-DMA shares a quarter k-tile apart (1) or in lock-step (0)
 int gemm8_wg_target(int set);      // experiment: workgroup target of late-stage weight gradients on gemm8 (0 = off)
 int gemm_cfgx_mode(int set);       // tile-configuration experiments of the tiled engine (bit mask)
 int gemm_noatomic_mode(int set);   // what-if (timing only): split-K partials as plain stores

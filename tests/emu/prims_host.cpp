@@ -67,6 +67,7 @@ int gemm_noatomic_mode(int) { return 0; }
 int gemm_cfgx_mode(int) { return 0; }
 int gemm8_wg_target(int) { return 0; }
 int gemm8_pipe_mode(int) { return 0; }
+int gemm8_stag_mode(int) { return 0; }
 
 void zero(const Ctx&, void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
 

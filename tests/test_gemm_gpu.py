@@ -225,13 +225,15 @@ def test_gemm_softmax_epilogues(mode, tk):
 
 
 # ---- gemm8.hip: the 8-wave LDS-DMA pipelined kernel of the deep products -------------------------------------------------
-@pytest.fixture
-def gemm8_all():
-    """route every eligible shape to the 8-wave kernel (its size gates would send these small test matrices to the tiled engine)"""
+@pytest.fixture(params=[1, 0], ids=["staggered", "lockstep"])
+def gemm8_all(request):
+    """route every eligible shape to the 8-wave kernel (its size gates would send these small test matrices to the tiled engine); both
+    DMA-issue schedules of its pipelined k-loop: the two wave halves a quarter k-tile apart (round 6, default) and in lock-step"""
     lib = default_lib()
-    old = lib.test_tune("gemm8", 2)
+    old, olds = lib.test_tune("gemm8", 2), lib.test_tune("g8stag", request.param)
     yield lib
     lib.test_tune("gemm8", old)
+    lib.test_tune("g8stag", olds)
 
 
 @pytest.mark.parametrize("ak,bk", LAYOUTS)
