@@ -32,7 +32,8 @@ typedef mt_bf16x8 wbf8;
 typedef mt_f32x16 wf16;
 constexpr int WP = 80;                          // LDS pitch of a [tokens][32] bf16 image: 64 B of data + 16 (conflict-free ds_read_b128 rows)
 constexpr int WMAXN = 160;                      // tokens of a window, padded to whole 32-row tiles (ws <= 12: n <= 144)
-constexpr int WIMG = WMAXN * WP;
+// The kernels are instantiated for windows of <= 64 tokens (HTS-AT's 8 x 8 windows, the 6 x 6 one-window maps: 3 x 64 x 80 B = 15 KB of
+// LDS forward, 21 KB backward -> 8+ workgroups per CU) and <= 160 (Swin-V2's 12 x 12: 39 / 53 KB)
 
 struct WArgs {
   const unsigned short* qkv;                    // [B][L][3][heads][hd] bf16 (the qkv projection of the un-partitioned map)
@@ -105,12 +106,13 @@ __device__ __forceinline__ void store_rows_T(const wf16& o, float mul, unsigned 
   }
 }
 
-constexpr int WMAXT = WMAXN / 32;               // 5 tiles
 
 // ---- forward --------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wattn_fwd_k(const WArgs p) {
+template <int NPAD>
+__global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_fwd_k(const WArgs p) {
+  constexpr int WIMG = NPAD * WP, WMAXT = NPAD / 32;
   __shared__ __attribute__((aligned(16))) char smem[3 * WIMG];
-  __shared__ int rows[WMAXN];
+  __shared__ int rows[NPAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
   const int head = blockIdx.x % p.heads, w = (blockIdx.x / p.heads) % p.nW, b = blockIdx.x / (p.heads * p.nW);
   const int wy = w / p.nwx, wx = w - wy * p.nwx;
@@ -172,10 +174,12 @@ __global__ __launch_bounds__(256) void wattn_fwd_k(const WArgs p) {
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wattn_bwd_k(const WArgs p) {
+template <int NPAD>
+__global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_bwd_k(const WArgs p) {
+  constexpr int WIMG = NPAD * WP, WMAXT = NPAD / 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * WIMG];
-  __shared__ int rows[WMAXN];
-  __shared__ float sL[WMAXN], sD[WMAXN];
+  __shared__ int rows[NPAD];
+  __shared__ float sL[NPAD], sD[NPAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
   const int head = blockIdx.x % p.heads, w = (blockIdx.x / p.heads) % p.nW, b = blockIdx.x / (p.heads * p.nW);
   const int wy = w / p.nwx, wx = w - wy * p.nwx;
@@ -295,7 +299,9 @@ int window_attn_forward(void* stream, int B, int H, int W, int ws, int shift, in
   WArgs a = wattn_args(B, H, W, ws, shift, heads, hd, nwm);
   a.qkv = (const unsigned short*)qkv; a.bm = bm; a.scale = scale; a.out = (unsigned short*)out; a.lse = lse;
   const int nt = (a.n + 31) / 32, nw = nt < 4 ? nt : 4;
-  hipLaunchKernelGGL(wattn_fwd_k, dim3((unsigned)((long)B * a.nW * heads)), dim3(64 * nw), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((long)B * a.nW * heads));
+  if (a.n <= 64) hipLaunchKernelGGL(wattn_fwd_k<64>, grid, dim3(64 * nw), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(wattn_fwd_k<WMAXN>, grid, dim3(64 * nw), 0, (hipStream_t)stream, a);
   return 0;
 }
 int window_attn_backward(void* stream, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
@@ -305,7 +311,9 @@ int window_attn_backward(void* stream, int B, int H, int W, int ws, int shift, i
   a.qkv = (const unsigned short*)qkv; a.bm = bm; a.scale = scale; a.o_in = (const unsigned short*)out; a.lse = const_cast<float*>(lse);
   a.dout = (const unsigned short*)dout; a.dqkv = (unsigned short*)dqkv;
   const int nt = (a.n + 31) / 32, nw = nt < 4 ? nt : 4;
-  hipLaunchKernelGGL(wattn_bwd_k, dim3((unsigned)((long)B * a.nW * heads)), dim3(64 * nw), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((long)B * a.nW * heads));
+  if (a.n <= 64) hipLaunchKernelGGL(wattn_bwd_k<64>, grid, dim3(64 * nw), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(wattn_bwd_k<WMAXN>, grid, dim3(64 * nw), 0, (hipStream_t)stream, a);
   return 0;
 }
 
