@@ -303,8 +303,7 @@ void gemm8_kernel(const G8 p) {
     // With `stag` the upper half of the waves issues its share a quarter of a k-tile LATER (tile it + 1 into the buffer the barrier at
     // the end of iteration it - 1 freed, behind the first MFMA group of iteration it; still covered by the vmcnt(0) in front of this
     // iteration's barrier), so one wave of every SIMD multiplies while the other one issues.
-    const bool late = p.stag && wave >= G8_NW / 2;
-    const bool late1 = late && p.stag == 1, late2 = late && p.stag == 2;
+    const bool late = p.stag && wave >= G8_NW / 2;           // (half a k-tile later instead: measured, less -- the late half then waits for its own data)
     if (nk > 0) {
       issue(kt_begin, 0);
       if (nk > 1) { issue(kt_begin + 1, 1); g8_wait_vm<NDMA>(); } else g8_wait_vm<0>();
@@ -318,13 +317,12 @@ void gemm8_kernel(const G8 p) {
         mmap(0);
         __builtin_amdgcn_sched_barrier(0);
         landedp(1);
-        if (late1 && it >= 1 && it + 1 < nk) issue(kt_begin + it + 1, (it + 1) & 1);
+        if (late && it >= 1 && it + 1 < nk) issue(kt_begin + it + 1, (it + 1) & 1);
         rdp(std::integral_constant<int, 2>{}, boff);
         __builtin_amdgcn_sched_barrier(0);
         mmap(1);
         __builtin_amdgcn_sched_barrier(0);
         landedp(0);
-        if (late2 && it >= 1 && it + 1 < nk) issue(kt_begin + it + 1, (it + 1) & 1);
         rdp(std::integral_constant<int, 3>{}, boff);
         __builtin_amdgcn_sched_barrier(0);
         mmap(0);
@@ -530,8 +528,8 @@ static void g8_launch_p(const G8& k, int ak, int bk, bool batched, bool two, dim
 }
 // "g8pipe" (dgsct_test_tune / DGSCT_G8PIPE): 1 = the cross-tile pipelined k-loop (default), 0 = the round-3 loop (two barriers per k-tile)
 static std::atomic<int> g_g8pipe{getenv("DGSCT_G8PIPE") ? atoi(getenv("DGSCT_G8PIPE")) : 1};
-static std::atomic<int> g_g8stag{getenv("DGSCT_G8STAG") ? atoi(getenv("DGSCT_G8STAG")) : 1};      // 1: after the first MFMA group (default), 2: after the second, 0: lock-step
-int gemm8_stag_mode(int set) { const int old = g_g8stag.load(); if (set >= 0) g_g8stag.store(set); return old; }
+static std::atomic<int> g_g8stag{getenv("DGSCT_G8STAG") ? atoi(getenv("DGSCT_G8STAG")) : 1};      // 1: the upper wave half issues behind the first MFMA group of the next iteration (default), 0: lock-step
+int gemm8_stag_mode(int set) { const int old = g_g8stag.load(); if (set >= 0) g_g8stag.store(set ? 1 : 0); return old; }
 int gemm8_pipe_mode(int set) { const int old = g_g8pipe.load(); if (set >= 0) g_g8pipe.store(set ? 1 : 0); return old; }
 template <int BN>
 static void g8_launch(const G8& k, int ak, int bk, bool batched, bool two, dim3 grid, hipStream_t s) {
