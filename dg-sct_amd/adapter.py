@@ -77,19 +77,21 @@ class VisualAdapter(nn.Module):
         self.flavour = flavour
         self.compute_dtype = compute_dtype
         self._lib = lib
-        # AVS/AVQA copies have no num_tk argument and read opt.num_tokens (PVT_AVSModel.py:130, net_avst.py:60)
-        self.num_tk = int(num_tk if num_tk is not None else opt.num_tokens)
+        # AVE / AVVP / pretrain copies: `num_tk=87` is the constructor default (net_trans.py:437, mgn.py:166; every call site passes
+        # opt.num_tokens); AVS / AVQA copies have no such argument and read opt.num_tokens (PVT_AVSModel.py:130, net_avst.py:60)
+        if num_tk is None:
+            num_tk = 87 if flavour in ("ave", "avvp", "pretrain") else opt.num_tokens
+        self.num_tk = int(num_tk)
         if not (adapter_kind == "bottleneck" and self.is_multimodal):
             # "bottleneck" without is_multimodal and "basic" are never built by any reference launcher
             # (SURVEY 8a-1); anything else raises exactly like the reference (:549-550).
             raise NotImplementedError(f"adapter_kind={adapter_kind!r} with is_multimodal={self.is_multimodal} is not on the "
                                       f"DG-SCT hot path")
-        if not 1 <= self.num_tk <= 32:
-            # the latent tokens of a frame are ONE 32-row MFMA tile in the fused attention kernels (csrc/attn*.hip).  Every
-            # reference launcher passes --num_tokens <= 32 (AVE/AVVP train.sh: 32, AVS: 32, AVQA: 2); the constructor default
-            # of the reference (87) is never used by a script.  Fail here, with the reason, not inside dgsct_query.
-            raise ValueError(f"dg-sct_amd: num_tokens={self.num_tk} is outside the supported range 1..32 (latent tokens of a frame "
-                             f"are held in one 32-row MFMA tile); see INTEGRATION.md 'Limits'")
+        if not 1 <= self.num_tk <= 1024:
+            # num_tokens <= 32 (every reference launcher: AVE/AVVP train.sh 32, AVS 32, AVQA 2) runs on the fused attention kernels
+            # (csrc/attn*.hip: one 32-row MFMA tile of latent tokens per frame); more -- the reference constructor's default is 87 --
+            # on batched products + row softmax (csrc/attn_wide.cpp).  Fail here, with the reason, not inside dgsct_query.
+            raise ValueError(f"dg-sct_amd: num_tokens={self.num_tk} is outside the supported range 1..1024; see INTEGRATION.md 'Limits'")
         if input_dim != output_dim or linear_out != input_dim:
             raise ValueError("DG-SCT adapters have input_dim == output_dim == linear_out")
         C, d_model = linear_out, linear_out // 2

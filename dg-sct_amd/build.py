@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdgsct.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["gemm.hip", "gemm_fx.hip", "gemm8.hip", "gemm_skinny.hip", "gemm_tall.hip", "gemm_wgbt.hip", "gemm_fp8.hip", "attn.hip", "attn2.hip", "temporal.hip", "wattn.hip", "prims_hip.hip", "prims_strip.hip", "prims_proj.hip", "fused_gate.hip", "plan.cpp", "capi.cpp", "err.cpp"]
+SOURCES = ["gemm.hip", "gemm_fx.hip", "gemm8.hip", "gemm_skinny.hip", "gemm_tall.hip", "gemm_wgbt.hip", "gemm_fp8.hip", "attn.hip", "attn2.hip", "temporal.hip", "wattn.hip", "prims_hip.hip", "prims_strip.hip", "prims_proj.hip", "fused_gate.hip", "plan.cpp", "attn_wide.cpp", "capi.cpp", "err.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 

@@ -50,6 +50,9 @@ Plan::Plan(const dgsct_adapter_desc& d_, bool record_regions) : record_regions_(
     orderA = a <= b;
   }
   ok = validate();
+  // more than one 32-row MFMA tile of latent tokens per frame: attn_wide.cpp instead of the fused kernels.  DGSCT_WIDE_ATTN=1 (read per
+  // layout: tests set it around a call) sends every tk down that path, so that the goldens of the fused kernels check it too.
+  { const char* e = getenv("DGSCT_WIDE_ATTN"); wide = tk > 32 || (e && atoi(e) != 0); }
   if (ok) xc_scratch = !fp8 && gate_bwd_fused_shape(E, N, C, ds, g);
   if (ok) layout();
 }
@@ -60,7 +63,7 @@ bool Plan::validate() {
   if (d.r <= 0 || g <= 0 || C % d.r || ds % g || C % g) return bad("C must be divisible by r and g, C/r by g");
   if (C % 4 || C > 1536) return bad("C must be a multiple of 4 and <= 1536");
   if (dd % 4) return bad("C/2 must be a multiple of 4");
-  if (tk > 32) return bad("tk must be <= 32 (the latent tokens of one frame are one 32-row MFMA tile)");
+  if (tk > 1024) return bad("tk must be <= 1024");
   if (d.dtype != DGSCT_F32 && d.dtype != DGSCT_BF16 && d.dtype != DGSCT_BF16_FP8) return bad("dtype");
   if (fp8 && (C % 16 || Co % 16)) return bad("fp8 projections need C and Co to be multiples of 16");
   if (E == DT_BF16 && C % 8) return bad("C must be a multiple of 8 in bf16 mode (16-byte rows)");
@@ -133,7 +136,9 @@ void Plan::layout() {
       prep_w8[2] = a.take("wv28", (int64_t)dd * C);
       prep_w8scale = a.take("w8scale", 4 * 4);
     }
-    prep_t0pk = E == DT_BF16 ? a.take("t0pk", tok_pack_elems(1, C) * 2) : -1;      // my_tokens packed for attn2.hip
+    prep_t0pk = (E == DT_BF16 && !wide) ? a.take("t0pk", tok_pack_elems(1, C) * 2) : -1;      // my_tokens packed for attn2.hip
+    prep_t0hi = (E == DT_BF16 && wide) ? a.take("t0hi", (int64_t)tk * C * 2) : -1;            // ... as a hi / lo pair for attn_wide.cpp
+    prep_t0lo = (E == DT_BF16 && wide) ? a.take("t0lo", (int64_t)tk * C * 2) : -1;
     prep_bytes = a.off;
   }
   // ---- saved
@@ -150,7 +155,7 @@ void Plan::layout() {
     s.Yp = a.take("Yp", R * C * es);
     s.T = a.take("T", orderA ? R * Co * es : (int64_t)B * C * Nop * es);
     s.tok = a.take("tok", (int64_t)B * tk * C * 4);          // fp32: the un-scaled logits X . tok^T amplify its rounding
-    s.tokpk = E == DT_BF16 ? a.take("tokpk", tok_pack_elems(B, C) * 2) : -1;   // bf16 hi / lo / transposed fragment images
+    s.tokpk = (E == DT_BF16 && !wide) ? a.take("tokpk", tok_pack_elems(B, C) * 2) : -1;   // bf16 hi / lo / transposed fragment images
     s.lse = a.take("lse", (int64_t)B * tk * 4);
     s.aE = a.take("aE", (int64_t)B * C * es);
     s.X1 = a.take("X1", R * C * es);
@@ -176,6 +181,9 @@ void Plan::layout() {
     s.bn2 = a.take("bn2", (int64_t)4 * C * 4);
     s.mu_p = a.take("mu_p", R * 4);
     s.rstd_p = a.take("rstd_p", R * 4);
+    s.P1 = wide ? a.take("P1", (int64_t)B * tk * Np * es) : -1;               // softmax_N(T0 Yp^T), softmax_tk(X tok^T): saved, not recomputed
+    s.P2 = wide ? a.take("P2", (int64_t)B * N * tkp * es) : -1;
+    s.tokhi = (wide && E == DT_BF16) ? a.take("tokhi", (int64_t)B * tk * C * es) : -1;
     saved_bytes = a.off;
   }
   // ---- forward scratch
@@ -183,6 +191,8 @@ void Plan::layout() {
     Arena a;
     wf.tokscr = a.take("tokscr", tokattn_scratch_floats(B, N, C) * 4);
     wf.Xc = xc_scratch ? a.take("Xc", R * C * es) : -1;       // (only the unfused test path of these shapes writes it)
+    wf.wL = wide ? a.take("wL", wide_attn_image_elems(B, N, tk) * 4) : -1;
+    wf.toklo = (wide && E == DT_BF16) ? a.take("toklo", (int64_t)B * tk * C * es) : -1;
     ws_fwd_bytes = a.off;
   }
   // ---- backward scratch
@@ -221,7 +231,11 @@ void Plan::layout() {
     wb.da = a.take("da", (int64_t)B * C * 4);
     wb.dpre_t = a.take("dpre_t", (int64_t)B * 4);
     wb.Dtok = a.take("Dtok", (int64_t)B * tk * 4);
-    wb.dtokpk = E == DT_BF16 ? a.take("dtokpk", tok_pack_elems(B, C) * 2) : -1;
+    wb.dtokpk = (E == DT_BF16 && !wide) ? a.take("dtokpk", tok_pack_elems(B, C) * 2) : -1;
+    wb.wdP = wide ? a.take("wdP", wide_attn_image_elems(B, N, tk) * 4) : -1;
+    wb.wdS = wide ? a.take("wdS", wide_attn_image_elems(B, N, tk) * es) : -1;
+    wb.dtokE = (wide && E == DT_BF16) ? a.take("dtokE", (int64_t)B * tk * C * es) : -1;
+    wb.daN = wide ? a.take("daN", (int64_t)B * C * 4) : -1;
     wb.dYp = a.take("dYp", R * C * es);
     wb.dT = a.take("dT", orderA ? R * Co * es : (int64_t)B * No * C * es);
     wb.rowtmp = a.take("rowtmp", R * 4);
@@ -348,6 +362,7 @@ int Plan::prepare(float* const* params, void* prep, void* stream) const {
     zero(ctx, colb2, (size_t)C * 4);
   }
   if (prep_t0pk >= 0) tok_pack(ctx, params[DGSCT_P_TOKENS], 1, tk, C, p + prep_t0pk);
+  if (prep_t0hi >= 0) split_hilo(ctx, params[DGSCT_P_TOKENS], (long)tk * C, p + prep_t0hi, p + prep_t0lo);
   if (fp8) {
     float* sc = (float*)(p + prep_w8scale);
     fp8_quantize(ctx, params[DGSCT_P_WC], (long)C * Co, p + prep_w8[0], sc + 0, sc + 3);
@@ -406,6 +421,11 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
   }
   // F2 ---- latent tokens attend to the remapped tokens (one pass over Yp)   :572-580, :592
   void* tokpk = s.tokpk >= 0 ? b.S(s.tokpk) : nullptr;
+  if (wide)
+    tokattn_fwd_wide(ctx, Yp, b.F(DGSCT_P_TOKENS), prep_t0hi >= 0 ? (const void*)(b.prep + prep_t0hi) : (const void*)b.F(DGSCT_P_TOKENS),
+                     prep_t0lo >= 0 ? b.prep + prep_t0lo : nullptr, B, N, C, tk, invN, b.S<float>(s.tok), b.S<float>(s.a), b.S(s.aE),
+                     b.Wk<float>(wf.wL), b.S(s.P1));
+  else
   if (!(SK & (128 | 16384))) tokattn_fwd(ctx, Yp, b.F(DGSCT_P_TOKENS), B, N, C, tk, b.S<float>(s.tok), b.S<float>(s.lse), b.S<float>(s.a), b.S(s.aE),
               b.Wk<float>(wf.tokscr), tokpk, prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr);
   {
@@ -420,6 +440,10 @@ int Plan::forward(float* const* params, const void* prep, const void* X, const v
     gemm(side, g2);
   }
   // F3 ---- X attends to the latent tokens (one pass over X)             :583-589
+  if (wide)
+    xattn_fwd_wide(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1), s.tokhi >= 0 ? b.S(s.tokhi) : nullptr,
+                   wf.toklo >= 0 ? b.Wk(wf.toklo) : nullptr, b.Wk<float>(wf.wL), b.S(s.P2));
+  else
   if (!(SK & (128 | 32768))) xattn_fwd(ctx, X, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, b.S(s.X1), tokpk);
   // F4-F6 ---- channel gate                                              :593-598
   {
@@ -982,6 +1006,10 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   }
   // B3 ---- X <- tokens attention: dX (output), dtok, d gate_av in one pass over X and dX1 (P2 recomputed)
   {
+    if (wide)
+      xattn_bwd_wide(ctx, X, dX1, s.tokhi >= 0 ? (const void*)b.S(s.tokhi) : (const void*)b.S(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX,
+                     skip_into_dx ? dOut : nullptr, b.Wk<float>(wb.dtokF), G(DGSCT_P_GATE_AV), b.S(s.P2), b.Wk<float>(wb.wdP), b.Wk(wb.wdS));
+    else
     if (!(SK & (128 | 65536))) xattn_bwd(ctx, X, dX1, b.S<float>(s.tok), b.F(DGSCT_P_GATE_AV), B, N, C, tk, dX, skip_into_dx ? dOut : nullptr,
               b.Wk<float>(wb.dtokF), G(DGSCT_P_GATE_AV),      // fused skip (f2): out = X + adapter(X, Y) => dX += dOut
               s.tokpk >= 0 ? b.S(s.tokpk) : nullptr);
@@ -1004,6 +1032,11 @@ int Plan::backward(float* const* params, const void* prep, const void* X, const 
   // B2 ---- tokens <- remapped tokens attention: dYp and d my_tokens in one pass over Yp (P1 recomputed from lse)
   void* dYp = b.Wk(wb.dYp);
   {
+    if (wide)
+      tokattn_bwd_wide(ctx, b.S(s.Yp), prep_t0hi >= 0 ? (const void*)(b.prep + prep_t0hi) : (const void*)b.F(DGSCT_P_TOKENS), b.Wk<float>(wb.dtokF),
+                       b.Wk<float>(wb.da), invN, B, N, C, tk, dYp, b.Wk<float>(wb.dT0b), b.S(s.P1), b.Wk<float>(wb.wdP), b.Wk(wb.wdS),
+                       wb.dtokE >= 0 ? b.Wk(wb.dtokE) : nullptr, b.Wk<float>(wb.daN));
+    else
     if (!(SK & (128 | 131072))) tokattn_bwd(ctx, b.S(s.Yp), b.F(DGSCT_P_TOKENS), b.S<float>(s.tok), b.S<float>(s.lse), b.Wk<float>(wb.dtokF),
                 b.Wk<float>(wb.da), invN, B, N, C, tk, dYp, b.Wk<float>(wb.dT0b), b.Wk<float>(wb.Dtok),
                 prep_t0pk >= 0 ? b.prep + prep_t0pk : nullptr, wb.dtokpk >= 0 ? b.Wk(wb.dtokpk) : nullptr);

@@ -30,23 +30,24 @@ struct Plan {
   bool fp8 = false;   // DGSCT_BF16_FP8: fp8 operands for fc / fc_affine_video_1 / fc_affine_video_2 (forward)
   int64_t prep_w8[3] = {-1, -1, -1}, prep_w8scale = -1;   // fp8 copies of Wc, Wv1, Wv2 + their 3 inverse scales (+ 1 scratch word)
   bool xc_scratch = false;   // Xc = X1 (1 + ch) is scratch (the fused gate backward writes it), not a saved activation
+  bool wide = false;   // num_tokens > 32: the latent-token attentions run as batched products + row softmax (attn_wide.cpp)
   bool orderA;   // remap association: (Wn.Y).Wc^T (A) or Wn.(Y.Wc^T) (B), whichever is cheaper
 
   // prep
-  int64_t prep_w[DGSCT_P_COUNT], prep_wt[DGSCT_P_COUNT], wcols[DGSCT_P_COUNT], wnumel[DGSCT_P_COUNT], prep_rowb, prep_colb, prep_colb2, prep_t0pk, prep_bytes;
+  int64_t prep_w[DGSCT_P_COUNT], prep_wt[DGSCT_P_COUNT], wcols[DGSCT_P_COUNT], wnumel[DGSCT_P_COUNT], prep_rowb, prep_colb, prep_colb2, prep_t0pk, prep_t0hi, prep_t0lo, prep_bytes;
   // saved
   struct {
     int64_t a, mvq1, cnt1, bnacc1, bnacc2, zero_end;
     int64_t Yp, T, tok, tokpk, lse, aE, X1, aq1, aq2, vq1, m1, q, ch, Xc, vq2, sl, sg, map, tg, X3, mu_b, rstd_b, Zp, Z, Op,
-        bn1, bn2, mu_p, rstd_p;
+        bn1, bn2, mu_p, rstd_p, P1, P2, tokhi;   // (P1 / P2 / tokhi: the wide path only)
   } s;
   std::vector<Region> saved_regions;
   int64_t saved_bytes;
   // forward / backward scratch
-  struct { int64_t tokscr, Xc; } wf;
+  struct { int64_t tokscr, Xc, wL, toklo; } wf;
   struct {
     int64_t bnsums2, bnsums1, dch, dtg, u, dwcsum, dtokF, dT0b, w2, zero_end;
-    int64_t dO, dZ, dX3, dX1, dXc, Xc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart, rowpart_v1, rowpart_v2, vq1part, dvq1, dvq2, dZp, t1, t3;
+    int64_t dO, dZ, dX3, dX1, dXc, Xc, dsg, dsl, tmpBd, dpre_c, dq, dm1, dpa1, dpa2, coef, da, dpre_t, Dtok, dtokpk, dYp, dT, rowtmp, rowpart, rowpart_v1, rowpart_v2, vq1part, dvq1, dvq2, dZp, t1, t3, wdP, wdS, dtokE, daN;
   } wb;
   int64_t ws_fwd_bytes, ws_bwd_bytes;
   // gradients

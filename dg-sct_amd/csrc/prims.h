@@ -347,6 +347,23 @@ void tokattn_bwd(const Ctx&, const void* Yp, const float* T0, const float* tok, 
                  const float* da, float invN, int B, int N, int C, int tk, void* dYp, float* dT0b, float* Dscratch,
                  const void* T0pk = nullptr, void* dtokpk = nullptr);
 
+// ---- num_tokens > 32 (attn_wide.cpp: plain C++ over gemm() and the row softmax kernels; the fused kernels above hold one 32-row token
+// tile per frame).  L / dP: fp32 scratch, dS: E scratch, each >= wide_attn_image_elems(B, N, tk) elements; P1 [B][tk][rup8(N)] and
+// P2 [B][N][rup8(tk)] (E) are SAVED by the forward.  bf16 mode: T0hi / T0lo = split_hilo(my_tokens) (from dgsct_prepare), tokhi / toklo
+// E [B][tk][C] written by xattn_fwd_wide (tokhi is saved), dtokE E [B][tk][C] of scratch; fp32 mode: T0hi = my_tokens, tokhi = tok and
+// T0lo = toklo = dtokE = null.  daN: B * C floats of scratch.  dtok / dT0b are WRITTEN (not accumulated).
+// hi = bf16(src), lo = bf16(src - hi)
+void split_hilo(const Ctx&, const float* src, long n, void* hi, void* lo);
+long wide_attn_image_elems(int B, int N, int tk);
+void tokattn_fwd_wide(const Ctx&, const void* Yp, const float* T0, const void* T0hi, const void* T0lo, int B, int N, int C, int tk,
+                      float invN, float* tok, float* a, void* aE, float* L, void* P1);
+void xattn_fwd_wide(const Ctx&, const void* X, const float* tok, const float* gate_av, int B, int N, int C, int tk, void* X1,
+                    void* tokhi, void* toklo, float* L, void* P2);
+void xattn_bwd_wide(const Ctx&, const void* X, const void* dX1, const void* tokhi, const float* gate_av, int B, int N, int C, int tk,
+                    void* dX, const void* R2, float* dtok, float* dgate, const void* P2, float* dP, void* dS);
+void tokattn_bwd_wide(const Ctx&, const void* Yp, const void* T0hi, const float* dtok, const float* da, float invN, int B, int N, int C,
+                      int tk, void* dYp, float* dT0b, const void* P1, float* dP, void* dS, void* dtokE, float* daN);
+
 // ---- TemporalAttention gate application (temporal.hip; reference net_trans.py:240-251), fp32 rows [R][D] ----------------
 void temporal_gate_fwd(const Ctx&, int R, int D, float gamma, const float* akv, const float* vkv, const float* vq, const float* aq,
                        const float* wa, const float* ba, const float* wv, const float* bv, float* out_v, float* out_a, float* gate,

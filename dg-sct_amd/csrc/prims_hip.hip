@@ -1361,6 +1361,21 @@ void cvt_multi(const Ctx& ctx, const CvtSeg* segs, int nseg) {
   hipLaunchKernelGGL(cvt_multi_k, dim3((int)blocks), dim3(256), 0, STREAM(ctx), t);
 }
 
+// hi = bf16(src), lo = bf16(src - hi): the fp32 latent tokens as the operand pair of the two-launch logit products (attn_wide.cpp)
+__global__ __launch_bounds__(256) void split_hilo_k(const float* __restrict__ src, long n, unsigned short* __restrict__ hi,
+                                                    unsigned short* __restrict__ lo) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = src[i];
+    const unsigned short h = f2bf(v);
+    hi[i] = h;
+    lo[i] = f2bf(v - __uint_as_float((unsigned)h << 16));
+  }
+}
+void split_hilo(const Ctx& ctx, const float* src, long n, void* hi, void* lo) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(split_hilo_k, dim3(flat_grid(n)), dim3(256), 0, STREAM(ctx), src, n, (unsigned short*)hi, (unsigned short*)lo);
+}
+
 struct ColsumTable { ColsumSeg seg[COLSUM_MAX_SEG]; int first_block[COLSUM_MAX_SEG + 1]; int nseg; };
 // thread -> one column (coalesced row reads), 4 row slices per workgroup combined in LDS
 __global__ __launch_bounds__(256) void colsum_multi_k(const ColsumTable t) {

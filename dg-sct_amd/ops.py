@@ -64,8 +64,9 @@ _SIZE_CACHE: Dict[Tuple, object] = {}
 
 
 def _sizes(lib: Lib, d: AdapterDesc):
-    """dgsct_query results are pure functions of the descriptor: ask once per (library, descriptor)."""
-    key = (id(lib), id(d))
+    """dgsct_query results are pure functions of the descriptor and of the two layout switches the library reads from the environment
+    at every call (test hooks: DGSCT_WIDE_ATTN, DGSCT_VQ1_DW): ask once per (library, descriptor, switches)."""
+    key = (id(lib), id(d), os.environ.get("DGSCT_WIDE_ATTN"), os.environ.get("DGSCT_VQ1_DW"))
     s = _SIZE_CACHE.get(key)
     if s is None:
         s = _SIZE_CACHE[key] = lib.query(d)

@@ -90,11 +90,23 @@ CONFIGS = {
 }
 
 
+# num_tokens > 32 at real stage-2 / stage-3 shapes (csrc/attn_wide.cpp; tests/test_adapter_gpu.py): (N, C, No, Co, tk)
+WIDE = {"wide_tk87_144x512": (144, 512, 256, 384, 87), "wide_tk40_64x768": (64, 768, 36, 1024, 40)}
+
+
 def main():
     emu = Lib(build_emu())
+    path = os.path.join(ROOT, "tests", "golden", "bf16_bounds.json")
     out = {"_doc": "relative-L2 bounds for the bf16 GPU tests; generated by oracle/make_bf16_bounds.py (K=%d perturbed ideal-bf16 "
                    "emulations, safety %.1f)" % (K, SAFETY)}
+    keep = lambda n: True
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":        # add / refresh the named cases, keep the rest of the file as it is
+        only = set(sys.argv[2].split(","))
+        out = json.load(open(path))
+        keep = lambda n: n in only
     for name in golden_names():
+        if not keep(name):
+            continue
         fx = load_golden(name)
         cfg = O.AdapterConfig(**fx["cfg"])
         state = {k: v.clone() for k, v in fx["state0"].items()}
@@ -103,6 +115,8 @@ def main():
         out[name] = bound_case(emu, cfg, state, fx["X"], fx["Y"], fx["dOut"], fx["dMap"], fx["dTmap"])
         print(name, {k: round(out[name][k], 4) for k in ("out", "map", "dX", "dY")}, flush=True)
     for name, (N, C, No, Co) in REAL.items():
+        if not keep(name):
+            continue
         cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2)
         p = O.random_params(cfg, "ave", seed=0, scale=0.577)
         gen = torch.Generator().manual_seed(1)
@@ -110,7 +124,19 @@ def main():
         dOut, dMap = torch.randn(10, N, C, generator=gen), torch.randn(10, N, generator=gen)
         out[name] = bound_case(emu, cfg, p, X, Y, dOut, dMap, None)
         print(name, {k: round(out[name][k], 4) for k in ("out", "map", "dX", "dY")}, flush=True)
+    for name, (N, C, No, Co, tk) in WIDE.items():
+        if not keep(name):
+            continue
+        cfg = O.AdapterConfig(N=N, C=C, No=No, Co=Co, tk=tk, r=8, g=2)
+        p = O.random_params(cfg, "ave", seed=0, scale=0.577)
+        gen = torch.Generator().manual_seed(1)
+        X, Y = torch.randn(10, N, C, generator=gen), torch.randn(10, No, Co, generator=gen)
+        dOut, dMap = torch.randn(10, N, C, generator=gen), torch.randn(10, N, generator=gen)
+        out[name] = bound_case(emu, cfg, p, X, Y, dOut, dMap, None)
+        print(name, {k: round(out[name][k], 4) for k in ("out", "map", "dX", "dY")}, flush=True)
     for name, (flavour, (N, C, No, Co), over) in CONFIGS.items():
+        if not keep(name):
+            continue
         cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour], **over})
         p = O.random_params(cfg, flavour, seed=0, scale=0.577)
         gen = torch.Generator().manual_seed(1)
@@ -118,7 +144,7 @@ def main():
         dOut, dMap = torch.randn(10, N, C, generator=gen), torch.randn(10, N, generator=gen)
         out[name] = bound_case(emu, cfg, p, X, Y, dOut, dMap, None)
         print(name, {k: round(out[name][k], 4) for k in ("out", "map", "dX", "dY")}, flush=True)
-    with open(os.path.join(ROOT, "tests", "golden", "bf16_bounds.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 
 

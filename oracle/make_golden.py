@@ -86,6 +86,10 @@ CASES = {
     "avqa": ("avqa", dict(N=16, C=32, No=36, Co=16, tk=2, r=8, g=4)),
     "avqa_audio_nogate": ("avqa", dict(N=36, C=16, No=16, Co=32, tk=2, r=4, g=4, use_gate=False)),
     "pretrain": ("pretrain", dict(N=16, C=32, No=36, Co=16, tk=4, r=8, g=2)),
+    # num_tokens > 32 (more than one 32-row MFMA tile of latent tokens per frame: csrc/attn_wide.cpp); 87 is the reference
+    # constructor's default (net_trans.py:437).  Appended: the seeds of the cases above (100 + index) do not move.
+    "ave_tk40": ("ave", dict(N=36, C=32, No=16, Co=48, tk=40, r=8, g=2)),
+    "ave_tk87": ("ave", dict(N=49, C=64, No=25, Co=32, tk=87, r=8, g=2)),
 }
 BATCH = 10   # BT = 1 clip x T=10 (2 clips x T=5 for AVS)
 

@@ -11,7 +11,7 @@ OUT = os.path.join(HERE, "libdgsct_emu.so")
 
 
 def build_emu() -> str:
-    srcs = [os.path.join(CSRC, f) for f in ("plan.cpp", "capi.cpp", "err.cpp")] + [os.path.join(HERE, "prims_host.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("plan.cpp", "attn_wide.cpp", "capi.cpp", "err.cpp")] + [os.path.join(HERE, "prims_host.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "dgsct.h")]
     if os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT

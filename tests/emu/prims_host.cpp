@@ -833,6 +833,13 @@ void cvt_multi(const Ctx&, const CvtSeg* segs, int nseg) {
     }
 }
 
+void split_hilo(const Ctx&, const float* src, long n, void* hi, void* lo) {
+  for (long i = 0; i < n; ++i) {
+    st(hi, DT_BF16, i, src[i]);
+    st(lo, DT_BF16, i, src[i] - ld(hi, DT_BF16, i));
+  }
+}
+
 void rowsum_f32(const Ctx&, const float* W, int R, int C, float* out) {
   for (int r = 0; r < R; ++r) { double s = 0; for (int c = 0; c < C; ++c) s += W[(long)r * C + c]; out[r] = (float)s; }
 }

@@ -94,8 +94,8 @@ def test_golden_bf16(name):
     check_bounds(name, r, out_o, map_o, dX_o, dY_o, g_o)
 
 
-def _real_case(N, C, No, Co, BT, dtype, seed=0, flavour="ave"):
-    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour]})
+def _real_case(N, C, No, Co, BT, dtype, seed=0, flavour="ave", tk=None):
+    cfg = O.AdapterConfig(**{**dict(N=N, C=C, No=No, Co=Co, tk=32, r=8, g=2), **O.FLAVOURS[flavour], **(dict(tk=tk) if tk else {})})
     # weights at the reference's default-init scale: nn.Linear/Conv2d init is U(-1/sqrt(fan_in), 1/sqrt(fan_in)),
     # i.e. std = 0.577/sqrt(fan_in) (random_params draws N(0, scale^2/fan_in)); my_tokens ~ U[0,1) as in the reference
     p = O.random_params(cfg, flavour, seed=seed, scale=0.577)
@@ -156,6 +156,63 @@ def test_real_shapes_bf16(shape):
     got = dict(out=r["out"][0], map=r["map"][0], dX=r["dX"][0], dY=r["dY"][0], grads={k: v[0] for k, v in r["grads"].items()})
     check_bounds(f"real_{shape[0]}x{shape[1]}", got, r["out"][1], r["map"][1], r["dX"][1], r["dY"][1],
                  {k: v[1] for k, v in r["grads"].items()})
+
+
+# ---- num_tokens > 32: more than one 32-row MFMA tile of latent tokens per frame (csrc/attn_wide.cpp: batched products on the tiled
+# engine + row softmax instead of the fused attention kernels).  87 is the reference constructor's default (net_trans.py:437).
+WIDE = [(144, 512, 256, 384, 87), (64, 768, 36, 1024, 40)]       # (N, C, No, Co, tk): bounds exist for these (oracle/make_bf16_bounds.py)
+
+
+@pytest.mark.parametrize("shape", WIDE + [(576, 256, 1024, 192, 87), (1024, 192, 576, 256, 33)])
+def test_wide_token_path_real_shapes_fp32(shape):
+    N, C, No, Co, tk = shape
+    r = _real_case(N, C, No, Co, BT=10, dtype=torch.float32, tk=tk)
+    for k in ("out", "map", "dX", "dY"):
+        assert fp32_err(*r[k]) < TOL_F32, (k, fp32_err(*r[k]))
+    assert not r["extra"], r["extra"]
+    bad = [(k, fp32_err(g, go)) for k, (g, go) in r["grads"].items() if not grad_close_fp32(g, go, TOL_F32, name=k)]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("shape", WIDE)
+def test_wide_token_path_real_shapes_bf16(shape):
+    """as test_real_shapes_bf16: outputs at BASELINE.json's 1e-2, every tensor inside the emulator-derived bound of the case"""
+    N, C, No, Co, tk = shape
+    r = _real_case(N, C, No, Co, BT=10, dtype=torch.bfloat16, seed=0, tk=tk)
+    for k in ("out", "map"):
+        assert _l2(*r[k]) < TOL_BF16, (k, _l2(*r[k]))
+        assert nrm_err(*r[k]) < 2 * TOL_BF16, (k, nrm_err(*r[k]))
+    got = dict(out=r["out"][0], map=r["map"][0], dX=r["dX"][0], dY=r["dY"][0], grads={k: v[0] for k, v in r["grads"].items()})
+    check_bounds(f"wide_tk{tk}_{N}x{C}", got, r["out"][1], r["map"][1], r["dX"][1], r["dY"][1], {k: v[1] for k, v in r["grads"].items()})
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fp32_on_the_wide_token_path(name, monkeypatch):
+    """DGSCT_WIDE_ATTN=1 (read by the library at every layout) sends num_tokens <= 32 down the wide path too: the reference goldens
+    of every flavour then check it, tk = 2 and tk = 4 included"""
+    monkeypatch.setenv("DGSCT_WIDE_ATTN", "1")
+    fx = load_golden(name)
+    r = run_library(default_lib(), fx, DEV, torch.float32, training=True)
+    torch.cuda.synchronize()
+    bad = [(k, fp32_err(r[k], fx[k])) for k in ("out", "map", "dX", "dY") if not fp32_err(r[k], fx[k]) < TOL_F32]
+    for k, g in fx["grads"].items():
+        if not grad_close_fp32(r["grads"][k], g, TOL_F32, name=k):
+            bad.append((k, fp32_err(r["grads"][k], g)))
+    assert not (set(r["grads"]) - set(fx["grads"]))
+    assert not bad, bad
+
+
+def test_wide_token_path_matches_the_fused_kernels_bf16(monkeypatch):
+    """the same bf16 call on both paths (tk = 32, a real stage-2 shape): they differ by rounding order only -- outputs to 1e-2 of each
+    other, input gradients to the distance either keeps from the oracle"""
+    a = _real_case(144, 512, 256, 384, BT=10, dtype=torch.bfloat16, seed=3)
+    monkeypatch.setenv("DGSCT_WIDE_ATTN", "1")
+    b = _real_case(144, 512, 256, 384, BT=10, dtype=torch.bfloat16, seed=3)
+    for k in ("out", "map"):
+        assert _l2(a[k][0], b[k][0]) < TOL_BF16, (k, _l2(a[k][0], b[k][0]))
+    for k in ("dX", "dY"):
+        ea, eb = _l2(*a[k]), _l2(*b[k])
+        assert eb < 1.5 * ea + 1e-2, (k, ea, eb)
 
 
 @pytest.mark.parametrize("flavour", ["avvp", "avs_s4", "avs_ms3", "avqa", "pretrain"])
@@ -582,19 +639,23 @@ def test_pair_backward_equals_the_two_node_path(dtype):
     assert not bad, bad
 
 
-def test_module_dropin_matches_oracle():
+@pytest.mark.parametrize("num_tk", [8, None])
+def test_module_dropin_matches_oracle(num_tk):
     """nn.Module boundary on the GPU: reference call convention ([BT,C,N,1] views), state_dict names, autograd -- against the
-    oracle (forward values, input gradients, every parameter gradient, BN buffers)."""
+    oracle (forward values, input gradients, every parameter gradient, BN buffers).  num_tk omitted: the reference constructor's
+    default of 87 latent tokens (net_trans.py:437), i.e. the num_tokens > 32 path."""
     from types import SimpleNamespace
     from dgsct_amd import VisualAdapter
     opt = SimpleNamespace(is_multimodal=1, num_conv_group=2, is_before_layernorm=1, is_post_layernorm=1, num_tokens=8)
     torch.manual_seed(0)
-    m = VisualAdapter(64, 64, "bottleneck", reduction_factor=8, opt=opt, use_bn=True, use_gate=True, num_tk=8,
-                      conv_dim_in=49, conv_dim_out=25, linear_in=48, linear_out=64).to(DEV)
+    kw = dict(num_tk=num_tk) if num_tk else {}
+    m = VisualAdapter(64, 64, "bottleneck", reduction_factor=8, opt=opt, use_bn=True, use_gate=True,
+                      conv_dim_in=49, conv_dim_out=25, linear_in=48, linear_out=64, **kw).to(DEV)
+    assert m.my_tokens.shape == (num_tk or 87, 64)
     with torch.no_grad():
         m.gate.fill_(0.7); m.gate_av.fill_(0.3)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    cfg = O.AdapterConfig(N=25, C=64, No=49, Co=48, tk=8, r=8, g=2)
+    cfg = O.AdapterConfig(N=25, C=64, No=49, Co=48, tk=num_tk or 87, r=8, g=2)
     BT = 10
     f = torch.randn(BT, 25, 64, device=DEV, requires_grad=True)
     fo = torch.randn(BT, 49, 48, device=DEV, requires_grad=True)

@@ -60,6 +60,20 @@ def test_schedule_without_the_gate_fusion_fp32(emu, name):
         assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_schedule_on_the_wide_token_path_fp32(emu, name, monkeypatch):
+    """num_tokens > 32 runs the two latent-token attentions as batched products + row softmax (csrc/attn_wide.cpp; the goldens
+    ave_tk40 / ave_tk87 take that path by themselves).  DGSCT_WIDE_ATTN=1 sends every tk down it: all reference goldens check it."""
+    monkeypatch.setenv("DGSCT_WIDE_ATTN", "1")
+    fx = load_golden(name)
+    r = run_library(emu, fx, torch.device("cpu"), torch.float32, training=True)
+    tol = 1e-4
+    for k in ("out", "map", "dX", "dY"):
+        assert rel_err(r[k], fx[k]) < tol, k
+    for k, g in fx["grads"].items():
+        assert rel_err(r["grads"][k].reshape(g.shape), g) < tol, k
+
+
 @pytest.mark.parametrize("mask", [0, 31, 4 + 32, 1 + 2, 8 + 16])
 @pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "pretrain", "avs_s4", "avqa"])
 def test_schedule_with_the_fused_gemm_hooks_fp32(emu, name, mask):
@@ -140,16 +154,18 @@ def test_schedule_eval_mode(emu, name):
     assert rel_err(r["map"], fx["eval_map"]) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "pretrain"])
+@pytest.mark.parametrize("name", ["ave_orderA", "ave_orderB", "pretrain", "ave_tk40"])
 def test_schedule_bf16_storage(emu, name):
-    """bf16 storage through the same schedule (host emulation rounds to bf16 at every store)."""
+    """bf16 storage through the same schedule (host emulation rounds to bf16 at every store).  ave_tk40: the bf16 branches of the
+    num_tokens > 32 path (hi / lo token operands, the E copy of dtok; csrc/attn_wide.cpp)."""
     fx = load_golden(name)
     r = run_library(emu, fx, torch.device("cpu"), torch.bfloat16, training=True)
     # bf16 storage of every intermediate on a tiny, un-averaged problem.  The gradient error is one realisation of the
-    # rounding noise that the un-scaled token attention amplifies (DESIGN.md section 7): 0.8 % .. 6 % across the
+    # rounding noise that the un-scaled token attention amplifies (DESIGN.md section 7): 0.8 % .. 8 % across the
     # flavours, and it moves inside that band whenever any intermediate is rounded differently.
+    wide = fx["cfg"]["tk"] > 32
     assert nrm_err(r["out"], fx["out"]) < 3e-2
-    assert nrm_err(r["dX"], fx["dX"]) < 8e-2
+    assert nrm_err(r["dX"], fx["dX"]) < (0.12 if wide else 8e-2)
     assert nrm_err(r["dY"], fx["dY"]) < 8e-2
 
 
