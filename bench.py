@@ -54,10 +54,11 @@ def alg_bytes_per_step(stages, BT, es=2):
     return tot
 
 
-def build_stack(backbone, dtype, device, concurrent=True, fp8=False):
+def build_stack(backbone, dtype, device, concurrent=True, fp8=False, num_tokens=32):
     torch.manual_seed(0)
     stages = ave_stage_shapes(backbone)
-    stack = AdapterStack(stages, compute_dtype=dtype, concurrent=concurrent, fp8_projections=fp8).to(device)
+    from dgsct_amd.stack import default_opt
+    stack = AdapterStack(stages, opt=default_opt(num_tokens=num_tokens), compute_dtype=dtype, concurrent=concurrent, fp8_projections=fp8).to(device)
     with torch.no_grad():              # BEFORE flattening: afterwards the per-name tensors are views, not parameters
         for n, p in stack.named_parameters():
             if n.endswith("gate") or n.endswith("gate_av"):
@@ -269,6 +270,8 @@ def main():
                     "(dgsct_amd/backbone.py, random-init, frozen, PyTorch-ROCm ops) inside the layer loop -- NOT the graded workload; the line "
                     "says so in config.workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--num-tokens", type=int, default=32, help="latent tokens per adapter (every reference launcher: <= 32 = the graded "
+                    "workload; more -- the reference constructor's default is 87 -- runs the attentions on csrc/attn_wide.cpp)")
     ap.add_argument("--no-optim", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no audio/visual adapter overlap)")
@@ -305,7 +308,7 @@ def main():
         per_gpu_batch = args.batch // world                 # clips of the fixed global batch that land on this rank
     BT = per_gpu_batch * T
 
-    stages, stack = build_stack(args.backbone, dtype, device, concurrent=not args.serial, fp8=fp8)
+    stages, stack = build_stack(args.backbone, dtype, device, concurrent=not args.serial, fp8=fp8, num_tokens=args.num_tokens)
     stack.train()
     params = [p for p in stack.parameters() if p.requires_grad]
     if dp:
@@ -515,7 +518,7 @@ def main():
             per_stage = dict(error=str(ex))
         if reducer is not None:
             reducer.paused = False
-        alg = 3.0 * alg_flops_per_frame(stages) * BT                 # fwd + bwd, per step
+        alg = 3.0 * alg_flops_per_frame(stages, tk=args.num_tokens) * BT                 # fwd + bwd, per step
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         # the GEMM family's own useful FLOPs (2 M N K per launch, summed by the library) over its own time: the latent-token
         # attention products (8 tk C N per frame of the algorithmic count) now run in the fused attention kernels, not here
@@ -632,7 +635,9 @@ def main():
             steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling=args.scaling,
             vs_baseline=None, dtype=("bf16_fp8" if fp8 else "bf16") if dtype == torch.bfloat16 else "f32", data="synthetic",
             config=dict(workload=f"AVE fine-tune adapter stack (BASELINE configs[1]): {args.backbone} + HTS-AT token/width "
-                                 f"shapes, 48 DG-SCT adapters, B={per_gpu_batch} clips/GPU x T=10, r=8 g=2 tk=32 BN+LN on" +
+                                 f"shapes, 48 DG-SCT adapters, B={per_gpu_batch} clips/GPU x T=10, r=8 g=2 tk={args.num_tokens} BN+LN on" +
+                                 (" (NOT the graded workload: num_tokens > 32 / DGSCT_WIDE_ATTN -- the unfused latent-token attentions of csrc/attn_wide.cpp)"
+                                  if args.num_tokens > 32 or os.environ.get("DGSCT_WIDE_ATTN", "0") not in ("", "0") else "") +
                                  (" + HARNESS B: the 12 frozen Swin-V2 blocks / HTS-AT blocks beside the adapter positions in the loop (not the graded workload)"
                                   if args.blocks else ""),
                         global_batch=per_gpu_batch * world, frames_per_clip=T, parallelism=f"dp{world}",

@@ -1008,6 +1008,32 @@ __global__ __launch_bounds__(256) void softmax_short_k(const float* in, long ld_
     for (int c = gl; c < ld_out; c += gs) ste_rt(out, odt, r * ld_out + c, c < L ? e / s : 0.f);
   }
 }
+// medium rows (64 < L <= 256; the latent-token axis of num_tokens > 32, attn_wide.cpp): one wavefront per row, four elements per lane
+__global__ __launch_bounds__(256) void softmax_wave_k(const float* in, long ld_in, void* out, int odt, long ld_out, long rows, int L,
+                                                      int pre_tanh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (long r = (long)blockIdx.x * 4 + w; r < rows; r += (long)gridDim.x * 4) {
+    float x[4], m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      x[i] = -INFINITY;
+      if (c < L) { x[i] = in[r * ld_in + c]; if (pre_tanh) x[i] = tanhf(x[i]); }
+      m = fmaxf(m, x[i]);
+    }
+    m = group_max(m, 64);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[i] = lane + 64 * i < L ? __expf(x[i] - m) : 0.f; s += x[i]; }
+    s = group_sum(s, 64);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < ld_out) ste_rt(out, odt, r * ld_out + c, x[i] * inv);
+    }
+  }
+}
 // long rows: one workgroup per row, three passes (logits are L2-resident: just written by the GEMM)
 __global__ __launch_bounds__(256) void softmax_long_k(const float* in, long ld_in, void* out, int odt, long ld_out, int L,
                                                       int pre_tanh) {
@@ -1117,6 +1143,10 @@ void softmax_rows(const Ctx& ctx, const float* in, long ld_in, void* out, int od
     const long nb = cdiv(rows, 256 / gs);
     hipLaunchKernelGGL(softmax_short_k, dim3((int)(nb > 8192 ? 8192 : nb)), dim3(256), 0, STREAM(ctx), in, ld_in, out, odt, ld_out,
                        rows, L, gs, pre_tanh);
+  } else if (L <= 256 && ld_out <= 256) {
+    const long nb = cdiv(rows, 4);
+    hipLaunchKernelGGL(softmax_wave_k, dim3((int)(nb > 16384 ? 16384 : nb)), dim3(256), 0, STREAM(ctx), in, ld_in, out, odt, ld_out,
+                       rows, L, pre_tanh);
   } else if (L % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_out <= 4096 && al16(in) && al16(out)) {
     const int nch = (int)cdiv(ld_out, 1024);
 #define SMV_(N_)                                                                                                        \
@@ -1150,6 +1180,36 @@ __global__ __launch_bounds__(256) void softmax_bwd_short_k(const void* P, int pd
     if (threadIdx.x == 0) unsafeAtomicAdd(dot_accum, t);
   }
 }
+// medium rows (64 < L <= 256): one wavefront per row; the dot accumulator gets ONE atomic per workgroup (a row each on one address --
+// 368 640 rows at stage 0 -- serialised for 12 ms)
+__global__ __launch_bounds__(256) void softmax_bwd_wave_k(const void* P, int pdt, long ldp, const float* dP, long lddp, void* out, int odt,
+                                                          long ldo, long rows, int L, const float* scale_ptr, float* dot_accum) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float sc = scale_ptr ? *scale_ptr : 1.f;
+  float dacc = 0.f;
+  for (long r = (long)blockIdx.x * 4 + w; r < rows; r += (long)gridDim.x * 4) {
+    float p[4], g[4], pd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      p[i] = 0.f; g[i] = 0.f;
+      if (c < L) { p[i] = lde_rt(P, pdt, r * ldp + c); g[i] = dP[r * lddp + c]; }
+      pd += p[i] * g[i];
+    }
+    pd = group_sum(pd, 64);
+    if (lane == 0) dacc += pd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < ldo) ste_rt(out, odt, r * ldo + c, sc * p[i] * (g[i] - pd));
+    }
+  }
+  if (dot_accum) {
+    const float t = block_sum(dacc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_accum, t);
+  }
+}
 __global__ __launch_bounds__(256) void softmax_bwd_long_k(const void* P, int pdt, long ldp, const float* dP, long lddp, void* out,
                                                           int odt, long ldo, int L, const float* scale_ptr, float* dot_accum) {
   __shared__ float red[4];
@@ -1175,6 +1235,10 @@ void softmax_bwd_rows(const Ctx& ctx, const void* P, long ldp, const float* dP, 
     const long nb = cdiv(rows, 256 / gs);
     hipLaunchKernelGGL(softmax_bwd_short_k, dim3((int)(nb > 2048 ? 2048 : nb)), dim3(256), 0, STREAM(ctx), P, pdt, ldp, dP, lddp,
                        out, odt, ldo, rows, L, gs, scale_ptr, dot_accum);
+  } else if (L <= 256 && ldo <= 256) {
+    const long nb = cdiv(rows, 4);
+    hipLaunchKernelGGL(softmax_bwd_wave_k, dim3((int)(nb > 4096 ? 4096 : nb)), dim3(256), 0, STREAM(ctx), P, pdt, ldp, dP, lddp, out, odt,
+                       ldo, rows, L, scale_ptr, dot_accum);
   } else if (pdt == DT_BF16 && odt == DT_BF16 && L % 4 == 0 && ldp % 4 == 0 && lddp % 4 == 0 && ldo % 4 == 0 && ldo <= 4096 &&
              al8(P) && al16(dP) && al8(out)) {
     const int nch = (int)cdiv(ldo, 1024);
