@@ -79,7 +79,7 @@ typedef struct dgsct_adapter_desc {
   int32_t T;         /* frames per clip (10; 5 for AVS) -- only checked (BT % T == 0)             */
   int32_t N, C;      /* own modality: tokens, width   (conv_dim_out, input_dim == linear_out)     */
   int32_t No, Co;    /* other modality: tokens, width (conv_dim_in, linear_in)                    */
-  int32_t tk;        /* latent tokens (num_tk / opt.num_tokens)                                   */
+  int32_t tk;        /* latent tokens (num_tk / opt.num_tokens), 1..1024; > 32: csrc/attn_wide.cpp */
   int32_t r, g;      /* reduction_factor (opt.Adapter_downsample), opt.num_conv_group             */
   int32_t dtype;     /* DGSCT_F32 | DGSCT_BF16 | DGSCT_BF16_FP8: activation storage + MFMA operand type */
   int32_t remap;     /* DGSCT_REMAP_*                                                             */
