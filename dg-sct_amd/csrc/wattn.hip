@@ -55,16 +55,39 @@ __device__ __forceinline__ int tok_row(const WArgs& p, int wy, int wx, int t) {
   x = x >= p.W ? x - p.W : x;
   return y * p.W + x;
 }
-// gather rows t = 0 .. n-1 of one of q / k / v (or of O / dO: `rowstride` elements between tokens, `col0` first column) into a
-// [WMAXN][32] bf16 image; rows >= n and columns >= hd are zero.  256 or fewer threads, 4 chunks of 16 B per row.
-__device__ __forceinline__ void gather_img(char* img, const unsigned short* base, long rowstride, int col0, const int* rows, int n, int npad,
-                                           int hd, int tid, int nthr) {
-  for (int idx = tid; idx < npad * 4; idx += nthr) {
-    const int t = idx >> 2, c = (idx & 3) * 8;
-    const int tt = t < n ? t : n - 1, cc = c < hd ? c : 0;
-    uint4 v = *reinterpret_cast<const uint4*>(base + (long)rows[tt] * rowstride + col0 + cc);
-    if (t >= n || c >= hd) v = make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4*>(img + t * WP + c * 2) = v;
+// gather rows t = 0 .. n-1 of NI tensors (q / k / v of a head: `rowstride` elements between tokens, first column col0[i]; or O / dO) into NI
+// consecutive [npad][32] bf16 images (WIMG bytes apart); rows >= n and columns >= hd are zero.  4 chunks of 16 B per row; per trip a thread
+// has its NI loads of TWO chunks in flight before the first LDS store (one image at a time, one chunk per trip, every load was a
+// serialised round trip: the kernels spent their time here, not in the products).
+struct GSrc { const unsigned short* base; long rowstride; int col0; };
+template <int NI>
+__device__ __forceinline__ void gather_imgs(char* img0, int wimg, const GSrc (&src)[NI], const int* rows, int n, int npad, int hd, int tid, int nthr) {
+  const int total = npad * 4;
+  for (int idx = tid; idx < total; idx += 2 * nthr) {
+    uint4 v[2][NI];
+    int off[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int id = idx + u * nthr, idc = id < total ? id : total - 1;
+      const int t = idc >> 2, c = (idc & 3) * 8;
+      const int tt = t < n ? t : n - 1, cc = c < hd ? c : 0;
+      const long ro = (long)rows[tt];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) v[u][i] = *reinterpret_cast<const uint4*>(src[i].base + ro * src[i].rowstride + src[i].col0 + cc);
+      if (t >= n || c >= hd) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[u][i] = make_uint4(0, 0, 0, 0);
+      }
+      off[u] = t * WP + c * 2;
+      live[u] = id < total;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (live[u]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(img0 + i * wimg + off[u]) = v[u][i];
+      }
   }
 }
 // K-major fragment of rows row0 .. +31, k-step kk (16 deep): lane l holds image[row0 + (l & 31)][16 kk + 8 (l >> 5) .. + 7]
@@ -109,7 +132,7 @@ __device__ __forceinline__ void store_rows_T(const wf16& o, float mul, unsigned 
 
 // ---- forward --------------------------------------------------------------------------------------------------------
 template <int NPAD>
-__global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_fwd_k(const WArgs p) {
+__global__ __launch_bounds__(NPAD <= 64 ? 128 : 320, 4) void wattn_fwd_k(const WArgs p) {
   constexpr int WIMG = NPAD * WP, WMAXT = NPAD / 32;
   __shared__ __attribute__((aligned(16))) char smem[3 * WIMG];
   __shared__ int rows[NPAD];
@@ -121,23 +144,26 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_fwd_k(const WArg
   __syncthreads();
   char* sQ = smem; char* sK = smem + WIMG; char* sV = smem + 2 * WIMG;
   const unsigned short* qb = p.qkv + (long)b * L * 3 * C + head * p.hd;
-  gather_img(sQ, qb, 3L * C, 0, rows, n, npad, p.hd, tid, blockDim.x);
-  gather_img(sK, qb, 3L * C, C, rows, n, npad, p.hd, tid, blockDim.x);
-  gather_img(sV, qb, 3L * C, 2 * C, rows, n, npad, p.hd, tid, blockDim.x);
+  {
+    const GSrc src[3] = {{qb, 3L * C, 0}, {qb, 3L * C, C}, {qb, 3L * C, 2 * C}};
+    gather_imgs<3>(smem, WIMG, src, rows, n, npad, p.hd, tid, blockDim.x);
+  }
   __syncthreads();
   const float sc = p.scale[head];
   const float* bmh = p.bm + ((long)(w % p.nwm) * p.heads + head) * n * n;
   for (int it = wave; it < nt; it += nwv) {
     const int i = it * 32 + (lane & 31), ic = i < n ? i : n - 1;
     const wbf8 q0 = frag_km(sQ, it * 32, 0, lane), q1 = frag_km(sQ, it * 32, 1, lane);
-    wf16 s[WMAXT];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int jt = 0; jt < WMAXT; ++jt) {
-      if (jt >= nt) break;
-      zero16(s[jt]);
-      s[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km(sK, jt * 32, 0, lane), q0, s[jt], 0, 0, 0);
-      s[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km(sK, jt * 32, 1, lane), q1, s[jt], 0, 0, 0);
+    // online softmax over the j tiles (running maximum, the accumulator rescaled when it moves): one logits tile live at a time.  With all
+    // five tiles of a 12 x 12 window held for a two-pass softmax the kernel needed 196 VGPRs -- two wavefronts per SIMD.
+    float mx = -INFINITY, sum = 0.f;
+    wf16 o; zero16(o);
+#pragma unroll 1
+    for (int jt = 0; jt < nt; ++jt) {
+      wf16 s; zero16(s);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km(sK, jt * 32, 0, lane), q0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km(sK, jt * 32, 1, lane), q1, s, 0, 0, 0);
+      float mt = -INFINITY;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int j0 = jt * 32 + 8 * q + 4 * (lane >> 5);          // n % 4 == 0: the four columns are all inside or all outside
@@ -145,29 +171,23 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_fwd_k(const WArg
         const float be[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = j0 < n ? s[jt][4 * q + e] * sc + be[e] : -INFINITY;
-          s[jt][4 * q + e] = v;
-          mx = fmaxf(mx, v);
+          const float v = j0 < n ? s[4 * q + e] * sc + be[e] : -INFINITY;
+          s[4 * q + e] = v;
+          mt = fmaxf(mt, v);
         }
       }
-    }
-    mx = fmaxf(mx, xor32(mx));
-    float sum = 0.f;
+      mt = fmaxf(mt, xor32(mt));                                   // (every tile jt < nt has a column inside: finite)
+      const float mn = fmaxf(mx, mt), alpha = __expf(mx - mn);     // first tile: exp(-inf) = 0
+      float part = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < WMAXT; ++jt) {
-      if (jt >= nt) break;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const float e = __expf(s[jt][r] - mx); s[jt][r] = e; sum += e; }
-    }
-    sum += xor32(sum);
-    wf16 o; zero16(o);
-#pragma unroll
-    for (int jt = 0; jt < WMAXT; ++jt) {
-      if (jt >= nt) break;
-      float* sv = reinterpret_cast<float*>(&s[jt]);
+      for (int r = 0; r < 16; ++r) { const float e = __expf(s[r] - mn); s[r] = e; part += e; o[r] *= alpha; }
+      sum = sum * alpha + part;
+      mx = mn;
+      float* sv = reinterpret_cast<float*>(&s);
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_acc(sV, jt * 32, 0, lane), regs8(sv), o, 0, 0, 0);
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_acc(sV, jt * 32, 1, lane), regs8(sv + 8), o, 0, 0, 0);
     }
+    sum += xor32(sum);
     store_rows_T(o, 1.f / sum, p.out + (long)b * L * C, C, head * p.hd, rows, it * 32, n, p.hd, lane);
     if (lane < 32 && i < n) p.lse[(((long)b * p.nW + w) * p.heads + head) * n + i] = mx + __logf(sum);
   }
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_fwd_k(const WArg
 
 // ---- backward -------------------------------------------------------------------------------------------------------
 template <int NPAD>
-__global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_bwd_k(const WArgs p) {
+__global__ __launch_bounds__(NPAD <= 64 ? 128 : 320, 4) void wattn_bwd_k(const WArgs p) {
   constexpr int WIMG = NPAD * WP, WMAXT = NPAD / 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * WIMG];
   __shared__ int rows[NPAD];
@@ -188,23 +208,33 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_bwd_k(const WArg
   __syncthreads();
   char* sQ = smem; char* sK = smem + WIMG; char* sV = smem + 2 * WIMG; char* sG = smem + 3 * WIMG;
   const unsigned short* qb = p.qkv + (long)b * L * 3 * C + head * p.hd;
-  gather_img(sQ, qb, 3L * C, 0, rows, n, npad, p.hd, tid, blockDim.x);
-  gather_img(sK, qb, 3L * C, C, rows, n, npad, p.hd, tid, blockDim.x);
-  gather_img(sV, qb, 3L * C, 2 * C, rows, n, npad, p.hd, tid, blockDim.x);
-  gather_img(sG, p.dout + (long)b * L * C + head * p.hd, C, 0, rows, n, npad, p.hd, tid, blockDim.x);
-  for (int t = tid; t < npad; t += blockDim.x) {             // D_i = dO_i . O_i (fp32), lse_i
+  {
+    const GSrc src[4] = {{qb, 3L * C, 0}, {qb, 3L * C, C}, {qb, 3L * C, 2 * C}, {p.dout + (long)b * L * C + head * p.hd, C, 0}};
+    gather_imgs<4>(smem, WIMG, src, rows, n, npad, p.hd, tid, blockDim.x);
+  }
+  for (int t = tid; t < npad; t += blockDim.x) {             // D_i = dO_i . O_i (fp32), lse_i: all eight 16-byte loads of a row in flight
     float d = 0.f, l = 0.f;
     if (t < n) {
       const unsigned short* og = p.o_in + ((long)b * L + rows[t]) * C + head * p.hd;
       const unsigned short* gg = p.dout + ((long)b * L + rows[t]) * C + head * p.hd;
-      for (int c = 0; c < p.hd; c += 8) {
-        float x[8], y[8];
-        unpack<DT_BF16, 8>(*reinterpret_cast<const uint4*>(og + c), x);
-        unpack<DT_BF16, 8>(*reinterpret_cast<const uint4*>(gg + c), y);
+      uint4 xo[4], xg[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d += x[e] * y[e];
+      for (int q = 0; q < 4; ++q) {
+        const int c = 8 * q < p.hd ? 8 * q : 0;
+        xo[q] = *reinterpret_cast<const uint4*>(og + c);
+        xg[q] = *reinterpret_cast<const uint4*>(gg + c);
       }
       l = p.lse[(((long)b * p.nW + w) * p.heads + head) * n + t];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float x[8], y[8];
+        unpack<DT_BF16, 8>(xo[q], x);
+        unpack<DT_BF16, 8>(xg[q], y);
+        float dd = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dd += x[e] * y[e];
+        if (8 * q < p.hd) d += dd;
+      }
     }
     sD[t] = d; sL[t] = l;
   }
@@ -219,9 +249,8 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_bwd_k(const WArg
     const wbf8 g0 = frag_km(sG, it * 32, 0, lane), g1 = frag_km(sG, it * 32, 1, lane);
     const float li = sL[ic], di = sD[ic];
     wf16 o; zero16(o);
-#pragma unroll
-    for (int jt = 0; jt < WMAXT; ++jt) {
-      if (jt >= nt) break;
+#pragma unroll 1                                             // (unrolled over 5 tiles the compiler kept every tile's fragments and temporaries
+    for (int jt = 0; jt < nt; ++jt) {                        //  live: 482 VGPRs, one wavefront per SIMD)
       wf16 s, dp; zero16(s); zero16(dp);
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km(sK, jt * 32, 0, lane), q0, s, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km(sK, jt * 32, 1, lane), q1, s, 0, 0, 0);
@@ -251,9 +280,8 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 256) void wattn_bwd_k(const WArg
     const wbf8 k0 = frag_km(sK, jt * 32, 0, lane), k1 = frag_km(sK, jt * 32, 1, lane);
     const wbf8 v0 = frag_km(sV, jt * 32, 0, lane), v1 = frag_km(sV, jt * 32, 1, lane);
     wf16 ok, ov; zero16(ok); zero16(ov);
-#pragma unroll
-    for (int it = 0; it < WMAXT; ++it) {
-      if (it >= nt) break;
+#pragma unroll 1
+    for (int it = 0; it < nt; ++it) {
       wf16 s, dp; zero16(s); zero16(dp);
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km(sQ, it * 32, 0, lane), k0, s, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km(sQ, it * 32, 1, lane), k1, s, 0, 0, 0);
@@ -298,7 +326,7 @@ int window_attn_forward(void* stream, int B, int H, int W, int ws, int shift, in
   if (!wattn_check(B, H, W, ws, shift, heads, hd, nwm)) return 2;
   WArgs a = wattn_args(B, H, W, ws, shift, heads, hd, nwm);
   a.qkv = (const unsigned short*)qkv; a.bm = bm; a.scale = scale; a.out = (unsigned short*)out; a.lse = lse;
-  const int nt = (a.n + 31) / 32, nw = nt < 4 ? nt : 4;
+  const int nt = (a.n + 31) / 32, nw = nt;        // one wavefront per 32-row tile (n <= 144: <= 5; four waves left one with two of the five tiles)
   const dim3 grid((unsigned)((long)B * a.nW * heads));
   if (a.n <= 64) hipLaunchKernelGGL(wattn_fwd_k<64>, grid, dim3(64 * nw), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(wattn_fwd_k<WMAXN>, grid, dim3(64 * nw), 0, (hipStream_t)stream, a);
@@ -310,7 +338,7 @@ int window_attn_backward(void* stream, int B, int H, int W, int ws, int shift, i
   WArgs a = wattn_args(B, H, W, ws, shift, heads, hd, nwm);
   a.qkv = (const unsigned short*)qkv; a.bm = bm; a.scale = scale; a.o_in = (const unsigned short*)out; a.lse = const_cast<float*>(lse);
   a.dout = (const unsigned short*)dout; a.dqkv = (unsigned short*)dqkv;
-  const int nt = (a.n + 31) / 32, nw = nt < 4 ? nt : 4;
+  const int nt = (a.n + 31) / 32, nw = nt;        // one wavefront per 32-row tile (n <= 144: <= 5; four waves left one with two of the five tiles)
   const dim3 grid((unsigned)((long)B * a.nW * heads));
   if (a.n <= 64) hipLaunchKernelGGL(wattn_bwd_k<64>, grid, dim3(64 * nw), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(wattn_bwd_k<WMAXN>, grid, dim3(64 * nw), 0, (hipStream_t)stream, a);
