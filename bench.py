@@ -337,7 +337,7 @@ def main():
     if args.blocks:
         from dgsct_amd import FrozenBlocks
         fb = FrozenBlocks(stages, dtype=dtype).to(device)
-        trainer.block_kwargs = dict(vis_block=fb.vis_block, aud_block=fb.aud_block)
+        trainer.block_kwargs = dict(vis_block=fb.vis_block_map, aud_block=fb.aud_block)
 
     def fwd_bwd():
         if args.phases:

@@ -67,6 +67,22 @@ def _shift_mask(H: int, W: int, ws: int, shift: int) -> Optional[torch.Tensor]:
     return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
 
 
+def _ln(norm: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None, lib=None) -> torch.Tensor:
+    """`norm(x)` (+ residual) on the library's row kernels (dgsct_layer_norm_*: one pass forward, one backward, the residual add of a
+    post-norm half-block folded in) instead of ATen's LayerNorm + add.  Frozen norms (the reference freezes both backbones,
+    main_trans.py:211-256) use an fp32 copy of weight / bias made once; trainable ones go through a differentiable cast."""
+    from . import ops
+    w, b = norm.weight, norm.bias
+    if torch.is_grad_enabled() and (w.requires_grad or b.requires_grad):
+        return ops.layer_norm(x, w.float(), b.float(), norm.eps, residual, lib)
+    key = (w._version, b._version, w.device)
+    c = norm.__dict__.get("_f32")
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            c = norm.__dict__["_f32"] = (key, w.detach().float().contiguous(), b.detach().float().contiguous())
+    return ops.layer_norm(x, c[1], c[2], norm.eps, residual, lib)
+
+
 class _Mlp(nn.Module):
     def __init__(self, dim: int, hidden: int):
         super().__init__()
@@ -159,8 +175,8 @@ class HTSATBlock(nn.Module):
         if self._use_fused(x):
             # fused window attention (csrc/wattn.hip): the attention probabilities are never materialised, so the second result of the
             # reference call `f_a, _ = blk_a(f_a)` (net_trans.py:897, discarded there) is None on this path
-            x = x + self.attn.forward_map(self.norm1(x), H, W, self.shift_size, self.attn_mask, self._lib)
-            return x + self.mlp(self.norm2(x)), None
+            x = x + self.attn.forward_map(_ln(self.norm1, x, None, self._lib), H, W, self.shift_size, self.attn_mask, self._lib)
+            return x + self.mlp(_ln(self.norm2, x, None, self._lib)), None
         y = self.norm1(x).reshape(B, H, W, C)
         s = self.shift_size
         if s:
@@ -279,15 +295,22 @@ class SwinV2Block(nn.Module):
             y = torch.roll(y, shifts=(s, s), dims=(1, 2))
         return y.reshape(B, L, C)
 
-    def attn_branch(self, x):
-        return self.norm1(self._attn(x))
+    def attn_branch(self, x, add_residual: bool = False):
+        """norm1(_attn(x)); add_residual: the whole line `x + norm1(_attn(x))` of net_trans.py:894 (one kernel with the fused LayerNorm)"""
+        if self._use_fused(x):
+            return _ln(self.norm1, self._attn(x), x if add_residual else None, self._lib)
+        y = self.norm1(self._attn(x))
+        return x + y if add_residual else y
 
-    def mlp_branch(self, x):
-        return self.norm2(self.mlp(x))
+    def mlp_branch(self, x, add_residual: bool = False):
+        if self._use_fused(x):
+            return _ln(self.norm2, self.mlp(x), x if add_residual else None, self._lib)
+        y = self.norm2(self.mlp(x))
+        return x + y if add_residual else y
 
     def forward(self, x):
-        x = x + self.attn_branch(x)
-        return x + self.mlp_branch(x)
+        x = self.attn_branch(x, add_residual=True)
+        return self.mlp_branch(x, add_residual=True)
 
 
 # heads per stage: Swin-V2-B / -L (timm `swinv2_{base,large}_window12_192_22k`), HTS-AT (esc_config.py:67)
@@ -317,6 +340,13 @@ class FrozenBlocks(nn.Module):
         """the residual branch of Swin block `idx`: half 0 = window attention, half 1 = MLP (net_trans.py:894 / :903)"""
         blk = self.vis[idx]
         return blk.attn_branch(f_v) if half == 0 else blk.mlp_branch(f_v)
+
+    def vis_block_map(self, idx: int, half: int, f_v: torch.Tensor) -> torch.Tensor:
+        """the whole residual line `f_v + branch(f_v)`: what AdapterStack takes when the callable says `returns_map` (the add then sits in
+        the fused LayerNorm kernel instead of a launch of its own)"""
+        blk = self.vis[idx]
+        return blk.attn_branch(f_v, True) if half == 0 else blk.mlp_branch(f_v, True)
+    vis_block_map.returns_map = True
 
     def aud_block(self, idx: int, f_a: torch.Tensor) -> torch.Tensor:
         """the whole HTS-AT block `idx` (net_trans.py:897): returns the updated map"""

@@ -291,6 +291,37 @@ int dgsct_window_attn_backward(int B, int H, int W, int ws, int shift, int heads
   return has_error() ? 1 : 0;
 }
 
+static bool ln_check(const char* who, int dtype, int64_t rows, int C) {
+  if (dtype != DGSCT_F32 && dtype != DGSCT_BF16) { set_error("%s: dtype must be DGSCT_F32 or DGSCT_BF16", who); return false; }
+  if (rows < 1 || rows > 0x7fffffffLL || C < 4 || C > 1536 || C % 4 || (dtype == DGSCT_BF16 && C % 8)) {
+    set_error("%s: rows must be 1 .. 2^31-1, C a multiple of 4 (bf16: 8) and <= 1536 (got %lld x %d)", who, (long long)rows, C);
+    return false;
+  }
+  return true;
+}
+int64_t dgsct_layer_norm_scratch_floats(int C) { return row_part_floats(0, C); }
+int dgsct_layer_norm_forward(int dtype, int64_t rows, int C, const void* x, const float* w, const float* b, float eps, const void* residual,
+                             void* out, float* mu, float* rstd, void* stream) {
+  begin_call();
+  if (!x || !w || !b || !out || !mu || !rstd) { set_error("dgsct_layer_norm_forward: NULL argument"); return 2; }
+  if (!ln_check("dgsct_layer_norm_forward", dtype, rows, C)) return 2;
+  Ctx ctx{stream, dtype};
+  tail_fwd(ctx, x, nullptr, nullptr, w, b, nullptr, 0, eps, (long)rows, C, out, mu, rstd, residual, nullptr);
+  check_async("dgsct_layer_norm_forward");
+  return has_error() ? 1 : 0;
+}
+int dgsct_layer_norm_backward(int dtype, int64_t rows, int C, const void* dout, const void* x, const float* w, const float* b, const float* mu,
+                              const float* rstd, float eps, void* dx, float* dw, float* db, float* scratch, void* stream) {
+  begin_call();
+  if (!dout || !x || !w || !b || !mu || !rstd || !dx || !dw || !db) { set_error("dgsct_layer_norm_backward: NULL argument"); return 2; }
+  if (!ln_check("dgsct_layer_norm_backward", dtype, rows, C)) return 2;
+  Ctx ctx{stream, dtype};
+  tail_bwd(ctx, dout, x, nullptr, nullptr, nullptr, nullptr, w, b, nullptr, 0, mu, rstd, (long)rows, C, dx, dw, db, nullptr, nullptr, eps,
+           scratch, scratch ? row_part_floats(0, C) : 0);
+  check_async("dgsct_layer_norm_backward");
+  return has_error() ? 1 : 0;
+}
+
 int dgsct_test_gemm_fp8(int M, int N, int K, const void* A, const float* W, const float* bias, int relu, void* D, void* w8,
                         float* scale, void* stream) {
   begin_call();

@@ -725,3 +725,70 @@ def window_attention(qkv: torch.Tensor, bm: torch.Tensor, scale: torch.Tensor, H
         raise RuntimeError("dg-sct_amd: window_attention: bm must be fp32 [1 | windows, heads, n, n] and scale fp32 [heads]")
     from ._lib import default_lib
     return _WindowAttnFn.apply(lib or default_lib(), qkv.contiguous(), bm.contiguous(), scale.contiguous(), H, W, ws, shift, heads)
+
+
+# ---- LayerNorm (+ residual) of the frozen backbone blocks ----------------------------------------------------
+_LN_SCRATCH: Dict[Tuple, torch.Tensor] = {}
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """out = LN(x; w, b) (+ residual) on the adapter tail's row kernels (dgsct_layer_norm_*): one pass forward (row statistics kept), one
+    pass backward; w / b fp32.  Gradients for w / b only when they ask for one (the blocks are frozen: main_trans.py:211-256)."""
+
+    @staticmethod
+    def forward(ctx, lib, x, w, b, eps, residual):
+        C_ = x.shape[-1]
+        rows = x.numel() // C_
+        out = torch.empty_like(x)
+        mu = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _mark_stream_use(x, w, b, residual)
+        with _dev_guard(x):
+            lib.layer_norm_forward(0 if x.dtype == torch.float32 else 1, rows, C_, x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps),
+                                   residual.data_ptr() if residual is not None else None, out.data_ptr(), mu.data_ptr(), rstd.data_ptr(),
+                                   _stream_of(x))
+        ctx.lib, ctx.eps, ctx.has_res = lib, float(eps), residual is not None
+        ctx.save_for_backward(x, w, b, mu, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, b, mu, rstd = ctx.saved_tensors
+        C_ = x.shape[-1]
+        rows = x.numel() // C_
+        dout = dout.contiguous()
+        if dout.dtype != x.dtype:
+            dout = dout.to(x.dtype)
+        dx = torch.empty_like(x)
+        dwb = torch.zeros(2, C_, dtype=torch.float32, device=x.device)
+        key = (id(ctx.lib), x.device, _stream_of(x), C_)
+        scr = _LN_SCRATCH.get(key)
+        if scr is None:
+            scr = _LN_SCRATCH[key] = torch.empty(int(ctx.lib.c.dgsct_layer_norm_scratch_floats(C_)), dtype=torch.float32, device=x.device)
+        _mark_stream_use(x, w, b, mu, rstd, dout)
+        with _dev_guard(x):
+            ctx.lib.layer_norm_backward(0 if x.dtype == torch.float32 else 1, rows, C_, dout.data_ptr(), x.data_ptr(), w.data_ptr(),
+                                        b.data_ptr(), mu.data_ptr(), rstd.data_ptr(), ctx.eps, dx.data_ptr(), dwb[0].data_ptr(),
+                                        dwb[1].data_ptr(), scr.data_ptr(), _stream_of(x))
+        return (None, dx, dwb[0] if ctx.needs_input_grad[2] else None, dwb[1] if ctx.needs_input_grad[3] else None, None,
+                dout if ctx.has_res else None)
+
+
+def layer_norm_supported(x: torch.Tensor) -> bool:
+    C_ = x.shape[-1]
+    return x.dtype in (torch.float32, torch.bfloat16) and C_ <= 1536 and C_ % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.numel() > 0
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
+               lib: Optional[Lib] = None) -> torch.Tensor:
+    """`F.layer_norm(x, (C,), weight, bias, eps)` (+ residual) over the last axis of x [..., C] (fp32 | bf16); weight / bias fp32 [C]."""
+    if not layer_norm_supported(x):
+        raise RuntimeError("dg-sct_amd: layer_norm takes fp32 / bf16 rows of <= 1536 channels (a multiple of 4; bf16: 8)")
+    if weight.dtype != torch.float32 or bias.dtype != torch.float32:
+        raise RuntimeError("dg-sct_amd: layer_norm: weight / bias must be fp32")
+    from ._lib import default_lib
+    if residual is not None:
+        residual = residual.contiguous()
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise RuntimeError("dg-sct_amd: layer_norm: residual must match x")
+    return _LayerNormFn.apply(lib or default_lib(), x.contiguous(), weight.contiguous(), bias.contiguous(), eps, residual)

@@ -96,7 +96,8 @@ class AdapterStack(nn.Module):
     def forward(self, feats: Sequence[Tuple[torch.Tensor, torch.Tensor]],
                 vis_block: Optional[Callable] = None, aud_block: Optional[Callable] = None):
         """feats[s] = (f_v [BT,Nv,Cv], f_a [BT,Na,Ca]) entering stage s.  ``vis_block(layer, half, f_v)`` /
-        ``aud_block(layer, f_a)`` return the frozen residual branches (None = identity stand-in).
+        ``aud_block(layer, f_a)`` return the frozen residual branches (None = identity stand-in); a ``vis_block`` with the attribute
+        ``returns_map = True`` returns ``f_v + branch(f_v)`` itself.
         Returns ([(f_v, f_a) leaving each stage], (map_v, map_a) of the last p2 adapters)."""
         outs = []
         idx = 0
@@ -164,7 +165,12 @@ class AdapterStack(nn.Module):
 
         def step(p_audio, p_vis, f_a, f_v, idx, half, with_aud_block):
             # frozen blocks first (they only read the pre-block maps), so their output can be the fused residual
-            r_v = f_v if vis_block is None else f_v + vis_block(idx, half, f_v)
+            if vis_block is None:
+                r_v = f_v
+            elif getattr(vis_block, "returns_map", False):       # the callable returns f_v + branch(f_v) itself (FrozenBlocks.vis_block_map)
+                r_v = vis_block(idx, half, f_v)
+            else:
+                r_v = f_v + vis_block(idx, half, f_v)
             r_a = f_a if (aud_block is None or not with_aud_block) else aud_block(idx, f_a)
             a, v = pair(p_audio, p_vis, f_a, f_v, r_a, r_v)
             if fuse:

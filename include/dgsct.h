@@ -222,6 +222,22 @@ int dgsct_window_attn_forward(int B, int H, int W, int ws, int shift, int heads,
 int dgsct_window_attn_backward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
                                const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, void* stream);
 
+/* ---- LayerNorm (+ residual) of the FROZEN backbone blocks ------------------------------------
+ * Replaces `self.norm1(x)` / `self.norm2(x)` of the HTS-AT block (DG-SCT/AVE/nets/htsat.py:192, :236) and, with `residual`, the whole
+ * residual line of a timm Swin-V2 half-block as the AVE loop writes it, `f_v = f_v + blk.norm1(blk._attn(f_v))`
+ * (DG-SCT/AVE/nets/net_trans.py:894, :903).  The row kernels are the adapter tail's (csrc/prims_hip.hip: tail_fwd / tail_bwd).
+ *   forward : out[r][:] = LN(x[r][:]; w, b, eps) (+ residual[r][:]);   mu / rstd: fp32 [rows], kept for backward
+ *   backward: dx = LayerNorm backward of dout;  dw[c] += sum_r dout * xhat,  db[c] += sum_r dout   (dw, db: fp32 [C], caller-zeroed;
+ *             the residual's gradient is dout itself)
+ * x, residual, out, dout, dx: [rows][C] contiguous, dtype DGSCT_F32 | DGSCT_BF16; w, b: fp32 [C].  C % 4 == 0 (bf16: % 8), C <= 1536.
+ * scratch: dgsct_layer_norm_scratch_floats(C) floats (per-workgroup partial sums of dw / db; NULL: atomics instead).
+ * Asynchronous on `stream`; 0 or an error code. */
+int64_t dgsct_layer_norm_scratch_floats(int C);
+int dgsct_layer_norm_forward(int dtype, int64_t rows, int C, const void* x, const float* w, const float* b, float eps, const void* residual,
+                             void* out, float* mu, float* rstd, void* stream);
+int dgsct_layer_norm_backward(int dtype, int64_t rows, int C, const void* dout, const void* x, const float* w, const float* b, const float* mu,
+                              const float* rstd, float eps, void* dx, float* dw, float* db, float* scratch, void* stream);
+
 /* ---- gate application of the post-backbone TemporalAttention ---------------------------
  * Replaces the tail of `TemporalAttention.forward` (DG-SCT/AVE/nets/net_trans.py:240-251; AVVP nets/mgn.py:148-159):
  *   audio_gate = audio_gated(audio_key_value_feature); video_gate = video_gated(video_key_value_feature)     [T,B,1]

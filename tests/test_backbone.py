@@ -238,3 +238,58 @@ def test_window_attention_kernel_against_the_emulation(geom):
         res[tag] = (o.detach(), q.grad)
     assert _L2(res["hip"][0], res["emu"][0]) < 6e-3
     assert _L2(res["hip"][1], res["emu"][1]) < 1e-2
+
+
+# ---- LayerNorm (+ residual) on the library's row kernels (dgsct_layer_norm_*) -------------------------------------------
+def _layer_norm_case(lib, device, dtype, rows, C, residual, train_affine):
+    from dgsct_amd import ops
+    torch.manual_seed(rows + C)
+    x = torch.randn(rows, C).to(dtype)
+    r = torch.randn(rows, C).to(dtype) if residual else None
+    w, b = (1 + 0.2 * torch.randn(C)), 0.2 * torch.randn(C)
+    g = torch.randn(rows, C).to(dtype)
+    # reference: fp32 evaluation of the same (dtype-representable) inputs
+    xr, wr, br = x.float().clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = r.float().clone().requires_grad_(True) if residual else None
+    yr = torch.nn.functional.layer_norm(xr, (C,), wr, br, 1e-5) + (rr if residual else 0)
+    yr.backward(g.float())
+    xd = x.clone().to(device).requires_grad_(True)
+    rd = r.clone().to(device).requires_grad_(True) if residual else None
+    wd, bd = w.clone().to(device).requires_grad_(train_affine), b.clone().to(device).requires_grad_(train_affine)
+    y = ops.layer_norm(xd.reshape(2, rows // 2, C), wd, bd, 1e-5, rd.reshape(2, rows // 2, C) if residual else None, lib)
+    y.backward(g.to(device).reshape(2, rows // 2, C))
+    tol = 1e-5 if dtype == torch.float32 else 1.2e-2
+    assert _L2(y.reshape(rows, C), yr) < tol and _L2(xd.grad, xr.grad) < (tol if dtype == torch.float32 else 2e-2)
+    if residual:
+        assert torch.equal(rd.grad.cpu(), g)
+    if train_affine:
+        assert _L2(wd.grad, wr.grad) < max(tol, 1e-4) and _L2(bd.grad, br.grad) < max(tol, 1e-4)
+    else:
+        assert wd.grad is None and bd.grad is None
+
+
+_LN_CASES = [(torch.float32, 64, 96, False, True), (torch.float32, 50, 132, True, False), (torch.bfloat16, 64, 128, True, True),
+             (torch.bfloat16, 36, 1024, False, False), (torch.bfloat16, 30, 1536, True, False)]
+
+
+@pytest.mark.parametrize("case", _LN_CASES, ids=lambda c: f"{str(c[0])[6:]}-{c[1]}x{c[2]}-res{int(c[3])}-aff{int(c[4])}")
+def test_layer_norm_c_abi_on_the_host_emulation(case):
+    from build_emu import build_emu
+    from dgsct_amd._lib import Lib
+    _layer_norm_case(Lib(build_emu()), torch.device("cpu"), *case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _LN_CASES + [(torch.bfloat16, 23040, 512, True, False), (torch.bfloat16, 40960, 96, False, True)],
+                         ids=lambda c: f"{str(c[0])[6:]}-{c[1]}x{c[2]}-res{int(c[3])}-aff{int(c[4])}")
+def test_layer_norm_kernels_on_gpu(case):
+    _layer_norm_case(None, torch.device("cuda:0"), *case)
+
+
+def test_vis_block_map_is_the_branch_plus_its_input():
+    """FrozenBlocks.vis_block_map (what bench.py --blocks hands to AdapterStack: `returns_map`) = f_v + vis_block(f_v)"""
+    fb = FrozenBlocks([dict(Nv=36, Cv=128, Na=64, Ca=96, layers=1)], dtype=torch.float32, fused=False)
+    f = torch.randn(2, 36, 128)
+    for half in (0, 1):
+        assert torch.allclose(fb.vis_block_map(0, half, f), f + fb.vis_block(0, half, f), atol=1e-6)
+    assert fb.vis_block_map.returns_map and not getattr(fb.vis_block, "returns_map", False)
