@@ -66,7 +66,7 @@ class AttnArgs(C.Structure):
 EXPORTS = ["dgsct_test_gemm_fp8", "dgsct_temporal_gate_forward", "dgsct_temporal_gate_backward", "dgsct_test_attn", "dgsct_test_attn_scratch_floats", "dgsct_version", "dgsct_arch", "dgsct_last_error", "dgsct_query", "dgsct_prepare", "dgsct_adapter_forward",
            "dgsct_adapter_forward_ex", "dgsct_adapter_backward", "dgsct_adapter_backward_ex", "dgsct_adapter_backward_ex2", "dgsct_saved_region", "dgsct_test_gemm", "dgsct_test_tune", "dgsct_frame_scale_forward", "dgsct_frame_scale_backward", "dgsct_prof_enable", "dgsct_prof_collect",
            "dgsct_stream_create", "dgsct_stream_destroy", "dgsct_map_pool_forward", "dgsct_map_pool_backward",
-           "dgsct_window_attn_forward", "dgsct_window_attn_backward",
+           "dgsct_window_attn_forward", "dgsct_window_attn_backward", "dgsct_window_attn_forward_ex", "dgsct_window_attn_backward_ex",
            "dgsct_layer_norm_scratch_floats", "dgsct_layer_norm_forward", "dgsct_layer_norm_backward"]
 
 _PP = C.POINTER(C.c_void_p)
@@ -124,6 +124,8 @@ class Lib:
         c.dgsct_map_pool_backward.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6
         c.dgsct_window_attn_forward.argtypes = [C.c_int] * 8 + [C.c_void_p] * 6
         c.dgsct_window_attn_backward.argtypes = [C.c_int] * 8 + [C.c_void_p] * 8
+        c.dgsct_window_attn_forward_ex.argtypes = [C.c_int] * 9 + [C.c_void_p] * 6
+        c.dgsct_window_attn_backward_ex.argtypes = [C.c_int] * 9 + [C.c_void_p] * 8
         c.dgsct_layer_norm_scratch_floats.argtypes = [C.c_int]
         c.dgsct_layer_norm_scratch_floats.restype = C.c_int64
         c.dgsct_layer_norm_forward.argtypes = [C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 5
@@ -200,12 +202,12 @@ class Lib:
     def map_pool_backward(self, dtype: int, BT: int, N: int, C_: int, F: int, amap: int, dpooled: int, dF, dmap, stream: int):
         self._check(self.c.dgsct_map_pool_backward(dtype, BT, N, C_, F, amap, dpooled, dF, dmap, stream), "dgsct_map_pool_backward")
 
-    def window_attn_forward(self, geom, qkv, bm, scale, out, lse, stream):
-        """geom = (B, H, W, ws, shift, heads, hd, nwm); pointers as ints (include/dgsct.h: dgsct_window_attn_forward)"""
-        self._check(self.c.dgsct_window_attn_forward(*geom, qkv, bm, scale, out, lse, stream), "dgsct_window_attn_forward")
+    def window_attn_forward(self, geom, qkv, bm, scale, out, lse, stream, flags=0):
+        """geom = (B, H, W, ws, shift, heads, hd, nwm); pointers as ints; flags: WATTN_COSINE (include/dgsct.h: dgsct_window_attn_forward_ex)"""
+        self._check(self.c.dgsct_window_attn_forward_ex(*geom, flags, qkv, bm, scale, out, lse, stream), "dgsct_window_attn_forward")
 
-    def window_attn_backward(self, geom, qkv, bm, scale, out, lse, dout, dqkv, stream):
-        self._check(self.c.dgsct_window_attn_backward(*geom, qkv, bm, scale, out, lse, dout, dqkv, stream), "dgsct_window_attn_backward")
+    def window_attn_backward(self, geom, qkv, bm, scale, out, lse, dout, dqkv, stream, flags=0):
+        self._check(self.c.dgsct_window_attn_backward_ex(*geom, flags, qkv, bm, scale, out, lse, dout, dqkv, stream), "dgsct_window_attn_backward")
 
     def layer_norm_forward(self, dtype, rows, C_, x, w, b, eps, residual, out, mu, rstd, stream):
         self._check(self.c.dgsct_layer_norm_forward(dtype, rows, C_, x, w, b, eps, residual, out, mu, rstd, stream), "dgsct_layer_norm_forward")

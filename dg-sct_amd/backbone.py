@@ -225,16 +225,16 @@ class _WindowAttentionV2(nn.Module):
         return self._tab_cache[1], self._tab_cache[2]
 
     def forward_map(self, y, H, W, shift, mask=None, lib=None):
-        """cosine window attention on the un-partitioned map (see _WindowAttentionV1.forward_map): q, k are normalised here, the fused kernel
-        (csrc/wattn.hip) applies the per-head logit scale, the continuous position bias and the shift mask"""
+        """cosine window attention on the un-partitioned map (see _WindowAttentionV1.forward_map): the fused kernel (csrc/wattn.hip) normalises
+        the q / k rows of a head in LDS (F.normalize), applies the per-head logit scale, the continuous position bias and the shift mask, and
+        its backward returns the gradient of the raw projection"""
         from . import ops
         B, L, C = y.shape
         h = self.num_heads
         bias3 = torch.cat([self.q_bias, torch.zeros_like(self.v_bias), self.v_bias])
-        qkv = F.linear(y, self.qkv.weight, bias3).reshape(B, L, 3, h, C // h)
-        qkv = torch.stack([F.normalize(qkv[:, :, 0], dim=-1), F.normalize(qkv[:, :, 1], dim=-1), qkv[:, :, 2]], dim=2).reshape(B, L, 3 * C)
+        qkv = F.linear(y, self.qkv.weight, bias3)
         bm, scale = self._tables(mask)
-        return self.proj(ops.window_attention(qkv, bm, scale, H, W, self.window_size[0], shift, h, lib))
+        return self.proj(ops.window_attention(qkv, bm, scale, H, W, self.window_size[0], shift, h, lib, cosine=True))
 
     def forward(self, x, mask=None):
         Bw, n, C = x.shape

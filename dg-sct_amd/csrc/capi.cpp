@@ -272,23 +272,33 @@ int dgsct_test_attn(int op, const dgsct_attn_args* a, void* stream) {
   return has_error() ? 1 : 0;
 }
 
-int dgsct_window_attn_forward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
-                              const float* scale, void* out, float* lse, void* stream) {
+int dgsct_window_attn_forward_ex(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, int flags, const void* qkv, const float* bm,
+                                 const float* scale, void* out, float* lse, void* stream) {
   begin_call();
   if (!qkv || !bm || !scale || !out || !lse) { set_error("dgsct_window_attn_forward: NULL argument"); return 2; }
-  const int rc = window_attn_forward(stream, B, H, W, ws, shift, heads, hd, nwm, qkv, bm, scale, out, lse);
+  if (flags & ~DGSCT_WATTN_COSINE) { set_error("dgsct_window_attn_forward: unknown flag bits 0x%x", flags); return 2; }
+  const int rc = window_attn_forward(stream, B, H, W, ws, shift, heads, hd, nwm, qkv, bm, scale, out, lse, flags & DGSCT_WATTN_COSINE);
   if (rc) return rc;
   check_async("dgsct_window_attn_forward");
   return has_error() ? 1 : 0;
 }
-int dgsct_window_attn_backward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
-                               const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, void* stream) {
+int dgsct_window_attn_backward_ex(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, int flags, const void* qkv, const float* bm,
+                                  const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, void* stream) {
   begin_call();
   if (!qkv || !bm || !scale || !out || !lse || !dout || !dqkv) { set_error("dgsct_window_attn_backward: NULL argument"); return 2; }
-  const int rc = window_attn_backward(stream, B, H, W, ws, shift, heads, hd, nwm, qkv, bm, scale, out, lse, dout, dqkv);
+  if (flags & ~DGSCT_WATTN_COSINE) { set_error("dgsct_window_attn_backward: unknown flag bits 0x%x", flags); return 2; }
+  const int rc = window_attn_backward(stream, B, H, W, ws, shift, heads, hd, nwm, qkv, bm, scale, out, lse, dout, dqkv, flags & DGSCT_WATTN_COSINE);
   if (rc) return rc;
   check_async("dgsct_window_attn_backward");
   return has_error() ? 1 : 0;
+}
+int dgsct_window_attn_forward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
+                              const float* scale, void* out, float* lse, void* stream) {
+  return dgsct_window_attn_forward_ex(B, H, W, ws, shift, heads, hd, nwm, 0, qkv, bm, scale, out, lse, stream);
+}
+int dgsct_window_attn_backward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
+                               const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, void* stream) {
+  return dgsct_window_attn_backward_ex(B, H, W, ws, shift, heads, hd, nwm, 0, qkv, bm, scale, out, lse, dout, dqkv, stream);
 }
 
 static bool ln_check(const char* who, int dtype, int64_t rows, int C) {

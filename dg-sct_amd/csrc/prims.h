@@ -382,9 +382,10 @@ void frame_scale_bwd(const Ctx&, int rows, long inner, float gamma, const void* 
 // O = softmax(scale_h q k^T + bm[w % nwm][h]) v per (frame, window, head), window partition + cyclic shift as address arithmetic on the
 // [B][H*W][3][heads][hd] qkv projection of the un-partitioned map; bf16, hd in {8, 16, 24, 32}, ws*ws <= 144.  Return 0 or 2 (set_error).
 int window_attn_forward(void* stream, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
-                        const float* scale, void* out, float* lse);
+                        const float* scale, void* out, float* lse, int cosine = 0);
 int window_attn_backward(void* stream, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
-                         const float* scale, const void* out, const float* lse, const void* dout, void* dqkv);
+                         const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, int cosine = 0);
+// cosine != 0 (Swin-V2): q and k rows are L2-normalised inside (x / max(|x|, 1e-12)); backward returns the gradient of the RAW q, k
 
 // Small fp32/E elementwise helpers on [n]-sized vectors (n <= a few 100k).
 enum EwOp : int {

@@ -45,6 +45,7 @@ struct WArgs {
   const unsigned short* dout;                   // backward: dO, laid out like O
   unsigned short* dqkv;                         // backward: laid out like qkv (every element written exactly once)
   int H, W, ws, shift, heads, hd, n, nW, nwm, nwx;
+  int cosine;                                   // q, k rows are L2-normalised in LDS (Swin-V2 cosine attention); backward returns d(raw q, k)
 };
 
 // map row (token index y * W + x) of local token t of window w: window partition + cyclic shift as address arithmetic
@@ -129,6 +130,54 @@ __device__ __forceinline__ void store_rows_T(const wf16& o, float mul, unsigned 
   }
 }
 
+// cosine attention (Swin-V2: F.normalize(q), F.normalize(k) in front of the logits): rows of the Q and K images (consecutive, WIMG apart)
+// scaled to unit L2 norm in place, x / max(|x|, 1e-12) in fp32, stored bf16; inv (optional, [2][npad]) keeps 1 / max(|x|, eps) for backward
+__device__ __forceinline__ void normalise_qk(char* img0, int wimg, int npad, float* inv, int tid, int nthr) {
+  for (int idx = tid; idx < 2 * npad; idx += nthr) {
+    const int which = idx >= npad, t = idx - which * npad;
+    char* row = img0 + which * wimg + t * WP;
+    float x[4][8], ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unpack<DT_BF16, 8>(*reinterpret_cast<const uint4*>(row + q * 16), x[q]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += x[q][e] * x[q][e];
+    }
+    const float r = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<uint4*>(row + q * 16) = make_uint4(f2bf2(x[q][0] * r, x[q][1] * r), f2bf2(x[q][2] * r, x[q][3] * r),
+                                                           f2bf2(x[q][4] * r, x[q][5] * r), f2bf2(x[q][6] * r, x[q][7] * r));
+    if (inv) inv[idx] = r;
+  }
+}
+// store_rows_T through the backward of the normalisation: o holds d(normalised row)^T; the raw row's gradient is
+// inv * (g - xn (xn . g)), xn = the normalised row (from its LDS image).  Every lane takes part in the row dot (lane ^ 32 holds the other half).
+__device__ __forceinline__ void store_rows_T_cos(const wf16& o, float mul, const char* img, const float* inv, unsigned short* base, long rowstride,
+                                                 int col0, const int* rows, int row0, int n, int hd, int lane) {
+  const int t = row0 + (lane & 31);
+  float xn[16], dot = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint2 u = *reinterpret_cast<const uint2*>(img + t * WP + (8 * q + 4 * (lane >> 5)) * 2);
+    xn[4 * q] = __uint_as_float(u.x << 16); xn[4 * q + 1] = __uint_as_float(u.x & 0xffff0000u);
+    xn[4 * q + 2] = __uint_as_float(u.y << 16); xn[4 * q + 3] = __uint_as_float(u.y & 0xffff0000u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dot += o[4 * q + e] * xn[4 * q + e];
+  }
+  dot += xor32(dot);
+  if (t >= n) return;
+  const float f = mul * inv[t];
+  unsigned short* d = base + (long)rows[t] * rowstride + col0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 8 * q + 4 * (lane >> 5);
+    if (c < hd)
+      *reinterpret_cast<uint2*>(d + c) = make_uint2(f2bf2(f * (o[4 * q] - xn[4 * q] * dot), f * (o[4 * q + 1] - xn[4 * q + 1] * dot)),
+                                                    f2bf2(f * (o[4 * q + 2] - xn[4 * q + 2] * dot), f * (o[4 * q + 3] - xn[4 * q + 3] * dot)));
+  }
+}
+
 
 // ---- forward --------------------------------------------------------------------------------------------------------
 template <int NPAD>
@@ -149,6 +198,7 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 320, 4) void wattn_fwd_k(const W
     gather_imgs<3>(smem, WIMG, src, rows, n, npad, p.hd, tid, blockDim.x);
   }
   __syncthreads();
+  if (p.cosine) { normalise_qk(smem, WIMG, npad, nullptr, tid, blockDim.x); __syncthreads(); }
   const float sc = p.scale[head];
   const float* bmh = p.bm + ((long)(w % p.nwm) * p.heads + head) * n * n;
   for (int it = wave; it < nt; it += nwv) {
@@ -199,7 +249,7 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 320, 4) void wattn_bwd_k(const W
   constexpr int WIMG = NPAD * WP, WMAXT = NPAD / 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * WIMG];
   __shared__ int rows[NPAD];
-  __shared__ float sL[NPAD], sD[NPAD];
+  __shared__ float sL[NPAD], sD[NPAD], sInv[2 * NPAD];       // sInv: 1 / |q_i|, 1 / |k_j| (cosine mode)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
   const int head = blockIdx.x % p.heads, w = (blockIdx.x / p.heads) % p.nW, b = blockIdx.x / (p.heads * p.nW);
   const int wy = w / p.nwx, wx = w - wy * p.nwx;
@@ -239,6 +289,7 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 320, 4) void wattn_bwd_k(const W
     sD[t] = d; sL[t] = l;
   }
   __syncthreads();
+  if (p.cosine) { normalise_qk(smem, WIMG, npad, sInv, tid, blockDim.x); __syncthreads(); }
   const float sc = p.scale[head];
   const float* bmh = p.bm + ((long)(w % p.nwm) * p.heads + head) * n * n;
   unsigned short* dq = p.dqkv + (long)b * L * 3 * C + head * p.hd;
@@ -272,7 +323,8 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 320, 4) void wattn_bwd_k(const W
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_acc(sK, jt * 32, 0, lane), regs8(ds), o, 0, 0, 0);
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_acc(sK, jt * 32, 1, lane), regs8(ds + 8), o, 0, 0, 0);
     }
-    store_rows_T(o, sc, dq, 3L * C, 0, rows, it * 32, n, p.hd, lane);
+    if (p.cosine) store_rows_T_cos(o, sc, sQ, sInv, dq, 3L * C, 0, rows, it * 32, n, p.hd, lane);
+    else store_rows_T(o, sc, dq, 3L * C, 0, rows, it * 32, n, p.hd, lane);
   }
   // pass 2 (j-owner; logits[i][j]): dK and dV rows
   for (int jt = wave; jt < nt; jt += nwv) {
@@ -300,7 +352,8 @@ __global__ __launch_bounds__(NPAD <= 64 ? 128 : 320, 4) void wattn_bwd_k(const W
       ok = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_acc(sQ, it * 32, 0, lane), regs8(ds), ok, 0, 0, 0);
       ok = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_acc(sQ, it * 32, 1, lane), regs8(ds + 8), ok, 0, 0, 0);
     }
-    store_rows_T(ok, sc, dq, 3L * C, C, rows, jt * 32, n, p.hd, lane);
+    if (p.cosine) store_rows_T_cos(ok, sc, sK, sInv + npad, dq, 3L * C, C, rows, jt * 32, n, p.hd, lane);
+    else store_rows_T(ok, sc, dq, 3L * C, C, rows, jt * 32, n, p.hd, lane);
     store_rows_T(ov, 1.f, dq, 3L * C, 2 * C, rows, jt * 32, n, p.hd, lane);
   }
 }
@@ -322,9 +375,10 @@ static WArgs wattn_args(int B, int H, int W, int ws, int shift, int heads, int h
   return a;
 }
 int window_attn_forward(void* stream, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
-                        const float* scale, void* out, float* lse) {
+                        const float* scale, void* out, float* lse, int cosine) {
   if (!wattn_check(B, H, W, ws, shift, heads, hd, nwm)) return 2;
   WArgs a = wattn_args(B, H, W, ws, shift, heads, hd, nwm);
+  a.cosine = cosine;
   a.qkv = (const unsigned short*)qkv; a.bm = bm; a.scale = scale; a.out = (unsigned short*)out; a.lse = lse;
   const int nt = (a.n + 31) / 32, nw = nt;        // one wavefront per 32-row tile (n <= 144: <= 5; four waves left one with two of the five tiles)
   const dim3 grid((unsigned)((long)B * a.nW * heads));
@@ -333,9 +387,10 @@ int window_attn_forward(void* stream, int B, int H, int W, int ws, int shift, in
   return 0;
 }
 int window_attn_backward(void* stream, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
-                         const float* scale, const void* out, const float* lse, const void* dout, void* dqkv) {
+                         const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, int cosine) {
   if (!wattn_check(B, H, W, ws, shift, heads, hd, nwm)) return 2;
   WArgs a = wattn_args(B, H, W, ws, shift, heads, hd, nwm);
+  a.cosine = cosine;
   a.qkv = (const unsigned short*)qkv; a.bm = bm; a.scale = scale; a.o_in = (const unsigned short*)out; a.lse = const_cast<float*>(lse);
   a.dout = (const unsigned short*)dout; a.dqkv = (unsigned short*)dqkv;
   const int nt = (a.n + 31) / 32, nw = nt;        // one wavefront per 32-row tile (n <= 144: <= 5; four waves left one with two of the five tiles)

@@ -679,7 +679,7 @@ class _WindowAttnFn(torch.autograd.Function):
     shift are address arithmetic inside the kernel (csrc/wattn.hip).  bm / scale are frozen tables: no gradient."""
 
     @staticmethod
-    def forward(ctx, lib, qkv, bm, scale, H, W, ws, shift, heads):
+    def forward(ctx, lib, qkv, bm, scale, H, W, ws, shift, heads, cosine=False):
         B, L, C3 = qkv.shape
         hd = C3 // (3 * heads)
         nW = (H // ws) * (W // ws)
@@ -688,8 +688,9 @@ class _WindowAttnFn(torch.autograd.Function):
         lse = torch.empty(B, nW, heads, ws * ws, dtype=torch.float32, device=qkv.device)
         _mark_stream_use(qkv, bm, scale)
         with _dev_guard(qkv):
-            lib.window_attn_forward(geom, qkv.data_ptr(), bm.data_ptr(), scale.data_ptr(), out.data_ptr(), lse.data_ptr(), _stream_of(qkv))
-        ctx.lib, ctx.geom = lib, geom
+            lib.window_attn_forward(geom, qkv.data_ptr(), bm.data_ptr(), scale.data_ptr(), out.data_ptr(), lse.data_ptr(), _stream_of(qkv),
+                                    1 if cosine else 0)
+        ctx.lib, ctx.geom, ctx.flags = lib, geom, 1 if cosine else 0
         ctx.save_for_backward(qkv, bm, scale, out, lse)
         return out
 
@@ -703,8 +704,8 @@ class _WindowAttnFn(torch.autograd.Function):
         _mark_stream_use(qkv, bm, scale, out, lse, dout)
         with _dev_guard(qkv):
             ctx.lib.window_attn_backward(ctx.geom, qkv.data_ptr(), bm.data_ptr(), scale.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                                         dout.data_ptr(), dqkv.data_ptr(), _stream_of(qkv))
-        return None, dqkv, None, None, None, None, None, None, None
+                                         dout.data_ptr(), dqkv.data_ptr(), _stream_of(qkv), ctx.flags)
+        return None, dqkv, None, None, None, None, None, None, None, None
 
 
 def window_attention_supported(qkv: torch.Tensor, ws: int, heads: int) -> bool:
@@ -716,15 +717,16 @@ def window_attention_supported(qkv: torch.Tensor, ws: int, heads: int) -> bool:
 
 
 def window_attention(qkv: torch.Tensor, bm: torch.Tensor, scale: torch.Tensor, H: int, W: int, ws: int, shift: int, heads: int,
-                     lib: Optional[Lib] = None) -> torch.Tensor:
+                     lib: Optional[Lib] = None, cosine: bool = False) -> torch.Tensor:
     """qkv [B, H*W, 3*heads*hd] bf16 (token-major map, NOT partitioned / rolled), bm [1 | nW, heads, n, n] fp32, scale [heads] fp32
-    -> O [B, H*W, heads*hd] at the map positions (what window_reverse + roll-back of the reference block produce)."""
+    -> O [B, H*W, heads*hd] at the map positions (what window_reverse + roll-back of the reference block produce).
+    cosine: q and k are L2-normalised per head inside the kernel (Swin-V2), qkv is the raw projection."""
     if not window_attention_supported(qkv, ws, heads):
         raise RuntimeError("dg-sct_amd: window_attention takes bf16 qkv with head width 8/16/24/32 and windows of <= 144 tokens")
     if bm.dtype != torch.float32 or scale.dtype != torch.float32 or bm.shape[1:] != (heads, ws * ws, ws * ws):
         raise RuntimeError("dg-sct_amd: window_attention: bm must be fp32 [1 | windows, heads, n, n] and scale fp32 [heads]")
     from ._lib import default_lib
-    return _WindowAttnFn.apply(lib or default_lib(), qkv.contiguous(), bm.contiguous(), scale.contiguous(), H, W, ws, shift, heads)
+    return _WindowAttnFn.apply(lib or default_lib(), qkv.contiguous(), bm.contiguous(), scale.contiguous(), H, W, ws, shift, heads, cosine)
 
 
 # ---- LayerNorm (+ residual) of the frozen backbone blocks (SURVEY.md 8(f) row f4) ----------------------------------------------------

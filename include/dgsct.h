@@ -221,6 +221,14 @@ int dgsct_window_attn_forward(int B, int H, int W, int ws, int shift, int heads,
                               const float* scale, void* out, float* lse, void* stream);
 int dgsct_window_attn_backward(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv, const float* bm,
                                const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, void* stream);
+/* ..._ex: the same with `flags`.  DGSCT_WATTN_COSINE: q and k rows are L2-normalised inside the kernel, x / max(|x|, 1e-12) as
+ * F.normalize does (the timm Swin-V2 block's cosine attention: qkv is then the RAW projection, and backward returns the gradient of
+ * the raw q / k through the normalisation) -- no normalised copy of the map, no autograd nodes for it. */
+#define DGSCT_WATTN_COSINE 1
+int dgsct_window_attn_forward_ex(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, int flags, const void* qkv, const float* bm,
+                                 const float* scale, void* out, float* lse, void* stream);
+int dgsct_window_attn_backward_ex(int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, int flags, const void* qkv, const float* bm,
+                                  const float* scale, const void* out, const float* lse, const void* dout, void* dqkv, void* stream);
 
 /* ---- LayerNorm (+ residual) of the FROZEN backbone blocks ------------------------------------
  * Replaces `self.norm1(x)` / `self.norm2(x)` of the HTS-AT block (DG-SCT/AVE/nets/htsat.py:192, :236) and, with `residual`, the whole

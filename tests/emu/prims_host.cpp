@@ -1101,22 +1101,34 @@ static int win_row(const WinGeom& g, int w, int t) {
   return ((wy * g.ws + ly + g.shift) % g.H) * g.W + (wx * g.ws + lx + g.shift) % g.W;
 }
 }  // namespace
+// q / k rows of one (frame, window, head) as the kernel holds them in LDS: raw bf16, or (cosine) x / max(|x|, 1e-12) rounded to bf16
+static void win_rows(const WinGeom& g, const uint16_t* qkv, int b, int w, int h, int which, int cosine, std::vector<float>& x, std::vector<float>& inv) {
+  x.assign((size_t)g.n * g.hd, 0.f); inv.assign(g.n, 1.f);
+  for (int t = 0; t < g.n; ++t) {
+    const uint16_t* r = qkv + ((long)b * g.L + win_row(g, w, t)) * 3 * g.C + which * g.C + h * g.hd;
+    float ss = 0.f;
+    for (int d = 0; d < g.hd; ++d) { x[(size_t)t * g.hd + d] = bf2f(r[d]); ss += bf2f(r[d]) * bf2f(r[d]); }
+    if (cosine && which < 2) {
+      inv[t] = 1.f / std::max(std::sqrt(ss), 1e-12f);
+      for (int d = 0; d < g.hd; ++d) x[(size_t)t * g.hd + d] = bf2f(f2bf(x[(size_t)t * g.hd + d] * inv[t]));
+    }
+  }
+}
 int window_attn_forward(void*, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv_, const float* bm,
-                        const float* scale, void* out_, float* lse) {
+                        const float* scale, void* out_, float* lse, int cosine) {
   WinGeom g;
   if (!win_geom(g, B, H, W, ws, shift, heads, hd, nwm)) return 2;
   const uint16_t* qkv = (const uint16_t*)qkv_; uint16_t* out = (uint16_t*)out_;
   const int n = g.n;
-  std::vector<float> s(n);
+  std::vector<float> s(n), Q, K, V, iq, ik, iv;
   for (int b = 0; b < B; ++b) for (int w = 0; w < g.nW; ++w) for (int h = 0; h < heads; ++h) {
     const float* bmh = bm + ((long)(w % nwm) * heads + h) * n * n;
+    win_rows(g, qkv, b, w, h, 0, cosine, Q, iq); win_rows(g, qkv, b, w, h, 1, cosine, K, ik); win_rows(g, qkv, b, w, h, 2, 0, V, iv);
     for (int i = 0; i < n; ++i) {
-      const uint16_t* q = qkv + ((long)b * g.L + win_row(g, w, i)) * 3 * g.C + h * hd;
       float mx = -INFINITY;
       for (int j = 0; j < n; ++j) {
-        const uint16_t* k = qkv + ((long)b * g.L + win_row(g, w, j)) * 3 * g.C + g.C + h * hd;
         float a = 0.f;
-        for (int d = 0; d < hd; ++d) a += bf2f(q[d]) * bf2f(k[d]);
+        for (int d = 0; d < hd; ++d) a += Q[(size_t)i * hd + d] * K[(size_t)j * hd + d];
         s[j] = a * scale[h] + bmh[(long)i * n + j];
         mx = std::max(mx, s[j]);
       }
@@ -1125,7 +1137,7 @@ int window_attn_forward(void*, int B, int H, int W, int ws, int shift, int heads
       uint16_t* o = out + ((long)b * g.L + win_row(g, w, i)) * g.C + h * hd;
       for (int d = 0; d < hd; ++d) {
         float a = 0.f;
-        for (int j = 0; j < n; ++j) a += bf2f(f2bf(s[j])) * bf2f(qkv[((long)b * g.L + win_row(g, w, j)) * 3 * g.C + 2 * g.C + h * hd + d]);   // (bf16 probabilities, as on the device)
+        for (int j = 0; j < n; ++j) a += bf2f(f2bf(s[j])) * V[(size_t)j * hd + d];   // (bf16 probabilities, as on the device)
         o[d] = f2bf(a / sum);
       }
       lse[(((long)b * g.nW + w) * heads + h) * n + i] = mx + std::log(sum);
@@ -1134,16 +1146,17 @@ int window_attn_forward(void*, int B, int H, int W, int ws, int shift, int heads
   return 0;
 }
 int window_attn_backward(void*, int B, int H, int W, int ws, int shift, int heads, int hd, int nwm, const void* qkv_, const float* bm,
-                         const float* scale, const void* out_, const float* lse, const void* dout_, void* dqkv_) {
+                         const float* scale, const void* out_, const float* lse, const void* dout_, void* dqkv_, int cosine) {
   WinGeom g;
   if (!win_geom(g, B, H, W, ws, shift, heads, hd, nwm)) return 2;
   const uint16_t* qkv = (const uint16_t*)qkv_; const uint16_t* out = (const uint16_t*)out_; const uint16_t* dout = (const uint16_t*)dout_;
   uint16_t* dqkv = (uint16_t*)dqkv_;
   const int n = g.n;
-  std::vector<float> P((size_t)n * n), dS((size_t)n * n), Dv(n);
+  std::vector<float> P((size_t)n * n), dS((size_t)n * n), Dv(n), Q, K, V, iq, ik, iv, gq(hd), gk(hd);
   for (int b = 0; b < B; ++b) for (int w = 0; w < g.nW; ++w) for (int h = 0; h < heads; ++h) {
     const float* bmh = bm + ((long)(w % nwm) * heads + h) * n * n;
     auto row = [&](int t) { return (long)b * g.L + win_row(g, w, t); };
+    win_rows(g, qkv, b, w, h, 0, cosine, Q, iq); win_rows(g, qkv, b, w, h, 1, cosine, K, ik); win_rows(g, qkv, b, w, h, 2, 0, V, iv);
     for (int i = 0; i < n; ++i) {
       float d = 0.f;
       for (int c = 0; c < hd; ++c) d += bf2f(out[row(i) * g.C + h * hd + c]) * bf2f(dout[row(i) * g.C + h * hd + c]);
@@ -1152,26 +1165,41 @@ int window_attn_backward(void*, int B, int H, int W, int ws, int shift, int head
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
       float a = 0.f, dp = 0.f;
       for (int c = 0; c < hd; ++c) {
-        a += bf2f(qkv[row(i) * 3 * g.C + h * hd + c]) * bf2f(qkv[row(j) * 3 * g.C + g.C + h * hd + c]);
-        dp += bf2f(dout[row(i) * g.C + h * hd + c]) * bf2f(qkv[row(j) * 3 * g.C + 2 * g.C + h * hd + c]);
+        a += Q[(size_t)i * hd + c] * K[(size_t)j * hd + c];
+        dp += bf2f(dout[row(i) * g.C + h * hd + c]) * V[(size_t)j * hd + c];
       }
       const float p = std::exp(a * scale[h] + bmh[(long)i * n + j] - lse[(((long)b * g.nW + w) * heads + h) * n + i]);
       P[(size_t)i * n + j] = bf2f(f2bf(p));
       dS[(size_t)i * n + j] = bf2f(f2bf(p * (dp - Dv[i])));
     }
-    for (int i = 0; i < n; ++i) for (int c = 0; c < hd; ++c) {
-      float a = 0.f;
-      for (int j = 0; j < n; ++j) a += dS[(size_t)i * n + j] * bf2f(qkv[row(j) * 3 * g.C + g.C + h * hd + c]);
-      dqkv[row(i) * 3 * g.C + h * hd + c] = f2bf(a * scale[h]);
-    }
-    for (int j = 0; j < n; ++j) for (int c = 0; c < hd; ++c) {
-      float ak = 0.f, av = 0.f;
-      for (int i = 0; i < n; ++i) {
-        ak += dS[(size_t)i * n + j] * bf2f(qkv[row(i) * 3 * g.C + h * hd + c]);
-        av += P[(size_t)i * n + j] * bf2f(dout[row(i) * g.C + h * hd + c]);
+    // the gradient of a (normalised) row g -> the raw row: inv * (g - xn (xn . g))   (cosine mode; identity otherwise)
+    auto through_norm = [&](std::vector<float>& gr, const std::vector<float>& X, const std::vector<float>& inv, int t) {
+      if (!cosine) return;
+      float dot = 0.f;
+      for (int c = 0; c < hd; ++c) dot += gr[c] * X[(size_t)t * hd + c];
+      for (int c = 0; c < hd; ++c) gr[c] = inv[t] * (gr[c] - X[(size_t)t * hd + c] * dot);
+    };
+    for (int i = 0; i < n; ++i) {
+      for (int c = 0; c < hd; ++c) {
+        float a = 0.f;
+        for (int j = 0; j < n; ++j) a += dS[(size_t)i * n + j] * K[(size_t)j * hd + c];
+        gq[c] = a * scale[h];
       }
-      dqkv[row(j) * 3 * g.C + g.C + h * hd + c] = f2bf(ak * scale[h]);
-      dqkv[row(j) * 3 * g.C + 2 * g.C + h * hd + c] = f2bf(av);
+      through_norm(gq, Q, iq, i);
+      for (int c = 0; c < hd; ++c) dqkv[row(i) * 3 * g.C + h * hd + c] = f2bf(gq[c]);
+    }
+    for (int j = 0; j < n; ++j) {
+      for (int c = 0; c < hd; ++c) {
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < n; ++i) {
+          ak += dS[(size_t)i * n + j] * Q[(size_t)i * hd + c];
+          av += P[(size_t)i * n + j] * bf2f(dout[row(i) * g.C + h * hd + c]);
+        }
+        gk[c] = ak * scale[h];
+        dqkv[row(j) * 3 * g.C + 2 * g.C + h * hd + c] = f2bf(av);
+      }
+      through_norm(gk, K, ik, j);
+      for (int c = 0; c < hd; ++c) dqkv[row(j) * 3 * g.C + g.C + h * hd + c] = f2bf(gk[c]);
     }
   }
   return 0;

@@ -215,9 +215,11 @@ def test_fused_window_attention_kernel_on_gpu(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("geom", [(2, 16, 16, 8, 4, 4, 24), (2, 24, 24, 12, 6, 4, 32), (3, 6, 6, 6, 0, 8, 32), (2, 8, 8, 8, 0, 3, 16), (1, 24, 12, 12, 0, 2, 8)])
-def test_window_attention_kernel_against_the_emulation(geom):
+@pytest.mark.parametrize("cosine", [False, True], ids=["dot", "cosine"])
+def test_window_attention_kernel_against_the_emulation(geom, cosine):
     """the gfx950 kernel against the host loops on identical bf16 inputs through the same C-ABI entry points: forward O and lse, backward
-    dqkv -- shifted and un-shifted windows, head widths 8 ... 32, 36 / 64 / 144-token windows, non-square maps"""
+    dqkv -- shifted and un-shifted windows, head widths 8 ... 32, 36 / 64 / 144-token windows, non-square maps; cosine: q / k rows
+    normalised inside (DGSCT_WATTN_COSINE), the gradient returned for the raw rows"""
     from build_emu import build_emu
     from dgsct_amd import ops
     from dgsct_amd._lib import Lib, default_lib
@@ -233,11 +235,18 @@ def test_window_attention_kernel_against_the_emulation(geom):
     res = {}
     for tag, lib, dev in (("emu", Lib(build_emu()), torch.device("cpu")), ("hip", default_lib(), torch.device("cuda:0"))):
         q = qkv.detach().clone().to(dev).requires_grad_(True)
-        o = ops.window_attention(q, bm.to(dev), scale.to(dev), H, W, ws, shift, heads, lib)
+        o = ops.window_attention(q, bm.to(dev), scale.to(dev) * (8.0 if cosine else 1.0), H, W, ws, shift, heads, lib, cosine=cosine)
         o.backward(dout.to(dev))
         res[tag] = (o.detach(), q.grad)
     assert _L2(res["hip"][0], res["emu"][0]) < 6e-3
     assert _L2(res["hip"][1], res["emu"][1]) < 1e-2
+    if cosine:      # against autograd through F.normalize on the CPU (fp32 evaluation of the same bf16 inputs)
+        q = qkv.float().requires_grad_(True)
+        x = q.reshape(B, H * W, 3, heads, hd)
+        qn = torch.cat([torch.nn.functional.normalize(x[:, :, :2], dim=-1), x[:, :, 2:]], dim=2).reshape(B, H * W, -1)
+        o = ops.window_attention(qn.bfloat16(), bm, scale * 8.0, H, W, ws, shift, heads, Lib(build_emu()))
+        o.backward(dout)
+        assert _L2(res["hip"][0], o) < 2e-2 and _L2(res["hip"][1], q.grad) < 4e-2
 
 
 # ---- LayerNorm (+ residual) on the library's row kernels (dgsct_layer_norm_*) -------------------------------------------
