@@ -1,4 +1,4 @@
-"""Frozen backbone blocks either side of the adapter calls (round 5: first step).
+"""Frozen backbone blocks either side of the adapter calls.
 
 The AVE layer loop (reference ``DG-SCT/AVE/nets/net_trans.py:880-916``) interleaves each adapter pair with
 
@@ -15,8 +15,14 @@ so a checkpoint loads by name, and with the signatures ``AdapterStack.forward(vi
 
 Parity: ``HTSATBlock`` is pinned against the reference class (``oracle/make_golden_backbone.py`` -> ``tests/golden/htsat_block.pt``).
 ``SwinV2Block`` restates timm==0.6.12's ``SwinTransformerV2Block`` (``requirements.txt:39``; un-vendored, not installed here, no
-reference test pins it): **parity unpinned**; ``tests/test_backbone.py`` checks its windowing / shift / mask plumbing against a
-direct per-token evaluation of the same published formulas.
+reference test pins it): **parity against timm unpinned**; ``tests/test_backbone.py`` checks its windowing / shift / mask plumbing against a
+direct per-token evaluation of the same published formulas, and the whole block (output, input gradient, 1e-5 in fp32) against an INDEPENDENT
+implementation of the same published block that is importable here -- Hugging Face transformers' ``Swinv2Layer``, parameters renamed to timm's
+layout (``oracle/make_golden_swinv2.py`` -> ``tests/golden/swinv2_block.pt``).
+
+On the GPU in bf16 (``fused=None``) the window attention of both blocks is one HIP kernel each way (``csrc/wattn.hip``; Swin-V2's q / k
+normalisation inside) and their LayerNorms (+ the post-norm residual) run on the adapter tail's row kernels (``dgsct_layer_norm_*``); the
+qkv / proj / MLP Linears and GELU stay ATen.
 """
 from __future__ import annotations
 
@@ -164,9 +170,9 @@ class HTSATBlock(nn.Module):
         self.register_buffer("attn_mask", _shift_mask(*self.input_resolution, window_size, shift_size))
 
     def _use_fused(self, x) -> bool:
-        from . import ops
         if self.fused is False or x.dtype != torch.bfloat16 or not (x.is_cuda or self._lib is not None):
             return False
+        from . import ops
         return ops.window_attention_supported(x.new_empty(1, 1, 3 * self.dim), self.window_size, self.num_heads)
 
     def forward(self, x):

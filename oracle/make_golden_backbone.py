@@ -7,7 +7,7 @@ in this repo), run on CPU, and compared with dg-sct_amd/backbone.py's ``HTSATBlo
 for an un-shifted and a shifted block (window 8 on a 16 x 16 map), and a block whose map is as large as its window.
 
 The Swin-V2 blocks of the visual backbone live in timm==0.6.12 (requirements.txt:39), which is neither vendored nor installed:
-parity unpinned, see dg-sct_amd/backbone.py.
+parity against timm unpinned (oracle/make_golden_swinv2.py pins the block against an independent implementation instead).
 """
 import ast
 import os
