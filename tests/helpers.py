@@ -21,7 +21,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def golden_names():
     """single-adapter golden cases (the stack fixture is loaded separately)"""
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.pt")))
-                  if not n.startswith(("stack_", "temporal", "fp8_", "htsat_", "ref_")))
+                  if not n.startswith(("stack_", "temporal", "fp8_", "htsat_", "swinv2_", "ref_")))
 
 
 def load_golden(name):
