@@ -533,14 +533,17 @@ def test_poisoned_buffers_at_production_shapes_bf16(shape, monkeypatch):
         assert _l2(*r[k]) < TOL_BF16, (k, _l2(*r[k]))
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["fused_attn", "wide_attn"])
 @pytest.mark.parametrize("flat", [False, True], ids=["unflat", "flat"])
-def test_stack_on_gpu_matches_reference_fixture(flat):
+def test_stack_on_gpu_matches_reference_fixture(flat, wide, monkeypatch):
     """SURVEY row a-10 on the device (net_trans.py:880-916): 12 adapters through AdapterStack with everything the benchmark
     uses switched on (two adapter streams, aux streams in forward and backward, fused residual/skip, flat parameters)
     against the reference-generated stack fixture: outputs, maps, input gradients and every parameter gradient; repeated
     to give stream-ordering bugs a chance to show."""
     from dgsct_amd import AdapterStack
     from dgsct_amd.stack import default_opt
+    if wide:        # (DGSCT_WIDE_ATTN: the num_tokens > 32 attention path for every adapter of the stack)
+        monkeypatch.setenv("DGSCT_WIDE_ATTN", "1")
     fx = load_golden("stack_2stage")
     st = AdapterStack(fx["stages"], opt=default_opt(num_tokens=4), concurrent=True)
     st.load_state_dict(fx["state0"])
@@ -588,14 +591,17 @@ def test_stack_on_gpu_matches_reference_fixture(flat):
         assert not bad, (rep, bad)
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["fused_attn", "wide_attn"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
-def test_pair_backward_equals_the_two_node_path(dtype):
+def test_pair_backward_equals_the_two_node_path(dtype, wide, monkeypatch):
     """AdapterStack's one-node path for the two adapters of a position (ops._PairFlatFn: d f = dX(own) + dY(other) formed in the
     epilogue of the product that writes dY, the two halves of each call issued around the other call's) against the two autograd
     nodes + accumulation it replaces, library against library on the same inputs: outputs and maps identical, input and parameter
     gradients equal up to the ONE bf16 rounding the fused sum no longer makes (fp32: up to summation order)."""
     from dgsct_amd import AdapterStack
     from dgsct_amd.stack import default_opt
+    if wide:        # the whole stack (two streams, deferred weight gradients, pair nodes) on the num_tokens > 32 attention path
+        monkeypatch.setenv("DGSCT_WIDE_ATTN", "1")
     fx = load_golden("stack_2stage")
     res = {}
     for pair in (False, True):
